@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward attention TFLOP/s, causal, L=4096, D=64 (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over one batch of synthetic packed qkv that is already resident
+in HBM: `flash_attention_qkv_packed(qkv[3, 128, 4096, 64] bf16, 8, 8)` per GPU (batch 8 x 16 heads;
+chunk counts = the reference heuristic for L=4096, D=64).  With N > 1 every rank owns its own 128
+groups (weak scaling, groups are independent) and the only exchange is the RCCL all-gather of O,
+double-buffered so the gather of step s overlaps the kernel of step s+1.
+
+FLOPs = 2*G*L^2*D (causal convention); roofline = MFMA, dense bf16 peak 2.5 PFLOP/s.
+The cpu_baseline leg times the oracle's dense restatement of the reference CPU path
+(flash_attention_ipu/_impl/flash_attention_qkv_packed.py:48-53) on the host cores of the same box.
+"""
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+for _p in (ROOT, ROOT / "flash-attention-ipu_amd"):
+    if str(_p) not in sys.path:
+        sys.path.insert(0, str(_p))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # name: (G per GPU, L, D, dtype, (nq, nk))
+    "cfg2": (128, 4096, 64, "bf16", (8, 8)),        # BASELINE configs[1] - the headline
+    "cfg2_f16": (128, 4096, 64, "f16", (8, 8)),
+    "cfg3": (16, 32768, 128, "bf16", (16, 16)),     # long context
+    "cfg5_shard": (256, 8192, 64, "bf16", (16, 8)),  # configs[4] per-GPU shard at 8 GPUs
+}
+PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def cpu_baseline(L, D, budget_s=12.0):
+    """Reference CPU path (dense fp32 torch, restated in oracle/) on this box's host cores."""
+    from oracle import dense_causal_attention
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    slab = 8
+    gen = torch.Generator().manual_seed(0)
+    qkv = torch.randn(3, slab, L, D, generator=gen)
+    dense_causal_attention(qkv)  # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < budget_s and len(times) < 30:
+        t0 = time.perf_counter()
+        dense_causal_attention(qkv)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    flops = 2.0 * slab * L * L * D
+    return {
+        "value": round(flops / med / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+        "sample": f"{len(times)} reps of a {slab}-group slab (of 128) at L={L}, D={D}, fp32 dense torch "
+                  f"restatement of fa.py:48-53, median {med * 1e3:.1f} ms/slab, scaled linearly in G",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of O (kernel only)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    import flash_attention_amd as fa
+    from flash_attention_amd._impl import _native
+    from flash_attention_amd.distributed import gather_output
+
+    assert _native.library_path() is not None
+    G, L, D, dname, (nq, nk) = CONFIGS[args.config]
+    dtype = DT[dname]
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    qkv = torch.randn(3, G, L, D, device=dev, generator=gen).to(dtype)
+    flops_step = 2.0 * G * L * L * D           # per GPU per step
+    plan = _native.plan(G, L, D, dtype, nq, nk)
+
+    do_gather = world > 1 and not args.no_gather
+    gathered = [torch.empty(world * G, L, D, dtype=dtype, device=dev) for _ in range(2)] if do_gather else None
+    pending = [None, None]
+
+    def step(i):
+        out = fa.flash_attention_qkv_packed(qkv, nq, nk)
+        if do_gather:
+            b = i & 1
+            if pending[b] is not None:
+                pending[b][1].wait()           # buffer b is free again (gather of step i-2 done)
+            _, work = gather_output(out, out=gathered[b], async_op=True)
+            pending[b] = (out, work)           # keep `out` alive until its gather completes
+        return out
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b][1].wait()
+                pending[b] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(i)
+    ev1.record()                                # kernels only: recorded on the launch stream before the drain
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # avg launch duration incl. launch gaps (HIP events)
+
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = t[0].item(), t[1].item()
+
+    if rank == 0:
+        total_tflops = world * flops_step * args.steps / elapsed / 1e12
+        achieved = flops_step / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = ROOT / "profiles" / "hbm_traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(args.config, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "fwd_attention_tflops_causal_L4096_D64" if args.config.startswith("cfg2") else f"fwd_attention_tflops_{args.config}",
+            "value": round(total_tflops, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dname,
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: packed qkv [3,{G},{L},{D}] {dname} per GPU, causal, "
+                                   f"num_chunks=({nq},{nk}), flash_attention_qkv_packed forward",
+                       "groups_per_gpu": G, "seq_len": L, "head_dim": D,
+                       "tile": f"{plan.block_q}x{plan.block_kv} ({plan.waves} waves)",
+                       "exchange": "rccl all-gather of O, overlapped" if do_gather else "none",
+                       "flops_per_step_per_gpu": flops_step},
+            "pct_mfma_peak": round(100.0 * total_tflops / (world * PEAK_TFLOPS), 2),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "fa_fwd_tile_kernel", "avg_launch_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes": 4 * G * L * D * 2},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(L, D)
+        elif world > 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

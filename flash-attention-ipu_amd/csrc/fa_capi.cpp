@@ -1,0 +1,191 @@
+// C ABI of libflash_attention.so - see include/flash_attention_amd.h for the contract and for the
+// reference interface (file:line) each entry point replaces.  No torch types, no exceptions, no host
+// synchronisation, no allocation: validate, pick a tile plan, enqueue one kernel on the caller's stream.
+
+#include "flash_attention_amd.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "fa_params.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int elt_size(int dtype) { return dtype == FA_DTYPE_F32 ? 4 : 2; }
+
+// num_chunks -> hardware tile.  The reference's chunk sizes (L/num_chunks, FA.cpp:193-195) are
+// upper bounds on the scheduling tile: the result is independent of them (semantic
+// contract), so a chunk larger than one workgroup can hold is subdivided into hardware tiles, and a
+// chunk that IS a hardware tile size is honoured exactly.  Tiles: 32 q rows per wave, 1..8 waves.
+// Both default tiles are 4 waves = 128 rows (3 workgroups per CU at D=64).
+int pick_waves(int64_t L, int64_t chunk_q) {
+    int64_t want = chunk_q < L ? chunk_q : L;
+    const char* env = getenv("FA_AMD_WAVES");
+    if (env && *env) {
+        int w = atoi(env);
+        if (w == 1 || w == 2 || w == 4 || w == 8) return w;
+    }
+    if (want >= 128) return 4;
+    if (want >= 64) return 2;
+    return 1;
+}
+
+bool tile_kernel_ok(int64_t D, int dtype, const void* const ptrs[4], const int64_t* const strides[4]) {
+    if (!(dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16)) return false;
+    if (!(D == 64 || D == 128)) return false;
+    for (int i = 0; i < 4; ++i) {
+        if (ptrs[i] && (reinterpret_cast<uintptr_t>(ptrs[i]) & 15)) return false;
+        if (strides[i]) {
+            for (int j = 0; j < 3; ++j)
+                if (strides[i][j] % 8) return false;   // 16-byte rows for 16-bit elements
+        }
+    }
+    return true;
+}
+
+int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, bool tile_ok, fa_plan_t* plan) {
+    if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1 (got %lld, %lld, %lld)", (long long)G, (long long)L, (long long)D);
+    if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
+    if (nq < 1 || L % nq != 0) return fail(FA_ERR_CHUNKS_Q, "sequence length %lld is not divisible by num_chunks_q=%d", (long long)L, nq);
+    if (nk < 1 || L % nk != 0) return fail(FA_ERR_CHUNKS_KV, "sequence length %lld is not divisible by num_chunks_kv=%d", (long long)L, nk);
+    if (L > (1ll << 30) || G > (1ll << 30)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30");
+    memset(plan, 0, sizeof(*plan));
+    plan->chunk_q = (int32_t)(L / nq);
+    plan->chunk_kv = (int32_t)(L / nk);
+    if (tile_ok) {
+        plan->kernel = 0;
+        plan->waves = pick_waves(L, plan->chunk_q);
+        plan->block_q = 32 * plan->waves;
+        plan->block_kv = 64;
+        const int64_t nqt = (L + plan->block_q - 1) / plan->block_q;
+        const int64_t g8 = (G + 7) / 8 * 8;
+        plan->grid = g8 * nqt;
+        plan->lds_bytes = 4 * 64 * D * 2;
+    } else {
+        if (D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic kernel supports D <= 1024 (got %lld)", (long long)D);
+        plan->kernel = 1;
+        plan->waves = 4;
+        plan->block_q = 1;
+        plan->block_kv = 1024;
+        plan->grid = G * L;
+        plan->lds_bytes = 1024 * 4 + 16 + D * 4;
+    }
+    if (plan->grid > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid of %lld workgroups exceeds 2^31-1", (long long)plan->grid);
+    return FA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fa_abi_version(void) { return FA_ABI_VERSION; }
+
+const char* fa_last_error(void) { return g_err; }
+
+const char* fa_error_string(int code) {
+    switch (code) {
+        case FA_OK: return "ok";
+        case FA_ERR_NULL_POINTER: return "null pointer";
+        case FA_ERR_BAD_SHAPE: return "bad shape";
+        case FA_ERR_BAD_DTYPE: return "bad dtype";
+        case FA_ERR_CHUNKS_Q: return "sequence length not divisible by num_chunks_q";
+        case FA_ERR_CHUNKS_KV: return "sequence length not divisible by num_chunks_kv";
+        case FA_ERR_MISALIGNED: return "misaligned pointer or stride";
+        case FA_ERR_NOT_CAUSAL: return "only causal attention is supported";
+        case FA_ERR_LAUNCH: return "kernel launch failed";
+        case FA_ERR_BAD_STRIDE: return "bad stride";
+        case FA_ERR_TOO_LARGE: return "problem too large";
+        default: return "unknown error";
+    }
+}
+
+int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_shape[3]) {
+    if (!qkv_shape || !out_shape) return fail(FA_ERR_NULL_POINTER, "null shape pointer");
+    if (rank != 4) return fail(FA_ERR_BAD_SHAPE, "qkv must have 4 dimensions (got %d)", rank);
+    if (qkv_shape[0] != 3) return fail(FA_ERR_BAD_SHAPE, "qkv must have size 3 at dimension 0 (got %lld)", (long long)qkv_shape[0]);
+    out_shape[0] = qkv_shape[1];
+    out_shape[1] = qkv_shape[2];
+    out_shape[2] = qkv_shape[3];
+    return FA_OK;
+}
+
+int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q, int32_t num_chunks_kv, fa_plan_t* plan) {
+    if (!plan) return fail(FA_ERR_NULL_POINTER, "null plan pointer");
+    const void* const ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
+    const int64_t* const strides[4] = {nullptr, nullptr, nullptr, nullptr};
+    return make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_kernel_ok(D, dtype, ptrs, strides), plan);
+}
+
+int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+           int64_t G, int64_t L, int64_t D, int64_t heads,
+           const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
+           int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,
+           float softmax_scale, int32_t causal, void* stream) {
+    if (!q || !k || !v || !out) return fail(FA_ERR_NULL_POINTER, "q, k, v and out must be non-null");
+    if (!q_strides || !k_strides || !v_strides || !o_strides) return fail(FA_ERR_NULL_POINTER, "stride arrays must be non-null");
+    if (!causal) return fail(FA_ERR_NOT_CAUSAL, "only causal attention is supported (reference: sdpa.py:29-32)");
+    if (heads < 1 || (G >= 1 && G % heads != 0)) return fail(FA_ERR_BAD_SHAPE, "G=%lld must be a positive multiple of heads=%lld", (long long)G, (long long)heads);
+    const void* const ptrs[4] = {q, k, v, out};
+    const int64_t* const strides[4] = {q_strides, k_strides, v_strides, o_strides};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j)
+            if (strides[i][j] < 0) return fail(FA_ERR_BAD_STRIDE, "negative strides are not supported");
+    if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
+    for (int i = 0; i < 4; ++i)
+        if (reinterpret_cast<uintptr_t>(ptrs[i]) % elt_size(dtype)) return fail(FA_ERR_MISALIGNED, "pointer %d is not element aligned", i);
+
+    fa_plan_t plan;
+    const bool tile_ok = tile_kernel_ok(D, dtype, ptrs, strides);
+    int rc = make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_ok, &plan);
+    if (rc != FA_OK) return rc;
+
+    fa::FwdParams p;
+    p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse;
+    p.q_sb = q_strides[0]; p.q_sh = q_strides[1]; p.q_sl = q_strides[2];
+    p.k_sb = k_strides[0]; p.k_sh = k_strides[1]; p.k_sl = k_strides[2];
+    p.v_sb = v_strides[0]; p.v_sh = v_strides[1]; p.v_sl = v_strides[2];
+    p.o_sb = o_strides[0]; p.o_sh = o_strides[1]; p.o_sl = o_strides[2];
+    p.G = (int32_t)G;
+    p.G8 = (int32_t)((G + 7) / 8 * 8);
+    p.H = (int32_t)heads;
+    p.L = (int32_t)L;
+    p.D = (int32_t)D;
+    p.nq_tiles = plan.kernel == 0 ? (int32_t)((L + plan.block_q - 1) / plan.block_q) : 0;
+    const char* sched = getenv("FA_AMD_SCHED");
+    p.sched = (sched && sched[0] == '1') ? 1 : 0;
+    p.scale = softmax_scale;
+    p.scale_log2 = softmax_scale * 1.4426950408889634f;
+
+    hipError_t e = plan.kernel == 0 ? fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream)
+                                    : fa::launch_fwd_generic(p, dtype, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
+int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,
+                      int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, void* stream) {
+    if (!qkv || !out) return fail(FA_ERR_NULL_POINTER, "qkv and out must be non-null");
+    if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1");
+    if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
+    const int64_t es = elt_size(dtype);
+    const int64_t strides[3] = {L * D, 0, D};
+    const char* base = static_cast<const char*>(qkv);
+    return fa_fwd(base, base + G * L * D * es, base + 2 * G * L * D * es, out, lse, G, L, D, 1,
+                  strides, strides, strides, strides, num_chunks_q, num_chunks_kv, dtype, 1.0f, 1, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,443 @@
+// FlashAttention forward for MI355X (gfx950 / CDNA4) - hand-written HIP, no compatibility layers.
+//
+// Replaces the whole L2-L4 stack of the reference forward (the Poplar program built by
+// flashAttentionQKVPackedWithStash, flash_attention_ipu/cpp/flash_attention_qkv_packed.cpp:175-334:
+// dynamicSlice + matMulGrouped + ~12 elementwise/reduce programs + matMulGroupedAcc per block)
+// with ONE fused kernel:
+//
+//   * one workgroup = NWAVES wavefronts = one (group g, q-tile) of BQ = 32*NWAVES query rows;
+//     each wave owns 32 query rows and keeps Q^T fragments, the O^T accumulator (fp32), the running
+//     max m and running sum l in VGPRs for the whole kv sweep;
+//   * K/V tiles of 64 keys stream HBM -> VGPR -> LDS (double buffered, loads issued before the
+//     tile's compute and committed after it: one barrier per tile);
+//   * S^T = K Q^T and O^T += V^T P^T run on v_mfma_f32_32x32x16_{bf16,f16}.  Computing the
+//     TRANSPOSED products puts a query row on a lane: the 32x32 accumulator of S^T holds 16 keys of
+//     one query per lane, so the row max/sum are in-lane plus ONE v_permlane32_swap, the O rescale
+//     is a per-lane scalar, and P^T is already in B-operand layout for the PV MFMA (no LDS round
+//     trip for P);
+//   * K is read from an XOR-swizzled row-major LDS image with ds_read_b128 (conflict-free), V from
+//     an [d/32][key/8][8][32] image with ds_read_b64_tr_b16 (hardware transpose, conflict-free);
+//   * the causal mask is an index predicate applied only on diagonal tiles; tiles entirely above the
+//     diagonal are never visited (the reference's doBlock, FA.cpp:244) and the reference's cyclic
+//     mask-block machinery (FA.cpp:47-173) is not needed;
+//   * softmax uses exp2 with the scale folded (p = 2^(s*c - m*c), c = scale*log2 e).
+//
+// A second, generic kernel covers every other shape/dtype (fp32, D not in {64,128}, unaligned
+// rows): one workgroup per query row, fp32 arithmetic.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fa_params.h"
+
+namespace fa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Elt;
+template <> struct Elt<__bf16> {
+    using vec8 = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Elt<_Float16> {
+    using vec8 = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// fmaxf() on MFMA results makes hipcc emit a canonicalising v_max_f32 x,x per operand; the scores are
+// never signalling NaNs, so take the max with single instructions.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float max2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// max over both 32-lane halves, result in every lane (one v_permlane32_swap).
+__device__ __forceinline__ float half_swap_max(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return max2(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA tile kernel.  T in {__bf16, _Float16}, D in {64, 128}, NWAVES in {1, 2, 4, 8}.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParams p) {
+    using E = Elt<T>;
+    using vec8 = typename E::vec8;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    constexpr int NT = NWAVES * 64;
+    constexpr int BQ = NWAVES * 32;
+    constexpr int BK = 64;
+    constexpr int ROWB = D * 2;           // bytes per K row in LDS
+    constexpr int TILE_B = BK * ROWB;     // bytes per K (or V) tile
+    constexpr int CHUNKS = TILE_B / 16;   // 16-byte chunks per tile
+    constexpr int CPT = CHUNKS / NT;      // chunks per thread per tile
+    constexpr int CPR = D / 8;            // chunks per row
+    constexpr int KS = D / 16;            // k-steps of the QK^T contraction
+    constexpr int DT = D / 32;            // 32-wide d tiles of O^T
+    static_assert(CHUNKS % NT == 0, "tile must split evenly over the workgroup");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B];  // K0 K1 V0 V1
+
+    // ---- which (group, q-tile) is this workgroup?  Blocks b and b+8 share an XCD (round-robin
+    // dispatch), so an XCD walks whole groups, heaviest q-tile first: K/V of a group stay in that
+    // XCD's L2 while its q-tiles run, and the causal tail is made of the light tiles.
+    const int b = blockIdx.x;
+    const int nq = p.nq_tiles;
+    int g, qi;
+    if (p.sched == 0) {
+        const int xcd = b & 7, slot = b >> 3;
+        const int gl = slot / nq;
+        qi = nq - 1 - (slot - gl * nq);
+        g = gl * 8 + xcd;
+    } else {  // heaviest-first over the whole grid (no L2 grouping)
+        qi = nq - 1 - b / p.G8;
+        g = b % p.G8;
+    }
+    if (g >= p.G) return;
+
+    const int L = p.L;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int bb = g / p.H, hh = g - bb * p.H;
+    const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
+    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
+    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+
+    const int q_row0 = qi * BQ + wave * 32;   // first query row of this wave
+    const int qrow = q_row0 + r;              // this lane's query row (both halves hold the same row)
+    const bool wave_active = q_row0 < L;
+
+    // ---- Q^T fragments (B operand of S^T = K Q^T): lane (r,h) holds Q[qrow][16ks + 8h + 0..7]
+    vec8 qf[KS];
+    {
+        const int qr = qrow < L ? qrow : L - 1;
+        const T* qp = qg + (int64_t)qr * p.q_sl + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const vec8*)(qp + 16 * ks);
+    }
+
+    // ---- per-thread staging geometry (tile-invariant)
+    int ld_key[CPT], ld_ch[CPT];
+    int st_k[CPT], st_v[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * NT;
+        const int key = c / CPR, ch = c % CPR;
+        ld_key[i] = key;
+        ld_ch[i] = ch;
+        const int sw = (D == 64) ? ((key >> 1) & 7) : (key & 15);
+        st_k[i] = key * ROWB + ((ch ^ sw) << 4);
+        st_v[i] = (ch >> 2) * (BK * 64) + (key >> 3) * 512 + (key & 7) * 64 + (ch & 3) * 16;
+    }
+
+    // ---- LDS read addresses (tile-invariant, per lane)
+    // K: row (32kb + r), chunk (2ks + h) ^ swz(row)
+    int k_rd[KS];
+    {
+        const int sw = (D == 64) ? ((r >> 1) & 7) : (r & 15);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * ROWB + (((2 * ks + h) ^ sw) << 4);
+    }
+    // V (transposed read): group gq = lane>>4 -> h = gq>>1, 16-col half c16 = gq&1; in-group lane
+    // 4*q4 + pp supplies row (4h + q4) of the 8-key block, cols 4pp..4pp+3 of the 16-col half.
+    const int v_rd = (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    const int n_tiles = (kv_end + BK - 1) / BK;
+
+    u32x4 kreg[CPT], vreg[CPT];
+    // rows past L are causally masked for every stored query row: clamping keeps the loads in bounds
+#define FA_ISSUE_LOADS(T_)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                        \
+        int krow = (T_) * BK + ld_key[i];                                                    \
+        krow = krow < L ? krow : L - 1;                                                      \
+        kreg[i] = *(const u32x4*)(kg + (int64_t)krow * p.k_sl + ld_ch[i] * 8);               \
+        vreg[i] = *(const u32x4*)(vg + (int64_t)krow * p.v_sl + ld_ch[i] * 8);               \
+    }
+#define FA_COMMIT_LOADS(BUF_)                                                                \
+    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                        \
+        *(u32x4*)(smem + (BUF_) * TILE_B + st_k[i]) = kreg[i];                               \
+        *(u32x4*)(smem + (2 + (BUF_)) * TILE_B + st_v[i]) = vreg[i];                         \
+    }
+
+    // ---- running state
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    float m = -INFINITY;   // running row max (raw logits)
+    float l = 0.f;         // running row sum over THIS half's keys (halves are added in the epilogue)
+    const float c = p.scale_log2;
+
+    FA_ISSUE_LOADS(0)
+    FA_COMMIT_LOADS(0)
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        const int kv0 = t * BK;
+        if (t + 1 < n_tiles) { FA_ISSUE_LOADS(t + 1) }
+
+        if (wave_active && kv0 <= q_row0 + 31) {
+            const unsigned char* kb_ = smem + buf * TILE_B;
+            const unsigned char* vb_ = smem + (2 + buf) * TILE_B;
+
+            // ---- S^T = K Q^T : two 32-key blocks
+            f32x16 s0, s1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const vec8 k0 = *(const vec8*)(kb_ + k_rd[ks]);
+                const vec8 k1 = *(const vec8*)(kb_ + 32 * ROWB + k_rd[ks]);
+                s0 = E::mfma(k0, qf[ks], s0);
+                s1 = E::mfma(k1, qf[ks], s1);
+            }
+
+            // ---- causal predicate, diagonal tiles only (wave-uniform branch)
+            if (kv0 + BK - 1 > q_row0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (key > qrow) s0[e] = -INFINITY;
+                    if (key + 32 > qrow) s1[e] = -INFINITY;
+                }
+            }
+
+            // ---- online softmax (row = lane; keys = registers x 2 halves)
+            float mx = max2(s0[0], s1[0]);
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = max3(mx, s0[e], s1[e]);
+            mx = half_swap_max(mx);
+            const float m_new = max2(m, mx);
+            const float alpha = fast_exp2((m - m_new) * c);
+            const float mc = m_new * c;
+            m = m_new;
+            float ls = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -mc));
+                s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -mc));
+                ls += s0[e];
+                ls += s1[e];
+            }
+            l = l * alpha + ls;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+            }
+
+            // ---- P^T fragments (B operand of O^T += V^T P^T): registers 8s..8s+7 of each block
+            vec8 pf[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pf[0][j] = (T)s0[j];
+                pf[1][j] = (T)s0[8 + j];
+                pf[2][j] = (T)s1[j];
+                pf[3][j] = (T)s1[8 + j];
+            }
+
+            // ---- O^T += V^T P^T
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const unsigned char* vp = vb_ + dt * (BK * 64) + kk * 1024 + v_rd;
+                    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (i16x4 __attribute__((address_space(3)))*)(vp));
+                    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (i16x4 __attribute__((address_space(3)))*)(vp + 512));
+                    const i16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[dt] = E::mfma(__builtin_bit_cast(vec8, v8), pf[kk], o[dt]);
+                }
+            }
+        }
+
+        if (t + 1 < n_tiles) { FA_COMMIT_LOADS(buf ^ 1) }
+        __syncthreads();
+    }
+
+    // ---- epilogue: O /= l, optional LSE, store
+    if (!wave_active || qrow >= L) return;
+    const float lt = half_swap_sum(l);
+    const float inv = 1.0f / lt;
+    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)qrow * p.o_sl;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            vec4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (T)(o[dt][4 * rg + j] * inv);
+            *(vec4*)(og + 32 * dt + 8 * rg + 4 * h) = w;
+        }
+    }
+    if (p.lse != nullptr && h == 0) {
+        // LSE of the scaled logits in natural log units: scale*m + ln(l)   (FA.cpp:316)
+        p.lse[(int64_t)g * L + qrow] = m * p.scale + __logf(lt);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel: any D, any L, fp32/bf16/f16 I/O, fp32 arithmetic.  One workgroup per query row.
+// Keys are processed in chunks of GEN_CHUNK: scores -> chunk max -> online rescale -> P in LDS ->
+// threads over d accumulate O.  Correctness path for odd shapes (reference tests use L=6, D=2,
+// tests/cpp/test_flash_attention.cpp:245-251), not a performance path.
+// ---------------------------------------------------------------------------------------------
+constexpr int GEN_THREADS = 256;
+constexpr int GEN_CHUNK = 1024;
+constexpr int GEN_MAXD_PER_THREAD = 4;   // D <= 1024
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+
+__device__ __forceinline__ float block_reduce(float x, float* red, bool is_max) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float y = __shfl_xor(x, off, 64);
+        x = is_max ? fmaxf(x, y) : x + y;
+    }
+    __syncthreads();   // red[] reuse
+    if (lane == 0) red[w] = x;
+    __syncthreads();
+    float rcc = red[0];
+#pragma unroll
+    for (int i = 1; i < GEN_THREADS / 64; ++i) rcc = is_max ? fmaxf(rcc, red[i]) : rcc + red[i];
+    return rcc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(GEN_THREADS) void fa_fwd_generic_kernel(const FwdParams p) {
+    __shared__ float pbuf[GEN_CHUNK];
+    __shared__ float red[GEN_THREADS / 64];
+    extern __shared__ float qrow_s[];   // D floats
+
+    const int L = p.L, D = p.D;
+    const int g = blockIdx.x / L;
+    const int row = blockIdx.x - g * L;
+    const int bb = g / p.H, hh = g - bb * p.H;
+    const T* qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh + (int64_t)row * p.q_sl;
+    const T* kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
+    const T* vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+    const int tid = threadIdx.x;
+
+    for (int d = tid; d < D; d += GEN_THREADS) qrow_s[d] = to_f32(qg[d]);
+    __syncthreads();
+
+    float oacc[GEN_MAXD_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < GEN_MAXD_PER_THREAD; ++i) oacc[i] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int nkeys = row + 1;   // causal: keys 0..row
+    (void)L;
+
+    for (int k0 = 0; k0 < nkeys; k0 += GEN_CHUNK) {
+        const int kn = nkeys - k0 < GEN_CHUNK ? nkeys - k0 : GEN_CHUNK;
+        float mx = -INFINITY;
+        for (int cidx = tid; cidx < kn; cidx += GEN_THREADS) {
+            const T* kp = kg + (int64_t)(k0 + cidx) * p.k_sl;
+            float acc = 0.f;
+            for (int d = 0; d < D; ++d) acc = __builtin_fmaf(qrow_s[d], to_f32(kp[d]), acc);
+            acc *= p.scale;
+            pbuf[cidx] = acc;
+            mx = fmaxf(mx, acc);
+        }
+        mx = block_reduce(mx, red, true);
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __expf(m - m_new);   // exp(-inf) = 0 on the first chunk
+        m = m_new;
+        float ls = 0.f;
+        for (int cidx = tid; cidx < kn; cidx += GEN_THREADS) {
+            const float e = __expf(pbuf[cidx] - m_new);
+            pbuf[cidx] = e;
+            ls += e;
+        }
+        ls = block_reduce(ls, red, false);   // barriers inside also publish pbuf
+        l = l * alpha + ls;
+#pragma unroll
+        for (int i = 0; i < GEN_MAXD_PER_THREAD; ++i) {
+            const int d = tid + i * GEN_THREADS;
+            if (d < D) {
+                float acc = oacc[i] * alpha;
+                const T* vp = vg + (int64_t)k0 * p.v_sl + d;
+                for (int cidx = 0; cidx < kn; ++cidx) acc = __builtin_fmaf(pbuf[cidx], to_f32(vp[(int64_t)cidx * p.v_sl]), acc);
+                oacc[i] = acc;
+            }
+        }
+        __syncthreads();   // pbuf is rewritten by the next chunk
+    }
+
+    T* og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)row * p.o_sl;
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int i = 0; i < GEN_MAXD_PER_THREAD; ++i) {
+        const int d = tid + i * GEN_THREADS;
+        if (d < D) og[d] = (T)(oacc[i] * inv);
+    }
+    if (p.lse != nullptr && tid == 0) p.lse[(int64_t)g * L + row] = m + __logf(l);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int NWAVES>
+static hipError_t launch_tile(const FwdParams& p, hipStream_t stream) {
+    const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
+    hipLaunchKernelGGL((fa_fwd_tile_kernel<T, D, NWAVES>), dim3((unsigned)grid), dim3(NWAVES * 64), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <typename T, int D>
+static hipError_t launch_tile_w(const FwdParams& p, int waves, hipStream_t stream) {
+    switch (waves) {
+        case 8: return launch_tile<T, D, 8>(p, stream);
+        case 4: return launch_tile<T, D, 4>(p, stream);
+        case 2: return launch_tile<T, D, 2>(p, stream);
+        default: return launch_tile<T, D, 1>(p, stream);
+    }
+}
+
+hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
+    if (dtype == 1) {
+        return p.D == 64 ? launch_tile_w<__bf16, 64>(p, waves, stream) : launch_tile_w<__bf16, 128>(p, waves, stream);
+    }
+    return p.D == 64 ? launch_tile_w<_Float16, 64>(p, waves, stream) : launch_tile_w<_Float16, 128>(p, waves, stream);
+}
+
+hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream) {
+    dim3 grid((unsigned)((int64_t)p.L * p.G));
+    const size_t dyn = (size_t)p.D * sizeof(float);
+    if (dtype == 1) hipLaunchKernelGGL((fa_fwd_generic_kernel<__bf16>), grid, dim3(GEN_THREADS), dyn, stream, p);
+    else if (dtype == 0) hipLaunchKernelGGL((fa_fwd_generic_kernel<_Float16>), grid, dim3(GEN_THREADS), dyn, stream, p);
+    else hipLaunchKernelGGL((fa_fwd_generic_kernel<float>), grid, dim3(GEN_THREADS), dyn, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace fa

@@ -1,0 +1,131 @@
+"""ctypes binding of libflash_attention.so (the C ABI declared in include/flash_attention_amd.h).
+
+Library discovery follows the reference loader (flash_attention_ipu/__init__.py:4-23): first
+`<pkg-parent>/build/libflash_attention.so`, then `<pkg-parent>/libflash_attention<EXT_SUFFIX>`;
+`FLASH_ATTENTION_AMD_LIB` overrides both.  There is NO fallback: a missing library is an
+ImportError at import time, and a GPU tensor can only be served by the HIP kernels in it.
+"""
+
+import ctypes
+import os
+import pathlib
+import sysconfig
+
+import torch
+
+_LIB = None
+_LIB_PATH = None
+
+FA_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+ABI_VERSION = 1
+
+
+class FaPlan(ctypes.Structure):
+    _fields_ = [
+        ("kernel", ctypes.c_int32),
+        ("block_q", ctypes.c_int32),
+        ("block_kv", ctypes.c_int32),
+        ("waves", ctypes.c_int32),
+        ("chunk_q", ctypes.c_int32),
+        ("chunk_kv", ctypes.c_int32),
+        ("grid", ctypes.c_int64),
+        ("lds_bytes", ctypes.c_int64),
+    ]
+
+
+def candidate_paths():
+    root = pathlib.Path(__file__).resolve().parent.parent.parent
+    name = "libflash_attention.so"
+    paths = []
+    env = os.environ.get("FLASH_ATTENTION_AMD_LIB")
+    if env:
+        paths.append(pathlib.Path(env))
+    paths.append(root / "build" / name)
+    paths.append((root / name).with_suffix(sysconfig.get_config_vars().get("EXT_SUFFIX") or ".so"))
+    return paths
+
+
+def load_native_library():
+    global _LIB, _LIB_PATH
+    if _LIB is not None:
+        return _LIB
+    tried = candidate_paths()
+    for path in tried:
+        if path.exists():
+            lib = ctypes.CDLL(str(path))
+            _declare(lib)
+            if lib.fa_abi_version() != ABI_VERSION:
+                raise ImportError(f"{path}: ABI version {lib.fa_abi_version()} != {ABI_VERSION}")
+            _LIB, _LIB_PATH = lib, path
+            return lib
+    raise ImportError(f"Cannot find libflash_attention.so - tried {[str(p) for p in tried]}")
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def _declare(lib):
+    i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    lib.fa_abi_version.restype = ctypes.c_int
+    lib.fa_abi_version.argtypes = []
+    lib.fa_last_error.restype = ctypes.c_char_p
+    lib.fa_last_error.argtypes = []
+    lib.fa_error_string.restype = ctypes.c_char_p
+    lib.fa_error_string.argtypes = [ctypes.c_int]
+    lib.fa_infer_output_shape.restype = ctypes.c_int
+    lib.fa_infer_output_shape.argtypes = [p64, i32, p64]
+    lib.fa_plan.restype = ctypes.c_int
+    lib.fa_plan.argtypes = [i64, i64, i64, i32, i32, i32, ctypes.POINTER(FaPlan)]
+    lib.fa_fwd.restype = ctypes.c_int
+    lib.fa_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, p64, p64, p64, p64,
+                           i32, i32, i32, ctypes.c_float, i32, vp]
+    lib.fa_fwd_qkv_packed.restype = ctypes.c_int
+    lib.fa_fwd_qkv_packed.argtypes = [vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
+
+
+def _raise(rc):
+    lib = load_native_library()
+    msg = lib.fa_last_error().decode() or lib.fa_error_string(rc).decode()
+    if rc in (-2, -3, -4, -5, -7, -9):
+        raise ValueError(f"flash_attention_amd: {msg}")
+    raise RuntimeError(f"flash_attention_amd: {msg} (code {rc})")
+
+
+def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv) -> FaPlan:
+    lib = load_native_library()
+    out = FaPlan()
+    rc = lib.fa_plan(G, L, D, FA_DTYPE[dtype], num_chunks_q, num_chunks_kv, ctypes.byref(out))
+    if rc != 0:
+        _raise(rc)
+    return out
+
+
+def _strides3(arr):
+    return (ctypes.c_int64 * 3)(*arr)
+
+
+def fwd_packed(qkv: torch.Tensor, out: torch.Tensor, lse, num_chunks_q: int, num_chunks_kv: int):
+    """qkv: contiguous CUDA [3,G,L,D]; out: contiguous [G,L,D]; lse: None or fp32 [G,L]."""
+    lib = load_native_library()
+    _, G, L, D = qkv.shape
+    with torch.cuda.device(qkv.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.fa_fwd_qkv_packed(qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+                                   G, L, D, num_chunks_q, num_chunks_kv, FA_DTYPE[qkv.dtype], stream)
+    if rc != 0:
+        _raise(rc)
+
+
+def fwd_strided(q, k, v, out, lse, G, L, D, heads, qs, ks, vs, os_, num_chunks_q, num_chunks_kv, scale):
+    """Strided three-view forward: see fa_fwd in include/flash_attention_amd.h."""
+    lib = load_native_library()
+    with torch.cuda.device(q.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                        lse.data_ptr() if lse is not None else None, G, L, D, heads,
+                        _strides3(qs), _strides3(ks), _strides3(vs), _strides3(os_),
+                        num_chunks_q, num_chunks_kv, FA_DTYPE[q.dtype], float(scale), 1, stream)
+    if rc != 0:
+        _raise(rc)

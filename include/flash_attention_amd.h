@@ -1,0 +1,118 @@
+/*
+ * flash_attention_amd.h - C ABI of libflash_attention.so (MI355X / gfx950 FlashAttention forward).
+ *
+ * This is the drop-in boundary for the ONE hot path of graphcore-research/flash-attention-ipu:
+ * the forward of `flash_attention_qkv_packed` and the causal SDPA override.  Every entry point is
+ * `extern "C"`, takes plain pointers and sizes (device pointers unless stated), owns no memory,
+ * never throws and never synchronises the host: kernels are enqueued on the caller's HIP stream.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo):
+ *
+ *   fa_fwd_qkv_packed   <- poptorch.custom_op("FlashAttentionQKVPacked", "ai.graphcore", v1,
+ *                          inputs=[qkv], attributes={num_chunks_q, num_chunks_kv})
+ *                          flash_attention_ipu/_impl/flash_attention_qkv_packed.py:39-46, which PopART
+ *                          resolves to FlashAttentionQKVPackedOpx::grow -> flashAttentionQKVPacked
+ *                          flash_attention_ipu/cpp/flash_attention_qkv_packed.cpp:618-641, :336-346
+ *   fa_fwd              <- flashAttentionQKVPackedWithStash (output + logSumExp stash)
+ *                          flash_attention_ipu/cpp/flash_attention_qkv_packed.cpp:175-334 and
+ *                          flash_attention_qkv_packed.hpp:10-21; takes q/k/v as three strided views so
+ *                          the SDPA override (scaled_dot_product_attention.py:55-59) needs no
+ *                          torch.stack copy, and takes the softmax scale as a scalar instead of a
+ *                          pre-multiplied q.
+ *   fa_infer_output_shape <- FlashAttentionQKVPackedOp::setup() shape inference [3,G,L,D]->[G,L,D]
+ *                          flash_attention_qkv_packed.cpp:571-577
+ *   fa_plan             <- the reference's (num_chunks_q, num_chunks_kv) -> chunk-size arithmetic
+ *                          flash_attention_qkv_packed.cpp:193-195 (chunkedQueryLen / chunkedKVLen);
+ *                          reports the hardware tile this library maps the request to.
+ *   fa_abi_version / fa_last_error / fa_error_string
+ *                       <- (no reference counterpart: the reference's .so ABI is static-init
+ *                          registration only, flash_attention_ipu/__init__.py:4-23; its errors are C++
+ *                          asserts, flash_attention_qkv_packed.cpp:183,190-191)
+ *
+ * Semantics (identical to the reference):
+ *   O[g] = softmax_rows(scale * Q[g] K[g]^T + M) V[g],  M[r,c] = -inf-equivalent for c > r (causal);
+ *   LSE[g,r] = log sum_c exp(scale * S[r,c]).  `scale` is 1.0 for the packed op (no 1/sqrt(D) inside
+ *   the op, flash_attention_qkv_packed.cpp:254); the SDPA override passes D^-0.5.
+ *   The result does not depend on num_chunks_q / num_chunks_kv.
+ */
+#ifndef FLASH_ATTENTION_AMD_H
+#define FLASH_ATTENTION_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_ABI_VERSION 1
+
+/* element types (reference allows FLOAT16 and FLOAT, FA.cpp:609; bf16 is new here) */
+enum { FA_DTYPE_F16 = 0, FA_DTYPE_BF16 = 1, FA_DTYPE_F32 = 2 };
+
+/* return codes */
+enum {
+    FA_OK = 0,
+    FA_ERR_NULL_POINTER = -1,
+    FA_ERR_BAD_SHAPE = -2,          /* G, L or D < 1 */
+    FA_ERR_BAD_DTYPE = -3,
+    FA_ERR_CHUNKS_Q = -4,           /* L % num_chunks_q != 0   (FA.cpp:190, fa.py:28-31) */
+    FA_ERR_CHUNKS_KV = -5,          /* L % num_chunks_kv != 0  (FA.cpp:191, fa.py:32-35) */
+    FA_ERR_MISALIGNED = -6,         /* MFMA path needs 16-byte aligned rows */
+    FA_ERR_NOT_CAUSAL = -7,         /* the reference path is causal only (sdpa.py:29-32) */
+    FA_ERR_LAUNCH = -8,             /* hipGetLastError() after the launch */
+    FA_ERR_BAD_STRIDE = -9,
+    FA_ERR_TOO_LARGE = -10          /* grid or offsets exceed what the kernel indexes */
+};
+
+/* hardware tile the request was mapped to (fa_plan) */
+typedef struct fa_plan_t {
+    int32_t kernel;      /* 0 = MFMA tile kernel (bf16/f16, D in {64,128}), 1 = generic kernel */
+    int32_t block_q;     /* q rows per workgroup */
+    int32_t block_kv;    /* keys per LDS tile */
+    int32_t waves;       /* wavefronts per workgroup */
+    int32_t chunk_q;     /* L / num_chunks_q  : the reference's chunkedQueryLen */
+    int32_t chunk_kv;    /* L / num_chunks_kv : the reference's chunkedKVLen */
+    int64_t grid;        /* workgroups launched */
+    int64_t lds_bytes;   /* LDS per workgroup */
+} fa_plan_t;
+
+int fa_abi_version(void);
+
+/* thread-local text of the last failure on this thread ("" if none) */
+const char* fa_last_error(void);
+const char* fa_error_string(int code);
+
+/* [3,G,L,D] -> [G,L,D]; returns FA_OK or FA_ERR_BAD_SHAPE (rank != 4 or dim0 != 3). */
+int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_shape[3]);
+
+/* Host-only: which kernel/tile would serve this request. No GPU needed. */
+int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q, int32_t num_chunks_kv,
+            fa_plan_t* plan);
+
+/*
+ * Forward on three strided views.  All pointers are device pointers.
+ *   q,k,v : element (g, r, d) at  base + (g / heads) * strides[0] + (g % heads) * strides[1]
+ *           + r * strides[2] + d   (strides in ELEMENTS; innermost dimension contiguous)
+ *   out   : same addressing with o_strides; dtype = input dtype
+ *   lse   : optional float32 [G, L] contiguous (NULL to skip)  - the reference's logSumExp stash
+ *   heads : inner group count for the 2-level group stride (1 => strides[1] unused, strides[0] is
+ *           the group stride)
+ *   softmax_scale : multiplies the logits (1.0f reproduces the packed op)
+ *   causal : must be 1
+ *   stream : hipStream_t (NULL = default stream)
+ */
+int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+           int64_t G, int64_t L, int64_t D, int64_t heads,
+           const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+           const int64_t o_strides[3],
+           int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,
+           float softmax_scale, int32_t causal, void* stream);
+
+/* Forward on a contiguous packed qkv [3,G,L,D] -> out [G,L,D] (scale 1, causal). */
+int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,
+                      int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASH_ATTENTION_AMD_H */

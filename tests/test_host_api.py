@@ -1,0 +1,192 @@
+"""CPU tests of the host-side mirror of the reference interface and of the C-ABI library
+(loads, exports every declared symbol, validates arguments).  No GPU compute calls."""
+
+import ctypes
+import json
+import pathlib
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import flash_attention_amd
+
+    return flash_attention_amd
+
+
+@pytest.fixture(scope="module")
+def native():
+    from flash_attention_amd._impl import _native
+
+    return _native
+
+
+@pytest.fixture(scope="module")
+def meta(golden_dir):
+    return json.loads((golden_dir / "g6_meta.json").read_text())
+
+
+def test_library_exports_every_declared_symbol(native):
+    header = (ROOT / "include" / "flash_attention_amd.h").read_text()
+    body = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(fa_[a-z_0-9]+)\s*\(", body))
+    assert {"fa_fwd", "fa_fwd_qkv_packed", "fa_plan", "fa_abi_version", "fa_last_error",
+            "fa_error_string", "fa_infer_output_shape"} <= declared
+    lib = native.load_native_library()
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/flash_attention_amd.h but not exported"
+    assert lib.fa_abi_version() == 1
+    assert native.library_path().name == "libflash_attention.so"
+
+
+def test_header_is_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 1;}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
+
+
+def test_c_abi_argument_validation(native):
+    lib = native.load_native_library()
+    shape = (ctypes.c_int64 * 4)(3, 8, 128, 64)
+    out = (ctypes.c_int64 * 3)()
+    assert lib.fa_infer_output_shape(shape, 4, out) == 0 and list(out) == [8, 128, 64]  # FA.cpp:571-577
+    assert lib.fa_infer_output_shape(shape, 3, out) == -2
+    bad = (ctypes.c_int64 * 4)(2, 8, 128, 64)
+    assert lib.fa_infer_output_shape(bad, 4, out) == -2 and b"size 3" in lib.fa_last_error()
+    plan = native.FaPlan()
+    assert lib.fa_plan(1, 6, 2, 2, 4, 1, ctypes.byref(plan)) == -4   # L % nq  (FA.cpp:190)
+    assert lib.fa_plan(1, 6, 2, 2, 1, 4, ctypes.byref(plan)) == -5   # L % nk  (FA.cpp:191)
+    assert lib.fa_plan(0, 6, 2, 2, 1, 1, ctypes.byref(plan)) == -2
+    assert lib.fa_plan(1, 6, 2, 7, 1, 1, ctypes.byref(plan)) == -3
+    assert lib.fa_fwd_qkv_packed(None, None, None, 1, 8, 64, 1, 1, 1, None) == -1
+    assert lib.fa_error_string(-4).decode().endswith("num_chunks_q")
+
+
+def test_plan_maps_chunks_to_hardware_tiles(native):
+    # chunk length is an upper bound on the tile; >= 128 rows -> the 4-wave 128-row tile
+    p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)       # config 2: heuristic (8,8) -> 512x512 chunks
+    assert (p.kernel, p.block_q, p.block_kv, p.waves, p.chunk_q, p.chunk_kv) == (0, 128, 64, 4, 512, 512)
+    assert p.grid == 128 * 32 and p.lds_bytes == 32768
+    p = native.plan(16, 32768, 128, torch.bfloat16, 16, 16)    # config 3
+    assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 128, 4, 65536)
+    assert native.plan(4, 4096, 64, torch.float16, 64, 64).block_q == 64     # 64-row chunks honoured
+    assert native.plan(4, 4096, 64, torch.float16, 128, 64).block_q == 32    # 32-row chunks honoured
+    assert native.plan(5, 200, 64, torch.bfloat16, 1, 1).grid == 8 * 2       # G padded to the 8 XCDs
+    assert native.plan(4, 6, 2, torch.float32, 3, 3).kernel == 1             # generic kernel
+    assert native.plan(4, 256, 64, torch.float32, 1, 1).kernel == 1
+    assert native.plan(4, 256, 96, torch.bfloat16, 1, 1).kernel == 1
+
+
+def test_value_errors_match_reference_text(fa, meta):
+    msgs = meta["errors"]["ValueError"]
+    cases = [(torch.zeros(3, 4, 4), 1, 1), (torch.zeros(2, 1, 4, 4), 1, 1),
+             (torch.zeros(3, 1, 6, 4), 4, 1), (torch.zeros(3, 1, 6, 4), 1, 4)]
+    for (x, a, b), msg in zip(cases, msgs):
+        with pytest.raises(ValueError) as e:
+            fa.flash_attention_qkv_packed(x, a, b)
+        assert str(e.value) == msg
+
+
+def test_cpu_branch_matches_golden_config1(fa, golden_dir):
+    """BASELINE config 1 (CPU plumbing): 1 head, seq 128, D 64, chunks 4x4."""
+    g = np.load(golden_dir / "g1_g2_config1.npz")
+    qkv = torch.from_numpy(g["qkv"])
+    assert torch.equal(fa.flash_attention_qkv_packed(qkv, 4, 4), torch.from_numpy(g["out_f32"]))
+    assert torch.equal(fa.flash_attention_qkv_packed(qkv.half(), 4, 4).float(), torch.from_numpy(g["out_f16"]))
+    assert torch.equal(fa.flash_attention_qkv_packed(qkv.bfloat16(), 4, 4).float(), torch.from_numpy(g["out_bf16"]))
+    assert fa.__all__ == ["flash_attention_qkv_packed"]
+
+
+def test_patch_function_contract():
+    from flash_attention_amd._impl.utils import patch_function
+    import types
+
+    mod = types.SimpleNamespace()
+
+    def orig(x, y=1):
+        """doc"""
+        return x + y
+
+    mod.orig = orig
+
+    @patch_function(orig, [mod])
+    def repl(orig_fn, x, y=1):
+        return 10 * orig_fn(x, y)
+
+    assert mod.orig is repl and mod.orig(1, y=2) == 30
+    assert mod.orig.__wrapped__ is orig and mod.orig.__name__ == "orig" and mod.orig.__doc__ == "doc"
+
+
+def test_sdpa_override_guards_and_passthrough(meta):
+    orig = F.scaled_dot_product_attention
+    orig = getattr(orig, "__wrapped__", orig)
+    import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl.scaled_dot_product_attention import chunk_heuristic
+
+    patched = F.scaled_dot_product_attention
+    assert patched.__wrapped__ is orig and patched.__name__ == "scaled_dot_product_attention"
+    x = torch.zeros(1, 8, 4)
+    msgs = meta["errors"]["NotImplementedError"]
+    calls = [dict(attn_mask=torch.ones(1, dtype=torch.bool), is_causal=True), dict(dropout_p=0.1, is_causal=True),
+             dict(is_causal=False)]
+    for kw, msg in zip(calls, msgs[:3]):
+        with pytest.raises(NotImplementedError) as e:
+            patched(x, x, x, **kw)
+        assert str(e.value) == msg
+    with pytest.raises(NotImplementedError) as e:   # multi-element mask: NotImplementedError, not RuntimeError
+        patched(x, x, x, attn_mask=torch.ones(8, 8, dtype=torch.bool), is_causal=True)
+    assert str(e.value) == msgs[0]
+    with pytest.raises(NotImplementedError) as e:
+        patched(x, torch.zeros(1, 4, 4), x, is_causal=True)
+    assert str(e.value) == msgs[3]
+    with pytest.raises(NotImplementedError) as e:
+        patched(x, x, torch.zeros(1, 8, 2), is_causal=True)
+    assert str(e.value) == msgs[4]
+    # off-device: passthrough to the original, scale kwarg forwarded
+    q = torch.randn(2, 3, 16, 8)
+    assert torch.equal(patched(q, q, q, is_causal=True), orig(q, q, q, is_causal=True))
+    assert torch.equal(patched(q, q, q, is_causal=True, scale=0.3), orig(q, q, q, is_causal=True, scale=0.3))
+    # un-patch / re-patch through __wrapped__ as the reference's OOM test does (t_sdpa.py:123-137)
+    F.scaled_dot_product_attention = patched.__wrapped__
+    assert F.scaled_dot_product_attention is orig
+    F.scaled_dot_product_attention = patched
+    for key, (nq, nk) in meta["heuristic"].items():
+        L, D = (int(v) for v in key.split(","))
+        assert chunk_heuristic(L, D) == (nq, nk)
+
+
+def test_group_view_never_copies_for_common_layouts():
+    from flash_attention_amd._impl.scaled_dot_product_attention import _group_view
+
+    x = torch.zeros(2, 16, 3 * 4 * 8)
+    q = x.split(32, dim=2)[1].view(2, 16, 4, 8).transpose(1, 2)   # nanoGPT-style [B,H,T,hs] view
+    t, heads, strides = _group_view(q)
+    assert t.data_ptr() == q.data_ptr() and heads == 4 and strides == (16 * 96, 8, 96)
+    c = torch.zeros(2, 3, 5, 16, 8)
+    t, heads, strides = _group_view(c)
+    assert t.data_ptr() == c.data_ptr() and heads == 1 and strides == (128, 0, 8)
+
+
+def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
+    """No silent fallback: without the .so the package refuses to import (init.py:20 behaviour)."""
+    from flash_attention_amd._impl import _native
+
+    monkeypatch.setattr(_native, "_LIB", None)
+    monkeypatch.setattr(_native, "candidate_paths", lambda: [tmp_path / "nope.so"])
+    with pytest.raises(ImportError, match="Cannot find libflash_attention.so"):
+        _native.load_native_library()
+
+
+def test_gpu_tensor_without_gpu_fails_loudly(fa):
+    if torch.cuda.is_available():
+        pytest.skip("needs a CPU-only box")
+    with pytest.raises((RuntimeError, AssertionError)):
+        fa.flash_attention_qkv_packed(torch.zeros(3, 1, 8, 64).cuda(), 1, 1)

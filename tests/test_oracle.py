@@ -1,0 +1,119 @@
+"""CPU tests of the oracle itself: the restatements against the golden vectors captured from the
+reference (tests/golden/generate_golden.py) and against each other.  No GPU, no product code."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense_causal_attention, dense_causal_attention_lse, frozen_randn, sdpa_chunk_heuristic
+from oracle import chunked
+
+SEED = 1123581321
+
+
+def test_dense_matches_golden_g1_g2(golden_dir):
+    g = np.load(golden_dir / "g1_g2_config1.npz")
+    qkv = torch.from_numpy(g["qkv"])
+    # G1: fp32, bit-for-bit the same expression as the reference's CPU branch
+    out = dense_causal_attention(qkv)
+    assert torch.equal(out, torch.from_numpy(g["out_f32"]))
+    # G2: the oracle run in the same 16-bit dtype reproduces the reference's 16-bit CPU path exactly.
+    # That path rounds the *scores* to 16 bits (torch CPU matmul in the tensor dtype), so it sits
+    # up to 1e-2 (fp16) / 7e-2 (bf16) away from exact arithmetic on the same rounded inputs: the
+    # bounds below document that noise, they are not the GPU parity tolerance.
+    for name, dt, noise in (("out_f16", torch.float16, 2e-2), ("out_bf16", torch.bfloat16, 1e-1)):
+        assert torch.equal(dense_causal_attention(qkv.to(dt)).float(), torch.from_numpy(g[name]))
+        ref16 = torch.from_numpy(g[name]).double()
+        orc = dense_causal_attention(qkv.to(dt), compute_dtype=torch.float64)
+        assert (ref16 - orc).abs().max().item() < noise
+
+
+def test_chunked_matches_golden_g3_all_chunk_pairs(golden_dir):
+    g = np.load(golden_dir / "g3_tiny_chunks.npz")
+    qkv = g["qkv"]
+    for (nq, nk), ref in zip(g["pairs"], g["outs"]):
+        if 6 // nk == 1:
+            continue
+        out, _ = chunked.chunked_attention(qkv.astype(np.float64), int(nq), int(nk))
+        np.testing.assert_allclose(out, ref, atol=1e-5, rtol=0)  # t_cpp:245-251 bound
+        out32, _ = chunked.chunked_attention(qkv, int(nq), int(nk))
+        np.testing.assert_allclose(out32, ref, atol=1e-5, rtol=0)
+    # chunk independence of the reference itself
+    assert np.abs(g["outs"] - g["outs"][0]).max() < 1e-6
+
+
+def test_triu_offset_sequences():
+    # examples quoted in SURVEY.md 8(a7) from FA.cpp:47-126
+    assert chunked.triu_offsets(2, 2) == [1]
+    assert chunked.triu_offsets(2, 3) == [1, 0, 2]
+    assert chunked.triu_offsets(512, 1024) == [1, 513]
+    assert chunked.triu_offsets(1024, 512) == [1, -511]
+    with pytest.raises(RuntimeError):
+        chunked.triu_offsets(4, 1)  # the reference loops forever here
+
+
+@pytest.mark.parametrize("L", [6, 8, 12, 16, 24, 32, 48, 64])
+def test_chunked_equals_dense_every_divisor_pair(L):
+    """The cyclic-mask chunked program == the dense -10000-masked result for every (nq, nk) with
+    Bk > 1 (semantic contract)."""
+    qkv = frozen_randn(SEED + L, (3, 2, L, 4)).double()
+    dense, lse_d = dense_causal_attention_lse(qkv)
+    divs = [d for d in range(1, L + 1) if L % d == 0]
+    for nq in divs:
+        for nk in divs:
+            if L // nk == 1:
+                continue
+            out, lse = chunked.chunked_attention(qkv.numpy(), nq, nk)
+            assert np.abs(out - dense.numpy()).max() < 1e-9, (nq, nk)
+            assert np.abs(lse - lse_d.numpy()).max() < 1e-9, (nq, nk)
+
+
+def test_chunked_medium_shapes_fp32():
+    # t_cpp:256-259: fp32 G=8 L=256 D=128, (nq,nk) in {2,4}^2, max|delta| <= 1e-5 (reduced G for CPU time)
+    qkv = frozen_randn(SEED, (3, 2, 256, 128))
+    dense = dense_causal_attention(qkv, compute_dtype=torch.float64).numpy()
+    for nq in (2, 4):
+        for nk in (2, 4):
+            # the reference bound (1e-5) is flash-vs-vanilla with BOTH in fp32; against an fp64 dense
+            # result the scalar fp32 accumulation alone costs ~1.5e-5, so check fp32 at 1e-4 and the
+            # fp64 run of the same program at 1e-12
+            out, _ = chunked.chunked_attention(qkv.numpy(), nq, nk)
+            assert np.abs(out - dense).max() <= 1e-4
+            out64, _ = chunked.chunked_attention(qkv.numpy().astype(np.float64), nq, nk)
+            assert np.abs(out64 - dense).max() <= 1e-12
+
+
+def test_dense_matches_golden_g5_sampled_rows(golden_dir):
+    g = np.load(golden_dir / "g5_large_sampled.npz")
+    for tag in ("N4_L1024_D128", "G2_L4096_D64"):
+        G, L, D = (int(x) for x in g[f"{tag}_shape"])
+        rows = g[f"{tag}_rowidx"]
+        x = frozen_randn(SEED, (3, G, L, D))
+        out = dense_causal_attention(x, compute_dtype=torch.float32)
+        np.testing.assert_allclose(out[:, rows, :].double().numpy(), g[f"{tag}_f32_rows"], atol=1e-5, rtol=1e-5)
+        assert abs(out.double().sum().item() - float(g[f"{tag}_f32_sum"])) < 1e-2
+        for dt_name, dt, noise in (("bf16", torch.bfloat16, 0.15), ("f16", torch.float16, 3e-2)):
+            # same-dtype oracle == reference 16-bit path (bitwise); fp64 oracle within that path's noise
+            o16 = dense_causal_attention(x.to(dt))
+            assert torch.equal(o16[:, rows, :].double(), torch.from_numpy(g[f"{tag}_{dt_name}_rows"]))
+            o64 = dense_causal_attention(x.to(dt), compute_dtype=torch.float64)
+            assert (o64[:, rows, :] - torch.from_numpy(g[f"{tag}_{dt_name}_rows"])).abs().max().item() < noise
+
+
+def test_heuristic_table(golden_dir):
+    meta = json.loads((golden_dir / "g6_meta.json").read_text())
+    for key, (nq, nk) in meta["heuristic"].items():
+        L, D = (int(x) for x in key.split(","))
+        assert sdpa_chunk_heuristic(L, D) == (nq, nk)
+
+
+def test_lse_definition():
+    qkv = frozen_randn(3, (3, 2, 33, 8)).double()
+    out, lse = dense_causal_attention_lse(qkv, scale=0.5)
+    q, k, _ = qkv
+    s = (q @ k.transpose(1, 2)) * 0.5
+    mask = torch.ones(33, 33, dtype=torch.bool).tril()
+    ref = torch.logsumexp(s.masked_fill(~mask, float("-inf")), dim=-1)
+    torch.testing.assert_close(lse, ref, atol=1e-10, rtol=0)
