@@ -49,6 +49,7 @@ def cpu_baseline(L, D, budget_s=12.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    cores = min(cores, 16)   # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
     torch.set_num_threads(cores)
     slab = 8
     gen = torch.Generator().manual_seed(0)

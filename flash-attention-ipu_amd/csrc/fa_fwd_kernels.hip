@@ -55,29 +55,31 @@ template <> struct Elt<_Float16> {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// fmaxf() on MFMA results makes hipcc emit a canonicalising v_max_f32 x,x per operand; the scores are
-// never signalling NaNs, so take the max with single instructions.
-__device__ __forceinline__ float max3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ float max2(float a, float b) {
-    float d;
-    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
+// The build uses -fno-honor-nans: without it fmaxf() on MFMA results costs a canonicalising
+// v_max_f32 x,x per operand (IEEE mode must quiet signalling NaNs).  Do NOT replace these by inline
+// asm: hipcc does not pad the MFMA-result -> VALU-read hazard for an asm statement, and the max then
+// reads stale scores.
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float max2(float a, float b) { return __builtin_fmaxf(a, b); }
 
-// max over both 32-lane halves, result in every lane (one v_permlane32_swap).
+// Exchange between the two 32-lane halves of a wave with ONE v_permlane32_swap: called with the same
+// value in both operands it returns {lower half's value, upper half's value} in every lane.
+// (Copy the two results to scalars before __builtin_bit_cast: bit-casting the vector ELEMENT r[1]
+// directly reads element 0 with this clang.)
+struct HalfPair { float lo, hi; };
+__device__ __forceinline__ HalfPair half_exchange(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return {__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
+}
 __device__ __forceinline__ float half_swap_max(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return max2(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    const HalfPair p = half_exchange(x);
+    return max2(p.lo, p.hi);
 }
 __device__ __forceinline__ float half_swap_sum(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    const HalfPair p = half_exchange(x);
+    return p.lo + p.hi;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -234,7 +234,10 @@ def test_full_size_properties_config2(dtype):
     # (3) linearity in V for power-of-two factors is bit-exact
     qkv2 = qkv.clone()
     qkv2[2] *= 4
-    assert torch.equal(fa.flash_attention_qkv_packed(qkv2, 8, 8), out * 4)
+    # (bit-exact for every normal value; fp16 outputs below 2^-14 sit on the denormal grid, where
+    # round(4x) != 4*round(x), hence the 2^-22 slack that only tiny values can use)
+    o4 = fa.flash_attention_qkv_packed(qkv2, 8, 8)
+    assert torch.equal(o4, out * 4) or (o4.float() - out.float() * 4).abs().max().item() <= 2.0 ** -22
     # (4) groups are independent: a permutation of the groups permutes the output bit-exactly
     perm = torch.randperm(G, device="cuda", generator=gen)
     assert torch.equal(fa.flash_attention_qkv_packed(qkv[:, perm].contiguous(), 8, 8), out[perm])
