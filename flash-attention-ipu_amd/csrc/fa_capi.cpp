@@ -74,7 +74,7 @@ int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_
         const int64_t nqt = (L + plan->block_q - 1) / plan->block_q;
         const int64_t g8 = (G + 7) / 8 * 8;
         plan->grid = g8 * nqt;
-        plan->lds_bytes = 4 * 64 * D * 2;
+        plan->lds_bytes = 2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64);
     } else {
         if (D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic kernel supports D <= 1024 (got %lld)", (long long)D);
         plan->kernel = 1;
@@ -149,7 +149,9 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
         if (reinterpret_cast<uintptr_t>(ptrs[i]) % elt_size(dtype)) return fail(FA_ERR_MISALIGNED, "pointer %d is not element aligned", i);
 
     fa_plan_t plan;
-    const bool tile_ok = tile_kernel_ok(D, dtype, ptrs, strides);
+    bool tile_ok = tile_kernel_ok(D, dtype, ptrs, strides);
+    // the MFMA kernel addresses K/V rows with 32-bit element offsets from the group base
+    if (tile_ok && (L * k_strides[2] >= (1ll << 31) || L * v_strides[2] >= (1ll << 31))) tile_ok = false;
     int rc = make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_ok, &plan);
     if (rc != FA_OK) return rc;
 

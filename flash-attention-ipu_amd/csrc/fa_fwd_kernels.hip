@@ -85,6 +85,11 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 // ---------------------------------------------------------------------------------------------
 // MFMA tile kernel.  T in {__bf16, _Float16}, D in {64, 128}, NWAVES in {1, 2, 4, 8}.
 // ---------------------------------------------------------------------------------------------
+// Lazy rescale threshold in log2 units: the running max m is only raised (and O, l rescaled) when a
+// tile's row max exceeds it by more than this, so P = 2^((s-m)c) stays <= 2^8 - exact in fp32
+// accumulators, harmless in bf16/f16 P (same relative rounding), and normalised away by O/l.
+constexpr float RESCALE_THR = 8.0f;
+
 template <typename T, int D, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParams p) {
     using E = Elt<T>;
@@ -93,16 +98,20 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
     constexpr int NT = NWAVES * 64;
     constexpr int BQ = NWAVES * 32;
     constexpr int BK = 64;
-    constexpr int ROWB = D * 2;           // bytes per K row in LDS
-    constexpr int TILE_B = BK * ROWB;     // bytes per K (or V) tile
-    constexpr int CHUNKS = TILE_B / 16;   // 16-byte chunks per tile
-    constexpr int CPT = CHUNKS / NT;      // chunks per thread per tile
-    constexpr int CPR = D / 8;            // chunks per row
-    constexpr int KS = D / 16;            // k-steps of the QK^T contraction
-    constexpr int DT = D / 32;            // 32-wide d tiles of O^T
+    constexpr int ROWB = D * 2;                 // bytes per K row in LDS
+    constexpr int KTILE_B = BK * ROWB;          // bytes per K tile
+    constexpr int VBLK_B = BK * 64 + 64;        // bytes per 32-column d-block of the V image (+64 B pad:
+                                                // the two 64-B halves of a staged 128-B row hit distinct banks)
+    constexpr int VTILE_B = (D / 32) * VBLK_B;  // bytes per V tile
+    constexpr int CHUNKS = KTILE_B / 16;        // 16-byte chunks per tile
+    constexpr int CPT = CHUNKS / NT;            // chunks per thread per tile
+    constexpr int CPR = D / 8;                  // chunks per row
+    constexpr int KS = D / 16;                  // k-steps of the QK^T contraction
+    constexpr int DT = D / 32;                  // 32-wide d tiles of O^T
     static_assert(CHUNKS % NT == 0, "tile must split evenly over the workgroup");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_B];  // K0 K1 V0 V1
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KTILE_B + 2 * VTILE_B];  // K0 K1 V0 V1
+    unsigned char* const smem_v = smem + 2 * KTILE_B;
 
     // ---- which (group, q-tile) is this workgroup?  Blocks b and b+8 share an XCD (round-robin
     // dispatch), so an XCD walks whole groups, heaviest q-tile first: K/V of a group stay in that
@@ -142,19 +151,25 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const vec8*)(qp + 16 * ks);
     }
 
-    // ---- per-thread staging geometry (tile-invariant)
-    int ld_key[CPT], ld_ch[CPT];
+    // ---- per-thread staging geometry.  Global side: 32-bit element offsets from the group base
+    // (the C ABI guarantees L*stride < 2^31), advanced by one tile per iteration; rows past L-1 are
+    // redirected to row L-1 (they are causally masked for every stored query row, any finite data do).
+    const unsigned k_sl = (unsigned)p.k_sl, v_sl = (unsigned)p.v_sl;
+    unsigned k_off[CPT], v_off[CPT];
+    int ld_key[CPT];
     int st_k[CPT], st_v[CPT];
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int c = tid + i * NT;
         const int key = c / CPR, ch = c % CPR;
         ld_key[i] = key;
-        ld_ch[i] = ch;
+        k_off[i] = (unsigned)key * k_sl + ch * 8;
+        v_off[i] = (unsigned)key * v_sl + ch * 8;
         const int sw = (D == 64) ? ((key >> 1) & 7) : (key & 15);
         st_k[i] = key * ROWB + ((ch ^ sw) << 4);
-        st_v[i] = (ch >> 2) * (BK * 64) + (key >> 3) * 512 + (key & 7) * 64 + (ch & 3) * 16;
+        st_v[i] = (ch >> 2) * VBLK_B + (key >> 3) * 512 + (key & 7) * 64 + (ch & 3) * 16;
     }
+    const unsigned k_last = (unsigned)(L - 1) * k_sl, v_last = (unsigned)(L - 1) * v_sl;
 
     // ---- LDS read addresses (tile-invariant, per lane)
     // K: row (32kb + r), chunk (2ks + h) ^ swz(row)
@@ -172,18 +187,29 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
     const int n_tiles = (kv_end + BK - 1) / BK;
 
     u32x4 kreg[CPT], vreg[CPT];
-    // rows past L are causally masked for every stored query row: clamping keeps the loads in bounds
-#define FA_ISSUE_LOADS(T_)                                                                   \
-    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                        \
-        int krow = (T_) * BK + ld_key[i];                                                    \
-        krow = krow < L ? krow : L - 1;                                                      \
-        kreg[i] = *(const u32x4*)(kg + (int64_t)krow * p.k_sl + ld_ch[i] * 8);               \
-        vreg[i] = *(const u32x4*)(vg + (int64_t)krow * p.v_sl + ld_ch[i] * 8);               \
+#define FA_ISSUE_LOADS(T_)                                                                        \
+    {                                                                                             \
+        const int kv0_ = (T_) * BK;                                                               \
+        const unsigned kt_ = (unsigned)kv0_ * k_sl, vt_ = (unsigned)kv0_ * v_sl;                  \
+        if (kv0_ + BK <= L) {                                                                     \
+            _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                     \
+                kreg[i] = *(const u32x4*)(kg + (kt_ + k_off[i]));                                 \
+                vreg[i] = *(const u32x4*)(vg + (vt_ + v_off[i]));                                 \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                     \
+                const bool in_ = kv0_ + ld_key[i] < L;                                            \
+                const unsigned ko_ = in_ ? kt_ + k_off[i] : k_last + (k_off[i] - ld_key[i] * k_sl); \
+                const unsigned vo_ = in_ ? vt_ + v_off[i] : v_last + (v_off[i] - ld_key[i] * v_sl); \
+                kreg[i] = *(const u32x4*)(kg + ko_);                                              \
+                vreg[i] = *(const u32x4*)(vg + vo_);                                              \
+            }                                                                                     \
+        }                                                                                         \
     }
-#define FA_COMMIT_LOADS(BUF_)                                                                \
-    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                        \
-        *(u32x4*)(smem + (BUF_) * TILE_B + st_k[i]) = kreg[i];                               \
-        *(u32x4*)(smem + (2 + (BUF_)) * TILE_B + st_v[i]) = vreg[i];                         \
+#define FA_COMMIT_LOADS(BUF_)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                             \
+        *(u32x4*)(smem + (BUF_) * KTILE_B + st_k[i]) = kreg[i];                                   \
+        *(u32x4*)(smem_v + (BUF_) * VTILE_B + st_v[i]) = vreg[i];                                 \
     }
 
     // ---- running state
@@ -192,22 +218,27 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-    float m = -INFINITY;   // running row max (raw logits)
+    float m = -INFINITY;   // running reference max (raw logits); lags the true max by <= RESCALE_THR/c
     float l = 0.f;         // running row sum over THIS half's keys (halves are added in the epilogue)
     const float c = p.scale_log2;
 
     FA_ISSUE_LOADS(0)
     FA_COMMIT_LOADS(0)
     __syncthreads();
+    // Q must have LANDED before the loop: otherwise hipcc carries "Q loads pending" into the loop
+    // and drains vmcnt to 0 in front of the QK^T MFMAs of EVERY tile, i.e. waits for the prefetch of
+    // tile t+1 it has just issued.  Using the registers here retires the wait once.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
 
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
         const int kv0 = t * BK;
-        if (t + 1 < n_tiles) { FA_ISSUE_LOADS(t + 1) }
+        if (t + 1 < n_tiles) FA_ISSUE_LOADS(t + 1)
 
         if (wave_active && kv0 <= q_row0 + 31) {
-            const unsigned char* kb_ = smem + buf * TILE_B;
-            const unsigned char* vb_ = smem + (2 + buf) * TILE_B;
+            const unsigned char* kb_ = smem + buf * KTILE_B;
+            const unsigned char* vb_ = smem_v + buf * VTILE_B;
 
             // ---- S^T = K Q^T : two 32-key blocks
             f32x16 s0, s1;
@@ -236,10 +267,20 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
 #pragma unroll
             for (int e = 1; e < 16; ++e) mx = max3(mx, s0[e], s1[e]);
             mx = half_swap_max(mx);
-            const float m_new = max2(m, mx);
-            const float alpha = fast_exp2((m - m_new) * c);
-            const float mc = m_new * c;
-            m = m_new;
+            // lazy rescale: only when some row of the wave outgrew its reference max by > THR
+            // (first tile: m = -inf, always taken).  Decision BEFORE this tile's P is formed, so
+            // everything already in O and l is scaled exactly once.
+            if (__builtin_amdgcn_ballot_w64((mx - m) * c > RESCALE_THR) != 0) {
+                const float m_new = max2(m, mx);
+                const float alpha = fast_exp2((m - m_new) * c);
+                m = m_new;
+                l *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+            }
+            const float mc = m * c;
             float ls = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -248,13 +289,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
                 ls += s0[e];
                 ls += s1[e];
             }
-            l = l * alpha + ls;
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
-            }
+            l += ls;
 
             // ---- P^T fragments (B operand of O^T += V^T P^T): registers 8s..8s+7 of each block
             vec8 pf[4];
@@ -271,7 +306,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
             for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const unsigned char* vp = vb_ + dt * (BK * 64) + kk * 1024 + v_rd;
+                    const unsigned char* vp = vb_ + dt * VBLK_B + kk * 1024 + v_rd;
                     const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (i16x4 __attribute__((address_space(3)))*)(vp));
                     const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -285,11 +320,13 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
         if (t + 1 < n_tiles) { FA_COMMIT_LOADS(buf ^ 1) }
         __syncthreads();
     }
+#undef FA_ISSUE_LOADS
+#undef FA_COMMIT_LOADS
 
     // ---- epilogue: O /= l, optional LSE, store
     if (!wave_active || qrow >= L) return;
     const float lt = half_swap_sum(l);
-    const float inv = 1.0f / lt;
+    const float inv = __builtin_amdgcn_rcpf(lt);
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)qrow * p.o_sl;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
