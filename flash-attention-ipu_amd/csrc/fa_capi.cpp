@@ -167,13 +167,29 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     p.L = (int32_t)L;
     p.D = (int32_t)D;
     p.nq_tiles = plan.kernel == 0 ? (int32_t)((L + plan.block_q - 1) / plan.block_q) : 0;
-    const char* sched = getenv("FA_AMD_SCHED");
-    p.sched = (sched && sched[0] == '1') ? 1 : 0;
+    // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
+    // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
+    {
+        const int64_t kv_bytes = 2 * L * D * elt_size(dtype);
+        int64_t bunch = kv_bytes > 0 ? (8ll << 20) / kv_bytes : 1;
+        const char* sched = getenv("FA_AMD_SCHED");
+        if (sched && *sched) bunch = atoi(sched);
+        const int64_t ng = p.G8 / 8;
+        if (bunch < 1) bunch = 1;
+        if (bunch > ng) bunch = ng;
+        p.sched = (int32_t)bunch;
+    }
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
 
-    hipError_t e = plan.kernel == 0 ? fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream)
-                                    : fa::launch_fwd_generic(p, dtype, (hipStream_t)stream);
+    // MFMA kernels: "pipe" (software-pipelined, default at D=64) or "tile" (default at D=128)
+    bool pipe = (D == 64);
+    const char* kv = getenv("FA_AMD_KERNEL");
+    if (kv && kv[0] == 'p') pipe = true;
+    if (kv && kv[0] == 't') pipe = false;
+    hipError_t e = plan.kernel != 0 ? fa::launch_fwd_generic(p, dtype, (hipStream_t)stream)
+                   : pipe           ? fa::launch_fwd_pipe(p, dtype, plan.waves, (hipStream_t)stream)
+                                    : fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
 }

@@ -1,0 +1,73 @@
+// Device-side helpers shared by the forward kernels (types, MFMA wrappers, half-wave exchange).
+#ifndef FA_DEVICE_H
+#define FA_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fa_params.h"
+
+namespace fa {
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Elt;
+template <> struct Elt<__bf16> {
+    using vec8 = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Elt<_Float16> {
+    using vec8 = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// The build uses -fno-honor-nans: without it fmaxf() on MFMA results costs a canonicalising
+// v_max_f32 x,x per operand (IEEE mode must quiet signalling NaNs).  Do NOT replace these by inline
+// asm: hipcc does not pad the MFMA-result -> VALU-read hazard for an asm statement, and the max then
+// reads stale scores.
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float max2(float a, float b) { return __builtin_fmaxf(a, b); }
+
+// Exchange between the two 32-lane halves of a wave with ONE v_permlane32_swap: called with the same
+// value in both operands it returns {lower half's value, upper half's value} in every lane.
+// (Copy the two results to scalars before __builtin_bit_cast: bit-casting the vector ELEMENT r[1]
+// directly reads element 0 with this clang.)
+struct HalfPair { float lo, hi; };
+__device__ __forceinline__ HalfPair half_exchange(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return {__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
+}
+__device__ __forceinline__ float half_swap_max(float x) {
+    const HalfPair p = half_exchange(x);
+    return max2(p.lo, p.hi);
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+    const HalfPair p = half_exchange(x);
+    return p.lo + p.hi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA tile kernel.  T in {__bf16, _Float16}, D in {64, 128}, NWAVES in {1, 2, 4, 8}.
+// ---------------------------------------------------------------------------------------------
+
+// Lazy rescale threshold in log2 units: the running max m is only raised (and O, l rescaled) when a
+// tile's row max exceeds it by more than this, so P = 2^((s-m)c) stays <= 2^8 - exact in fp32
+// accumulators, harmless in bf16/f16 P (same relative rounding), and normalised away by O/l.
+constexpr float RESCALE_THR = 8.0f;
+
+}  // namespace fa
+#endif

@@ -28,67 +28,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "fa_params.h"
+#include "fa_device.h"
+
+#ifndef FA_CHAIN_SPLIT
+#define FA_CHAIN_SPLIT 0   // experiment knob: split the max / row-sum dependency chains
+#endif
 
 namespace fa {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short i16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef short i16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-template <typename T> struct Elt;
-template <> struct Elt<__bf16> {
-    using vec8 = bf16x8;
-    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Elt<_Float16> {
-    using vec8 = f16x8;
-    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-};
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// The build uses -fno-honor-nans: without it fmaxf() on MFMA results costs a canonicalising
-// v_max_f32 x,x per operand (IEEE mode must quiet signalling NaNs).  Do NOT replace these by inline
-// asm: hipcc does not pad the MFMA-result -> VALU-read hazard for an asm statement, and the max then
-// reads stale scores.
-__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-__device__ __forceinline__ float max2(float a, float b) { return __builtin_fmaxf(a, b); }
-
-// Exchange between the two 32-lane halves of a wave with ONE v_permlane32_swap: called with the same
-// value in both operands it returns {lower half's value, upper half's value} in every lane.
-// (Copy the two results to scalars before __builtin_bit_cast: bit-casting the vector ELEMENT r[1]
-// directly reads element 0 with this clang.)
-struct HalfPair { float lo, hi; };
-__device__ __forceinline__ HalfPair half_exchange(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    const unsigned r0 = r[0], r1 = r[1];
-    return {__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
-}
-__device__ __forceinline__ float half_swap_max(float x) {
-    const HalfPair p = half_exchange(x);
-    return max2(p.lo, p.hi);
-}
-__device__ __forceinline__ float half_swap_sum(float x) {
-    const HalfPair p = half_exchange(x);
-    return p.lo + p.hi;
-}
-
-// ---------------------------------------------------------------------------------------------
-// MFMA tile kernel.  T in {__bf16, _Float16}, D in {64, 128}, NWAVES in {1, 2, 4, 8}.
-// ---------------------------------------------------------------------------------------------
-// Lazy rescale threshold in log2 units: the running max m is only raised (and O, l rescaled) when a
-// tile's row max exceeds it by more than this, so P = 2^((s-m)c) stays <= 2^8 - exact in fp32
-// accumulators, harmless in bf16/f16 P (same relative rounding), and normalised away by O/l.
-constexpr float RESCALE_THR = 8.0f;
 
 template <typename T, int D, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParams p) {
@@ -114,19 +61,24 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
     unsigned char* const smem_v = smem + 2 * KTILE_B;
 
     // ---- which (group, q-tile) is this workgroup?  Blocks b and b+8 share an XCD (round-robin
-    // dispatch), so an XCD walks whole groups, heaviest q-tile first: K/V of a group stay in that
-    // XCD's L2 while its q-tiles run, and the causal tail is made of the light tiles.
+    // dispatch).  Each XCD owns the groups g = 8*gl + xcd and walks them in bunches of `sched`
+    // groups; inside a bunch the q-tiles go heaviest first across all its groups.  A bunch keeps
+    // its K/V (sched x 2*L*D*2 bytes) in that XCD's 4 MiB L2 while longest-processing-time-first
+    // ordering evens out the causal imbalance (one group at a time leaves 10-16 % of the slots idle).
     const int b = blockIdx.x;
     const int nq = p.nq_tiles;
     int g, qi;
-    if (p.sched == 0) {
+    {
         const int xcd = b & 7, slot = b >> 3;
-        const int gl = slot / nq;
-        qi = nq - 1 - (slot - gl * nq);
-        g = gl * 8 + xcd;
-    } else {  // heaviest-first over the whole grid (no L2 grouping)
-        qi = nq - 1 - b / p.G8;
-        g = b % p.G8;
+        const int ng = p.G8 >> 3;                      // groups per XCD
+        const int per_bunch = p.sched * nq;
+        const int bunch = slot / per_bunch;
+        const int rem = slot - bunch * per_bunch;
+        const int g0 = bunch * p.sched;
+        const int bc = (ng - g0) < p.sched ? (ng - g0) : p.sched;   // groups in this bunch
+        const int qd = rem / bc;
+        qi = nq - 1 - qd;
+        g = (g0 + (rem - qd * bc)) * 8 + xcd;
     }
     if (g >= p.G) return;
 
@@ -263,10 +215,21 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
             }
 
             // ---- online softmax (row = lane; keys = registers x 2 halves)
+#if FA_CHAIN_SPLIT
+            // (two independent chains: a single 16-deep dependent chain stalls the wave)
+            float mxa = max3(s0[0], s0[1], s0[2]), mxb = max3(s1[0], s1[1], s1[2]);
+#pragma unroll
+            for (int e = 3; e < 15; e += 2) {
+                mxa = max3(mxa, s0[e], s0[e + 1]);
+                mxb = max3(mxb, s1[e], s1[e + 1]);
+            }
+            float mx = half_swap_max(max3(mxa, mxb, max2(s0[15], s1[15])));
+#else
             float mx = max2(s0[0], s1[0]);
 #pragma unroll
             for (int e = 1; e < 16; ++e) mx = max3(mx, s0[e], s1[e]);
             mx = half_swap_max(mx);
+#endif
             // lazy rescale: only when some row of the wave outgrew its reference max by > THR
             // (first tile: m = -inf, always taken).  Decision BEFORE this tile's P is formed, so
             // everything already in O and l is scaled exactly once.
@@ -281,6 +244,21 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
                     for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
             }
             const float mc = m * c;
+#if FA_CHAIN_SPLIT
+            float ls0 = 0.f, ls1 = 0.f, ls2 = 0.f, ls3 = 0.f;   // four short chains, not one of 32
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -mc));
+                s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -mc));
+                s0[e + 1] = fast_exp2(__builtin_fmaf(s0[e + 1], c, -mc));
+                s1[e + 1] = fast_exp2(__builtin_fmaf(s1[e + 1], c, -mc));
+                ls0 += s0[e];
+                ls1 += s1[e];
+                ls2 += s0[e + 1];
+                ls3 += s1[e + 1];
+            }
+            l += (ls0 + ls1) + (ls2 + ls3);
+#else
             float ls = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -290,6 +268,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
                 ls += s1[e];
             }
             l += ls;
+#endif
 
             // ---- P^T fragments (B operand of O^T += V^T P^T): registers 8s..8s+7 of each block
             vec8 pf[4];

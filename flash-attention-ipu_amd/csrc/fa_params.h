@@ -24,12 +24,13 @@ struct FwdParams {
     int32_t L;
     int32_t D;
     int32_t nq_tiles;      // q tiles per group
-    int32_t sched;         // 0 = XCD-grouped heavy-first, 1 = global heavy-first
+    int32_t sched;         // groups per XCD bunch (>= 1): heavy-first order inside a bunch
     float scale;           // softmax scale
     float scale_log2;      // scale * log2(e)
 };
 
 hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream);
+hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream);
 
 }  // namespace fa

@@ -1,0 +1,79 @@
+"""Developer aid: interleaved A/B timing of kernel builds/variants in ONE process (cdna guide rule 24).
+
+usage: python scripts/sweep.py [cfg] SPEC [SPEC ...]
+  SPEC = "[lib:]K=pipe,W=4,S=4"   lib = name of build/variants/libfa_<lib>.so (default: the shipped library)
+         K kernel (tile|pipe), W waves per workgroup, S groups per L2 bunch
+Each timing = N back-to-back launches between two events; rounds are interleaved across specs.
+"""
+import ctypes, os, sys, pathlib, statistics
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd")]
+import torch
+
+CFG = {"cfg2": (128, 4096, 64, torch.bfloat16, 8, 8), "cfg2h": (128, 4096, 64, torch.float16, 8, 8),
+       "cfg3": (16, 32768, 128, torch.bfloat16, 16, 16), "d128": (64, 4096, 128, torch.bfloat16, 8, 8),
+       "cfg5": (256, 8192, 64, torch.bfloat16, 16, 8), "short": (512, 1024, 64, torch.bfloat16, 4, 4)}
+args = sys.argv[1:]
+cfg = "cfg2"
+if args and args[0] in CFG:
+    cfg = args.pop(0)
+G, L, D, dt, nq, nk = CFG[cfg]
+specs = args or ["K=tile,W=4", "K=pipe,W=4"]
+LONG = int(os.environ.get("SWEEP_N", "20"))
+qkv = torch.randn(3, G, L, D, device="cuda").to(dt)
+out = torch.empty(G, L, D, device="cuda", dtype=dt)
+flops = 2.0 * G * L * L * D
+dcode = {torch.float16: 0, torch.bfloat16: 1}[dt]
+libs = {}
+
+def getlib(name):
+    if name not in libs:
+        path = ROOT / "flash-attention-ipu_amd" / "build" / ("libflash_attention.so" if name == "" else f"variants/libfa_{name}.so")
+        lib = ctypes.CDLL(str(path))
+        lib.fa_fwd_qkv_packed.restype = ctypes.c_int
+        lib.fa_fwd_qkv_packed.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_int32] * 3 + [ctypes.c_void_p]
+        libs[name] = lib
+    return libs[name]
+
+def parse(spec):
+    name, _, rest = spec.rpartition(":")
+    return name, rest
+
+def setenv(rest):
+    for k in ("FA_AMD_KERNEL", "FA_AMD_WAVES", "FA_AMD_SCHED"):
+        os.environ.pop(k, None)
+    for kv in rest.split(","):
+        if kv:
+            k, val = kv.split("=")
+            os.environ[{"K": "FA_AMD_KERNEL", "W": "FA_AMD_WAVES", "S": "FA_AMD_SCHED"}[k]] = val
+
+def timeit(spec, n):
+    name, rest = parse(spec)
+    lib = getlib(name)
+    setenv(rest)
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        rc = lib.fa_fwd_qkv_packed(qkv.data_ptr(), out.data_ptr(), None, G, L, D, nq, nk, dcode, stream)
+        assert rc == 0, rc
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+ref = None
+for s in specs:
+    timeit(s, 3)
+    o = out.clone()
+    if ref is None:
+        ref = o
+    elif not torch.equal(o, ref):
+        print(f"note: {s} differs from {specs[0]}: max|d|={(o.float()-ref.float()).abs().max().item():.3e}")
+res = {s: [] for s in specs}
+for rnd in range(7):
+    for s in specs:
+        res[s].append(timeit(s, LONG))
+for s in specs:
+    ts = res[s]
+    print(f"{cfg} {s:34s} median {statistics.median(ts)*1e3:8.1f} us  min {min(ts)*1e3:8.1f} us  "
+          f"{flops/statistics.median(ts)/1e9:8.1f} TF (max {flops/min(ts)/1e9:7.1f})", flush=True)
