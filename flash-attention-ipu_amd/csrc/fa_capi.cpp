@@ -182,13 +182,13 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
 
-    // MFMA kernels: "pipe" (software-pipelined, default at D=64) or "tile" (default at D=128)
-    bool pipe = (D == 64);
+    // MFMA kernels: "tile" (register-staged), "dma" (LDS-DMA staged), "pipe" (software-pipelined)
+    char which = (D == 64) ? 'd' : 't';
     const char* kv = getenv("FA_AMD_KERNEL");
-    if (kv && kv[0] == 'p') pipe = true;
-    if (kv && kv[0] == 't') pipe = false;
+    if (kv && (kv[0] == 'p' || kv[0] == 't' || kv[0] == 'd')) which = kv[0];
     hipError_t e = plan.kernel != 0 ? fa::launch_fwd_generic(p, dtype, (hipStream_t)stream)
-                   : pipe           ? fa::launch_fwd_pipe(p, dtype, plan.waves, (hipStream_t)stream)
+                   : which == 'p'   ? fa::launch_fwd_pipe(p, dtype, plan.waves, (hipStream_t)stream)
+                   : which == 'd'   ? fa::launch_fwd_dma(p, dtype, plan.waves, (hipStream_t)stream)
                                     : fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;

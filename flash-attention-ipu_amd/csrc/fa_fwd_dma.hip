@@ -1,0 +1,285 @@
+// FlashAttention forward for MI355X (gfx950) with LDS-DMA staging - 4 waves per SIMD at head_dim 64.
+//
+// Same tiling, LDS images, MFMA operand maps and arithmetic as fa_fwd_tile_kernel
+// (fa_fwd_kernels.hip - read its header first).  What changes is how K/V tiles reach LDS:
+//
+//   * `buffer_load_dwordx4 ... lds` (LDS-DMA): global -> LDS with no VGPR destination, no ds_write
+//     and no per-tile address arithmetic.  One wave-instruction moves a 1 KiB piece (64 lanes x 16 B,
+//     lane-linear in LDS); the K swizzle and the V [d/32][key/8][8][32] image are produced by
+//     choosing each lane's SOURCE address (the LDS destination cannot scatter).
+//   * the per-tile advance lives in the buffer descriptor (scalar adds), whose byte limit also
+//     zero-fills key rows past L - no clamping code;
+//   * the kv loop is unrolled by two, so every LDS address is base + immediate.
+//
+// That frees ~22 VGPRs (no staging registers, no staging addresses): the D=64 kernel fits 128 VGPRs
+// = 4 waves per SIMD (4 workgroups of 4 waves per CU), and removes ~25 VALU instructions per tile
+// from the VALU issue port, which is the binding resource of this kernel at head_dim 64.
+
+#include "fa_device.h"
+
+// experiment knobs (scripts/sweep.py builds variants with -D...)
+#ifndef FA_DMA_ONES
+#define FA_DMA_ONES 0   // 1: row sums on the matrix pipe (l += 1^T P^T, 4 MFMAs) instead of 32 v_add per tile
+#endif
+#ifndef FA_DMA_PRIO
+#define FA_DMA_PRIO 0   // 1: s_setprio 1 around the QK^T MFMA cluster, 2: around both MFMA clusters
+#endif
+
+namespace fa {
+
+// (the body lives in a __device__ function: the buffer/LDS-DMA builtins do not exist for the host pass,
+// and a __global__ template that names them loses its host-side launch stub)
+template <typename T, int D, int NWAVES>
+__device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
+    using E = Elt<T>;
+    using vec8 = typename E::vec8;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    constexpr int BQ = NWAVES * 32;
+    constexpr int BK = 64;
+    constexpr int ROWB = D * 2;
+    constexpr int KTILE_B = BK * ROWB;
+    constexpr int VBLK_B = BK * 64 + 64;
+    constexpr int VTILE_B = (D / 32) * VBLK_B;
+    constexpr int PIECES = KTILE_B / 1024;      // 1 KiB DMA pieces per K (or V) tile
+    constexpr int PPW = PIECES / NWAVES;        // pieces per wave
+    constexpr int KS = D / 16;
+    constexpr int DT = D / 32;
+    static_assert(PIECES % NWAVES == 0 && PPW >= 1, "pieces must split evenly over the waves");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KTILE_B + 2 * VTILE_B];  // K0 K1 V0 V1
+    unsigned char* const smem_v = smem + 2 * KTILE_B;
+
+    const int b = blockIdx.x;
+    const int nq = p.nq_tiles;
+    int g, qi;
+    {
+        const int xcd = b & 7, slot = b >> 3;
+        const int ng = p.G8 >> 3;
+        const int per_bunch = p.sched * nq;
+        const int bunch = slot / per_bunch;
+        const int rem = slot - bunch * per_bunch;
+        const int g0 = bunch * p.sched;
+        const int bc = (ng - g0) < p.sched ? (ng - g0) : p.sched;
+        const int qd = rem / bc;
+        qi = nq - 1 - qd;
+        g = (g0 + (rem - qd * bc)) * 8 + xcd;
+    }
+    if (g >= p.G) return;
+
+    const int L = p.L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base -> M0)
+    const int r = lane & 31, h = lane >> 5;
+    const int bb = g / p.H, hh = g - bb * p.H;
+    const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
+    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
+    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+
+    const int q_row0 = qi * BQ + wave * 32;
+    const int qrow = q_row0 + r;
+    const bool wave_active = q_row0 < L;
+
+    vec8 qf[KS];
+    {
+        const int qr = qrow < L ? qrow : L - 1;
+        const T* qp = qg + (int64_t)qr * p.q_sl + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const vec8*)(qp + 16 * ks);
+    }
+
+    // ---- LDS-DMA geometry: piece pc = wave + j*NWAVES of a tile, lane -> source byte offset
+    const unsigned k_slb = (unsigned)p.k_sl * 2, v_slb = (unsigned)p.v_sl * 2;   // row strides in bytes
+    unsigned k_vo[PPW], v_vo[PPW];
+    int k_dst[PPW], v_dst[PPW];    // wave-uniform LDS byte offsets of the pieces inside a tile buffer
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pc = wave + j * NWAVES;
+        // K: lane-linear piece = 1024/ROWB rows; LDS chunk position cp of row holds global chunk cp ^ swz(row)
+        const int row = pc * (1024 / ROWB) + lane / (ROWB / 16);
+        const int cp = lane % (ROWB / 16);
+        const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+        k_vo[j] = (unsigned)row * k_slb + ((cp ^ sw) << 4);
+        k_dst[j] = pc * 1024;
+        // V: piece = two 8-key blocks of one 32-column d-block
+        const int dblk = pc >> 2, q2 = pc & 3;
+        const int key = (2 * q2 + (lane >> 5)) * 8 + ((lane >> 2) & 7);
+        v_vo[j] = (unsigned)key * v_slb + ((dblk * 4 + (lane & 3)) << 4);
+        v_dst[j] = dblk * VBLK_B + q2 * 1024;
+    }
+    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;   // extent of this group's K
+    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
+
+    // tile T_ -> buffer BUF_: descriptors start at the tile's first row; rows past L read as zeros
+#define FA_DMA_TILE(T_, BUF_)                                                                      \
+    {                                                                                              \
+        const unsigned ko_ = (unsigned)(T_) * BK * k_slb, vo_ = (unsigned)(T_) * BK * v_slb;       \
+        const auto kr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)kg + ko_), (short)0, \
+                                                           (int)(k_bytes - ko_), 0x00020000);      \
+        const auto vr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)vg + vo_), (short)0, \
+                                                           (int)(v_bytes - vo_), 0x00020000);      \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                kr_, (__attribute__((address_space(3))) void*)(smem + (BUF_) * KTILE_B + k_dst[j]), \
+                16, k_vo[j], 0, 0, 0);                                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                vr_, (__attribute__((address_space(3))) void*)(smem_v + (BUF_) * VTILE_B + v_dst[j]), \
+                16, v_vo[j], 0, 0, 0);                                                             \
+        }                                                                                          \
+    }
+
+    int k_rd[KS];
+    {
+        const int sw = (D == 64) ? ((r >> 1) & 7) : (r & 15);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * ROWB + (((2 * ks + h) ^ sw) << 4);
+    }
+    const int v_rd = (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    const int n_tiles = (kv_end + BK - 1) / BK;
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    float m = -INFINITY;
+    float l = 0.f;
+    const float c = p.scale_log2;
+    f32x16 lacc;
+    vec8 ones;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+
+    // one kv tile from buffer BUF_ (compile-time): identical arithmetic to fa_fwd_tile_kernel
+#define FA_COMPUTE(T_, BUF_)                                                                       \
+    {                                                                                              \
+        const int kv0 = (T_) * BK;                                                                 \
+        if (wave_active && kv0 <= q_row0 + 31) {                                                   \
+            const unsigned char* kb_ = smem + (BUF_) * KTILE_B;                                    \
+            const unsigned char* vb_ = smem_v + (BUF_) * VTILE_B;                                  \
+            f32x16 s0, s1;                                                                         \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }           \
+            if (FA_DMA_PRIO >= 1) __builtin_amdgcn_s_setprio(1);                                   \
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                    \
+                const vec8 k0 = *(const vec8*)(kb_ + k_rd[ks]);                                    \
+                const vec8 k1 = *(const vec8*)(kb_ + 32 * ROWB + k_rd[ks]);                        \
+                s0 = E::mfma(k0, qf[ks], s0);                                                      \
+                s1 = E::mfma(k1, qf[ks], s1);                                                      \
+            }                                                                                      \
+            if (FA_DMA_PRIO >= 1) __builtin_amdgcn_s_setprio(0);                                   \
+            if (kv0 + BK - 1 > q_row0) {                                                           \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                   \
+                    const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;                          \
+                    if (key > qrow) s0[e] = -INFINITY;                                             \
+                    if (key + 32 > qrow) s1[e] = -INFINITY;                                        \
+                }                                                                                  \
+            }                                                                                      \
+            float mx = max2(s0[0], s1[0]);                                                         \
+            _Pragma("unroll") for (int e = 1; e < 16; ++e) mx = max3(mx, s0[e], s1[e]);            \
+            mx = half_swap_max(mx);                                                                \
+            if (__builtin_amdgcn_ballot_w64((mx - m) * c > RESCALE_THR) != 0) {                    \
+                const float m_new = max2(m, mx);                                                   \
+                const float alpha = fast_exp2((m - m_new) * c);                                    \
+                m = m_new;                                                                         \
+                l *= alpha;                                                                        \
+                if (FA_DMA_ONES) { _Pragma("unroll") for (int e = 0; e < 16; ++e) lacc[e] *= alpha; } \
+                _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                  \
+                    _Pragma("unroll") for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;              \
+            }                                                                                      \
+            const float mc = m * c;                                                                \
+            float ls = 0.f;                                                                        \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                       \
+                s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -mc));                                  \
+                s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -mc));                                  \
+                if (!FA_DMA_ONES) { ls += s0[e]; ls += s1[e]; }                                    \
+            }                                                                                      \
+            l += ls;                                                                               \
+            if (FA_DMA_PRIO >= 2) __builtin_amdgcn_s_setprio(1);                                   \
+            vec8 pf[4];                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
+                pf[0][j] = (T)s0[j];                                                               \
+                pf[1][j] = (T)s0[8 + j];                                                           \
+                pf[2][j] = (T)s1[j];                                                               \
+                pf[3][j] = (T)s1[8 + j];                                                           \
+            }                                                                                      \
+            _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                    \
+                _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                 \
+                    const unsigned char* vp = vb_ + dt * VBLK_B + kk * 1024 + v_rd;                \
+                    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                      \
+                        (i16x4 __attribute__((address_space(3)))*)(vp));                           \
+                    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                      \
+                        (i16x4 __attribute__((address_space(3)))*)(vp + 512));                     \
+                    const i16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);      \
+                    o[dt] = E::mfma(__builtin_bit_cast(vec8, v8), pf[kk], o[dt]);                  \
+                }                                                                                  \
+            }                                                                                      \
+            if (FA_DMA_ONES) {                                                                     \
+                _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) lacc = E::mfma(ones, pf[kk], lacc); \
+            }                                                                                      \
+            if (FA_DMA_PRIO >= 2) __builtin_amdgcn_s_setprio(0);                                   \
+        }                                                                                          \
+    }
+
+    FA_DMA_TILE(0, 0)
+    __syncthreads();   // (drains the DMA: an LDS-DMA is a pending LDS write on the vector-memory counter)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q landed (see fa_fwd_tile_kernel)
+
+    for (int t = 0; t < n_tiles; t += 2) {
+        if (t + 1 < n_tiles) FA_DMA_TILE(t + 1, 1)
+        FA_COMPUTE(t, 0)
+        __syncthreads();
+        if (t + 1 < n_tiles) {
+            if (t + 2 < n_tiles) FA_DMA_TILE(t + 2, 0)
+            FA_COMPUTE(t + 1, 1)
+            __syncthreads();
+        }
+    }
+#undef FA_DMA_TILE
+#undef FA_COMPUTE
+
+    if (!wave_active || qrow >= L) return;
+    const float lt = FA_DMA_ONES ? lacc[0] : half_swap_sum(l);
+    const float inv = __builtin_amdgcn_rcpf(lt);
+    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)qrow * p.o_sl;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            vec4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (T)(o[dt][4 * rg + j] * inv);
+            *(vec4*)(og + 32 * dt + 8 * rg + 4 * h) = w;
+        }
+    }
+    if (p.lse != nullptr && h == 0) p.lse[(int64_t)g * L + qrow] = m * p.scale + __logf(lt);
+}
+
+template <typename T, int D, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void fa_fwd_dma_kernel(const FwdParams p) {
+    fa_fwd_dma_body<T, D, NWAVES>(p);
+}
+
+template <typename T, int D>
+static hipError_t launch_dma_w(const FwdParams& p, int waves, hipStream_t stream) {
+    const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
+    switch (waves) {
+        case 8: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 8>), dim3((unsigned)grid), dim3(512), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 2>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
+        default: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
+    if (dtype == 1) {
+        return p.D == 64 ? launch_dma_w<__bf16, 64>(p, waves, stream) : launch_dma_w<__bf16, 128>(p, waves, stream);
+    }
+    return p.D == 64 ? launch_dma_w<_Float16, 64>(p, waves, stream) : launch_dma_w<_Float16, 128>(p, waves, stream);
+}
+
+}  // namespace fa

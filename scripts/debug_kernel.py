@@ -14,12 +14,14 @@ def run(tag, qkv, nq=1, nk=1):
     rows_bad = bad.any(-1).nonzero()
     print(f"{tag:40s} max|d|={err.max().item():.3e} bad={int(bad.sum())}/{bad.numel()} first_bad_rows={rows_bad[:6].tolist()}", flush=True)
 
-for dt in (torch.bfloat16, torch.float16):
-    for waves in ("1", "2", "4", "8"):
-        os.environ["FA_AMD_WAVES"] = waves
-        for (G, L, D) in [(1, 32, 64), (1, 64, 64), (1, 128, 64), (2, 320, 64), (1, 128, 128), (2, 320, 128)]:
-            x = frozen_randn(7 + L + D, (3, G, L, D)).to(dt)
-            run(f"{dt} w={waves} randn {G}x{L}x{D}", x)
-        # structured: zero q,k => uniform softmax => running mean of v
-        x = frozen_randn(3, (3, 1, 128, 64)).to(dt); x[0] = 0; x[1] = 0
-        run(f"{dt} w={waves} uniform-softmax", x)
+for kern in os.environ.get("DEBUG_KERNELS", "tile").split(","):
+    os.environ["FA_AMD_KERNEL"] = kern
+    for dt in (torch.bfloat16, torch.float16):
+        for waves in ("1", "2", "4", "8"):
+            os.environ["FA_AMD_WAVES"] = waves
+            for (G, L, D) in [(1, 32, 64), (1, 64, 64), (1, 128, 64), (2, 320, 64), (3, 1000, 64), (1, 128, 128), (2, 320, 128), (2, 777, 128)]:
+                x = frozen_randn(7 + L + D, (3, G, L, D)).to(dt)
+                run(f"{kern} {dt} w={waves} randn {G}x{L}x{D}", x)
+            # structured: zero q,k => uniform softmax => running mean of v
+            x = frozen_randn(3, (3, 1, 128, 64)).to(dt); x[0] = 0; x[1] = 0
+            run(f"{kern} {dt} w={waves} uniform-softmax", x)
