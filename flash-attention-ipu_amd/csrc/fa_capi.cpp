@@ -182,12 +182,12 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
 
-    // MFMA kernels: "tile" (register-staged), "dma" (LDS-DMA staged), "pipe" (software-pipelined)
-    char which = (D == 64) ? 'd' : 't';
+    // MFMA kernels: "dma" (LDS-DMA staged, default: 1.13-1.15x the register-staged one on every shape
+    // measured) or "tile" (register-staged; FA_AMD_KERNEL=tile selects it for A/B runs)
+    char which = 'd';
     const char* kv = getenv("FA_AMD_KERNEL");
-    if (kv && (kv[0] == 'p' || kv[0] == 't' || kv[0] == 'd')) which = kv[0];
+    if (kv && (kv[0] == 't' || kv[0] == 'd')) which = kv[0];
     hipError_t e = plan.kernel != 0 ? fa::launch_fwd_generic(p, dtype, (hipStream_t)stream)
-                   : which == 'p'   ? fa::launch_fwd_pipe(p, dtype, plan.waves, (hipStream_t)stream)
                    : which == 'd'   ? fa::launch_fwd_dma(p, dtype, plan.waves, (hipStream_t)stream)
                                     : fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

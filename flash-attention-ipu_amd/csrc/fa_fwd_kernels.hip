@@ -22,6 +22,10 @@
 //     mask-block machinery (FA.cpp:47-173) is not needed;
 //   * softmax uses exp2 with the scale folded (p = 2^(s*c - m*c), c = scale*log2 e).
 //
+// This file holds the register-staged form of the kernel (HBM -> VGPR -> ds_write -> LDS).  The
+// shipped default is its LDS-DMA form in fa_fwd_dma.hip (same tiling and arithmetic, bit-identical
+// results); this one stays selectable (FA_AMD_KERNEL=tile) as the A/B baseline.
+//
 // A second, generic kernel covers every other shape/dtype (fp32, D not in {64,128}, unaligned
 // rows): one workgroup per query row, fp32 arithmetic.
 

@@ -30,7 +30,6 @@ struct FwdParams {
 };
 
 hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream);
-hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream);
 
