@@ -74,9 +74,9 @@ def test_plan_maps_chunks_to_hardware_tiles(native):
     # chunk length is an upper bound on the tile; >= 128 rows -> the 4-wave 128-row tile
     p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)       # config 2: heuristic (8,8) -> 512x512 chunks
     assert (p.kernel, p.block_q, p.block_kv, p.waves, p.chunk_q, p.chunk_kv) == (0, 128, 64, 4, 512, 512)
-    assert p.grid == 128 * 32 and p.lds_bytes == 32768
+    assert p.grid == 128 * 32 and p.lds_bytes == 2 * 8192 + 4 * (4096 + 64)
     p = native.plan(16, 32768, 128, torch.bfloat16, 16, 16)    # config 3
-    assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 128, 4, 65536)
+    assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 128, 4, 2 * 16384 + 8 * (4096 + 64))
     assert native.plan(4, 4096, 64, torch.float16, 64, 64).block_q == 64     # 64-row chunks honoured
     assert native.plan(4, 4096, 64, torch.float16, 128, 64).block_q == 32    # 32-row chunks honoured
     assert native.plan(5, 200, 64, torch.bfloat16, 1, 1).grid == 8 * 2       # G padded to the 8 XCDs
