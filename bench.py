@@ -179,7 +179,7 @@ def main():
             "pct_mfma_peak": round(100.0 * total_tflops / (world * PEAK_TFLOPS), 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "fa_fwd_tile_kernel", "avg_launch_ms": round(kernel_ms, 4),
+                         "kernel": "fa_fwd_dma_kernel", "avg_launch_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": 4 * G * L * D * 2},
         }
         if not args.no_cpu_baseline and world == 1:
