@@ -89,10 +89,18 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no fallback)")
+    # FA_BENCH_REHEARSE=1: developer rehearsal of the N>1 control flow on a ONE-GPU box (all ranks on
+    # cuda:0, gloo instead of RCCL).  Never set by the driver; the numbers it prints mean nothing.
+    rehearse = os.environ.get("FA_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     import flash_attention_amd as fa
