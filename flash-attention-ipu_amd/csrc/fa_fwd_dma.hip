@@ -17,14 +17,6 @@
 
 #include "fa_device.h"
 
-// experiment knobs (scripts/sweep.py builds variants with -D...)
-#ifndef FA_DMA_ONES
-#define FA_DMA_ONES 0   // 1: row sums on the matrix pipe (l += 1^T P^T, 4 MFMAs) instead of 32 v_add per tile
-#endif
-#ifndef FA_DMA_PRIO
-#define FA_DMA_PRIO 0   // 1: s_setprio 1 around the QK^T MFMA cluster, 2: around both MFMA clusters
-#endif
-
 namespace fa {
 
 // (the body lives in a __device__ function: the buffer/LDS-DMA builtins do not exist for the host pass,
@@ -146,80 +138,87 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     float m = -INFINITY;
     float l = 0.f;
     const float c = p.scale_log2;
-    f32x16 lacc;
-    vec8 ones;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
 
-    // one kv tile from buffer BUF_ (compile-time): identical arithmetic to fa_fwd_tile_kernel
+    // ---- the pieces of one kv tile (buffer index BUF_ is compile-time); same arithmetic as fa_fwd_tile_kernel
+#define FA_QK(BUF_)                                                                                \
+    {                                                                                              \
+        const unsigned char* kb_ = smem + (BUF_) * KTILE_B;                                        \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }               \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                        \
+            const vec8 k0 = *(const vec8*)(kb_ + k_rd[ks]);                                        \
+            const vec8 k1 = *(const vec8*)(kb_ + 32 * ROWB + k_rd[ks]);                            \
+            s0 = E::mfma(k0, qf[ks], s0);                                                          \
+            s1 = E::mfma(k1, qf[ks], s1);                                                          \
+        }                                                                                          \
+        if (kv0 + BK - 1 > q_row0) { /* the wave's diagonal tile */                                \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                       \
+                const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;                              \
+                if (key > qrow) s0[e] = -INFINITY;                                                 \
+                if (key + 32 > qrow) s1[e] = -INFINITY;                                            \
+            }                                                                                      \
+        }                                                                                          \
+    }
+    // row max of the tile, then raise the reference max m (rescaling O and l) where it is outgrown by
+    // more than THR_ (log2 units); decided BEFORE the tile's P is formed
+#define FA_MAX_RESCALE(THR_)                                                                       \
+    {                                                                                              \
+        float mx = max2(s0[0], s1[0]);                                                             \
+        _Pragma("unroll") for (int e = 1; e < 16; ++e) mx = max3(mx, s0[e], s1[e]);                \
+        mx = half_swap_max(mx);                                                                    \
+        if (__builtin_amdgcn_ballot_w64((mx - m) * c > (THR_)) != 0) {                             \
+            const float m_new = max2(m, mx);                                                       \
+            const float alpha = fast_exp2((m - m_new) * c);                                        \
+            m = m_new;                                                                             \
+            l *= alpha;                                                                            \
+            _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                      \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;                  \
+        }                                                                                          \
+    }
+    // P = 2^(s*c - m*c) in place, ls = this lane's part of the row sum
+#define FA_SOFTMAX()                                                                               \
+    {                                                                                              \
+        const float mc = m * c;                                                                    \
+        ls = 0.f;                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                           \
+            s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -mc));                                      \
+            s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -mc));                                      \
+            ls += s0[e];                                                                           \
+            ls += s1[e];                                                                           \
+        }                                                                                          \
+    }
+#define FA_PV(BUF_)                                                                                \
+    {                                                                                              \
+        const unsigned char* vb_ = smem_v + (BUF_) * VTILE_B;                                      \
+        vec8 pf[4];                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+            pf[0][j] = (T)s0[j];                                                                   \
+            pf[1][j] = (T)s0[8 + j];                                                               \
+            pf[2][j] = (T)s1[j];                                                                   \
+            pf[3][j] = (T)s1[8 + j];                                                               \
+        }                                                                                          \
+        _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                        \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                     \
+                const unsigned char* vp = vb_ + dt * VBLK_B + kk * 1024 + v_rd;                    \
+                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
+                    (i16x4 __attribute__((address_space(3)))*)(vp));                               \
+                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
+                    (i16x4 __attribute__((address_space(3)))*)(vp + 512));                         \
+                const i16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);          \
+                o[dt] = E::mfma(__builtin_bit_cast(vec8, v8), pf[kk], o[dt]);                      \
+            }                                                                                      \
+        }                                                                                          \
+    }
 #define FA_COMPUTE(T_, BUF_)                                                                       \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
         if (wave_active && kv0 <= q_row0 + 31) {                                                   \
-            const unsigned char* kb_ = smem + (BUF_) * KTILE_B;                                    \
-            const unsigned char* vb_ = smem_v + (BUF_) * VTILE_B;                                  \
             f32x16 s0, s1;                                                                         \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }           \
-            if (FA_DMA_PRIO >= 1) __builtin_amdgcn_s_setprio(1);                                   \
-            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                    \
-                const vec8 k0 = *(const vec8*)(kb_ + k_rd[ks]);                                    \
-                const vec8 k1 = *(const vec8*)(kb_ + 32 * ROWB + k_rd[ks]);                        \
-                s0 = E::mfma(k0, qf[ks], s0);                                                      \
-                s1 = E::mfma(k1, qf[ks], s1);                                                      \
-            }                                                                                      \
-            if (FA_DMA_PRIO >= 1) __builtin_amdgcn_s_setprio(0);                                   \
-            if (kv0 + BK - 1 > q_row0) {                                                           \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                   \
-                    const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;                          \
-                    if (key > qrow) s0[e] = -INFINITY;                                             \
-                    if (key + 32 > qrow) s1[e] = -INFINITY;                                        \
-                }                                                                                  \
-            }                                                                                      \
-            float mx = max2(s0[0], s1[0]);                                                         \
-            _Pragma("unroll") for (int e = 1; e < 16; ++e) mx = max3(mx, s0[e], s1[e]);            \
-            mx = half_swap_max(mx);                                                                \
-            if (__builtin_amdgcn_ballot_w64((mx - m) * c > RESCALE_THR) != 0) {                    \
-                const float m_new = max2(m, mx);                                                   \
-                const float alpha = fast_exp2((m - m_new) * c);                                    \
-                m = m_new;                                                                         \
-                l *= alpha;                                                                        \
-                if (FA_DMA_ONES) { _Pragma("unroll") for (int e = 0; e < 16; ++e) lacc[e] *= alpha; } \
-                _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                  \
-                    _Pragma("unroll") for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;              \
-            }                                                                                      \
-            const float mc = m * c;                                                                \
-            float ls = 0.f;                                                                        \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                       \
-                s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -mc));                                  \
-                s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -mc));                                  \
-                if (!FA_DMA_ONES) { ls += s0[e]; ls += s1[e]; }                                    \
-            }                                                                                      \
+            float ls;                                                                              \
+            FA_QK(BUF_)                                                                            \
+            FA_MAX_RESCALE(RESCALE_THR)                                                            \
+            FA_SOFTMAX()                                                                           \
             l += ls;                                                                               \
-            if (FA_DMA_PRIO >= 2) __builtin_amdgcn_s_setprio(1);                                   \
-            vec8 pf[4];                                                                            \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
-                pf[0][j] = (T)s0[j];                                                               \
-                pf[1][j] = (T)s0[8 + j];                                                           \
-                pf[2][j] = (T)s1[j];                                                               \
-                pf[3][j] = (T)s1[8 + j];                                                           \
-            }                                                                                      \
-            _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                    \
-                _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                 \
-                    const unsigned char* vp = vb_ + dt * VBLK_B + kk * 1024 + v_rd;                \
-                    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                      \
-                        (i16x4 __attribute__((address_space(3)))*)(vp));                           \
-                    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                      \
-                        (i16x4 __attribute__((address_space(3)))*)(vp + 512));                     \
-                    const i16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);      \
-                    o[dt] = E::mfma(__builtin_bit_cast(vec8, v8), pf[kk], o[dt]);                  \
-                }                                                                                  \
-            }                                                                                      \
-            if (FA_DMA_ONES) {                                                                     \
-                _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) lacc = E::mfma(ones, pf[kk], lacc); \
-            }                                                                                      \
-            if (FA_DMA_PRIO >= 2) __builtin_amdgcn_s_setprio(0);                                   \
+            FA_PV(BUF_)                                                                            \
         }                                                                                          \
     }
 
@@ -240,9 +239,13 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     }
 #undef FA_DMA_TILE
 #undef FA_COMPUTE
+#undef FA_QK
+#undef FA_MAX_RESCALE
+#undef FA_SOFTMAX
+#undef FA_PV
 
     if (!wave_active || qrow >= L) return;
-    const float lt = FA_DMA_ONES ? lacc[0] : half_swap_sum(l);
+    const float lt = half_swap_sum(l);
     const float inv = __builtin_amdgcn_rcpf(lt);
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)qrow * p.o_sl;
 #pragma unroll
@@ -258,6 +261,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     if (p.lse != nullptr && h == 0) p.lse[(int64_t)g * L + qrow] = m * p.scale + __logf(lt);
 }
 
+// D=64 at 4+ waves per workgroup is built for 4 waves per SIMD (<= 128 VGPRs)
 template <typename T, int D, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_dma_kernel(const FwdParams p) {
     fa_fwd_dma_body<T, D, NWAVES>(p);
