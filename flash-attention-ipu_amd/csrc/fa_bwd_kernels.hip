@@ -1,0 +1,515 @@
+// FlashAttention backward for MI355X (gfx950): dQ, dK, dV of the causal forward in fa_fwd_dma.hip.
+//
+// Replaces the Poplar program built by flashAttentionQKVPackedGrad
+// (flash_attention_ipu/cpp/flash_attention_qkv_packed.cpp:348-512): recompute the scores from Q, K and
+// the forward's logSumExp, then   P = exp(S - lse),  dV += P^T dO,  dP = dO V^T,
+// dS = P o (dP - rowsum(dO o O)),  dQ += dS K,  dK += dS^T Q   (FA.cpp:452-472).
+// The reference runs one kv-outer / q-inner double loop that updates dQ in place; here the work is
+// split so that no gradient is ever summed across workgroups (deterministic, no atomics):
+//
+//   fa_bwd_dsum_kernel   Dsum[g,r] = sum_d dO[g,r,d] * O[g,r,d]           (FA.cpp:375-378)
+//   fa_bwd_dq_kernel     one workgroup per (group, 128 query rows): sweeps kv tiles <= diagonal,
+//                        dQ^T += K^T dS^T with the query row on the lane (same shape as the forward)
+//   fa_bwd_dkdv_kernel   one workgroup per (group, 128 keys): sweeps 64-row query tiles >= diagonal,
+//                        dV^T += dO^T P and dK^T += Q^T dS with the KEY on the lane, so the score and
+//                        dP accumulators are already the B operands of those two products.
+//
+// Every streamed tile (K, V in the dq kernel; Q, dO in the dkdv kernel) is consumed twice: by rows
+// (A operand of the score products, ds_read_b128) and transposed (A operand of the gradient products,
+// ds_read_b64_tr_b16).  One LDS image serves both: [d/32][row/8][8 rows][4 x 16-B chunks], chunk slot
+// XORed with (row>>2)&3 - conflict-free for both read kinds - filled by LDS-DMA with per-lane source
+// addresses, exactly like the forward's V image.
+// MFMA operand maps, the accumulator-as-operand trick and the DMA descriptor handling are the ones
+// documented in fa_fwd_kernels.hip / fa_fwd_dma.hip.
+
+#include "fa_device.h"
+
+namespace fa {
+
+// ---------------------------------------------------------------------------------------------
+// Dsum = rowsum(dO o O), one 16-byte chunk per thread, D/8 threads per row
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void fa_bwd_dsum_kernel(const BwdParams p) {
+    constexpr int TPR = D / 8;              // threads per row
+    constexpr int RPB = 256 / TPR;          // rows per block
+    typedef T vec8 __attribute__((ext_vector_type(8)));
+    const int64_t row_lin = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;   // over G*L
+    const int ch = threadIdx.x % TPR;
+    float acc = 0.f;
+    const bool ok = row_lin < (int64_t)p.G * p.L;
+    if (ok) {
+        const int g = (int)(row_lin / p.L), r = (int)(row_lin - (int64_t)g * p.L);
+        const int bb = g / p.H, hh = g - bb * p.H;
+        const T* op = (const T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)r * p.o_sl + ch * 8;
+        const T* gp = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh + (int64_t)r * p.do_sl + ch * 8;
+        const vec8 a = *(const vec8*)op, b = *(const vec8*)gp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
+    }
+#pragma unroll
+    for (int off = TPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (ok && ch == 0) p.dsum[row_lin] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared pieces of the two gradient kernels
+// ---------------------------------------------------------------------------------------------
+constexpr float LOG2E = 1.4426950408889634f;
+
+// dual-use tile image (see header): byte offset of 16-B chunk `chunk` of row `row` (row < 64)
+__device__ __forceinline__ int img_addr(int row, int chunk) {
+    return (chunk >> 2) * 4096 + (row >> 3) * 512 + (row & 7) * 64 + (((chunk & 3) ^ ((row >> 2) & 3)) << 4);
+}
+
+template <typename T, int D, int NWAVES>
+struct BwdGeom {
+    static constexpr int IMG_B = (D / 32) * 4096;    // bytes per 64-row tile image
+    static constexpr int PIECES = IMG_B / 1024;      // 1 KiB DMA pieces per image
+    static constexpr int PPW = PIECES / NWAVES;      // pieces per wave
+    static constexpr int KS = D / 16;
+    static constexpr int DT = D / 32;
+    static_assert(PIECES % NWAVES == 0 && PPW >= 1, "pieces must split evenly over the waves");
+};
+
+// which (group, block-of-128) does this workgroup own: same XCD-aware bunched order as the forward;
+// `heavy_first_desc` picks whether block index 0 or nblk-1 is the heaviest.
+__device__ __forceinline__ bool bwd_block_map(int G8, int G, int sched, int nblk, bool heavy_is_last, int& g, int& blk) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int ng = G8 >> 3;
+    const int per_bunch = sched * nblk;
+    const int bunch = slot / per_bunch;
+    const int rem = slot - bunch * per_bunch;
+    const int g0 = bunch * sched;
+    const int bc = (ng - g0) < sched ? (ng - g0) : sched;
+    const int qd = rem / bc;
+    blk = heavy_is_last ? nblk - 1 - qd : qd;
+    g = (g0 + (rem - qd * bc)) * 8 + xcd;
+    return g < G;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dQ: one workgroup = NWAVES x 32 query rows; streams K and V tiles of 64 keys
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int NWAVES>
+__device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
+    using E = Elt<T>;
+    using vec8 = typename E::vec8;
+    using GM = BwdGeom<T, D, NWAVES>;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    constexpr int BQ = NWAVES * 32, BK = 64, KS = GM::KS, DT = GM::DT, IMG_B = GM::IMG_B, PPW = GM::PPW;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * IMG_B];   // K0 K1 V0 V1
+    unsigned char* const smem_v = smem + 2 * IMG_B;
+
+    int g, qi;
+    if (!bwd_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, g, qi)) return;
+
+    const int L = p.L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bb = g / p.H, hh = g - bb * p.H;
+    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
+    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+
+    const int q_row0 = qi * BQ + wave * 32;
+    const int qrow = q_row0 + r;
+    const bool wave_active = q_row0 < L;
+    const int qr = qrow < L ? qrow : L - 1;
+
+    // B operands: Q^T and dO^T fragments of this lane's query row; per-row constants
+    vec8 qf[KS], dof[KS];
+    {
+        const T* qp = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh + (int64_t)qr * p.q_sl + 8 * h;
+        const T* gp = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh + (int64_t)qr * p.do_sl + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *(const vec8*)(qp + 16 * ks);
+            dof[ks] = *(const vec8*)(gp + 16 * ks);
+        }
+    }
+    const float lse2 = p.lse[(int64_t)g * L + qr] * LOG2E;
+    const float dsum = p.dsum[(int64_t)g * L + qr];
+    const float c = p.scale_log2;
+
+    // LDS-DMA geometry (pieces pc = wave + j*NWAVES of each image)
+    const unsigned k_slb = (unsigned)p.k_sl * 2, v_slb = (unsigned)p.v_sl * 2;
+    unsigned k_vo[PPW], v_vo[PPW];
+    int dst[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pc = wave + j * NWAVES;
+        const int row = (2 * (pc & 3) + (lane >> 5)) * 8 + ((lane >> 2) & 7);
+        const int chunk = (pc >> 2) * 4 + ((lane & 3) ^ ((row >> 2) & 3));
+        k_vo[j] = (unsigned)row * k_slb + (chunk << 4);
+        v_vo[j] = (unsigned)row * v_slb + (chunk << 4);
+        dst[j] = (pc >> 2) * 4096 + (pc & 3) * 1024;
+    }
+    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;
+    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
+#define FA_DMA_KV(T_, BUF_)                                                                        \
+    {                                                                                              \
+        const unsigned ko_ = (unsigned)(T_) * BK * k_slb, vo_ = (unsigned)(T_) * BK * v_slb;       \
+        const auto kr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)kg + ko_), (short)0, \
+                                                           (int)(k_bytes - ko_), 0x00020000);      \
+        const auto vr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)vg + vo_), (short)0, \
+                                                           (int)(v_bytes - vo_), 0x00020000);      \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                kr_, (__attribute__((address_space(3))) void*)(smem + (BUF_) * IMG_B + dst[j]), 16, k_vo[j], 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                vr_, (__attribute__((address_space(3))) void*)(smem_v + (BUF_) * IMG_B + dst[j]), 16, v_vo[j], 0, 0, 0); \
+        }                                                                                          \
+    }
+
+    // LDS read addresses: row reads (A operand rows = 32*blk + r) and transposed reads
+    int a_rd[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a_rd[ks] = img_addr(r, 2 * ks + h);
+    const int rowin8 = 4 * h + ((lane & 15) >> 2);
+    const int c4 = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+    const int trb0 = rowin8 * 64 + ((c4 ^ h) << 4) + (lane & 1) * 8;
+    const int trb1 = rowin8 * 64 + ((c4 ^ (2 + h)) << 4) + (lane & 1) * 8;
+
+    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    const int n_tiles = (kv_end + BK - 1) / BK;
+
+    f32x16 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+
+#define FA_DQ_TILE(T_, BUF_)                                                                       \
+    {                                                                                              \
+        const int kv0 = (T_) * BK;                                                                 \
+        if (wave_active && kv0 <= q_row0 + 31) {                                                   \
+            const unsigned char* kb_ = smem + (BUF_) * IMG_B;                                      \
+            const unsigned char* vb_ = smem_v + (BUF_) * IMG_B;                                    \
+            f32x16 s0, s1, t0, t1;                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; t0[e] = 0.f; t1[e] = 0.f; } \
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                    \
+                s0 = E::mfma(*(const vec8*)(kb_ + a_rd[ks]), qf[ks], s0);                          \
+                s1 = E::mfma(*(const vec8*)(kb_ + 2048 + a_rd[ks]), qf[ks], s1);                   \
+                t0 = E::mfma(*(const vec8*)(vb_ + a_rd[ks]), dof[ks], t0);                         \
+                t1 = E::mfma(*(const vec8*)(vb_ + 2048 + a_rd[ks]), dof[ks], t1);                  \
+            }                                                                                      \
+            if (kv0 + BK - 1 > q_row0) {                                                           \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                   \
+                    const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;                          \
+                    if (key > qrow) s0[e] = -INFINITY;                                             \
+                    if (key + 32 > qrow) s1[e] = -INFINITY;                                        \
+                }                                                                                  \
+            }                                                                                      \
+            /* dS^T = P^T o (dP^T - Dsum), P^T = 2^(S^T c - lse2): the row constants are lane scalars */ \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                       \
+                s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -lse2)) * (t0[e] - dsum);               \
+                s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -lse2)) * (t1[e] - dsum);               \
+            }                                                                                      \
+            vec8 dsf[4];                                                                           \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
+                dsf[0][j] = (T)s0[j];                                                              \
+                dsf[1][j] = (T)s0[8 + j];                                                          \
+                dsf[2][j] = (T)s1[j];                                                              \
+                dsf[3][j] = (T)s1[8 + j];                                                          \
+            }                                                                                      \
+            /* dQ^T += K^T dS^T */                                                                 \
+            _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                    \
+                _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                 \
+                    const unsigned char* ap = kb_ + dt * 4096 + kk * 1024;                         \
+                    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                      \
+                        (i16x4 __attribute__((address_space(3)))*)(ap + trb0));                    \
+                    const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                      \
+                        (i16x4 __attribute__((address_space(3)))*)(ap + 512 + trb1));              \
+                    const i16x8 a8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);      \
+                    dq[dt] = E::mfma(__builtin_bit_cast(vec8, a8), dsf[kk], dq[dt]);               \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+    FA_DMA_KV(0, 0)
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));   // row operands landed
+
+    for (int t = 0; t < n_tiles; t += 2) {
+        if (t + 1 < n_tiles) FA_DMA_KV(t + 1, 1)
+        FA_DQ_TILE(t, 0)
+        __syncthreads();
+        if (t + 1 < n_tiles) {
+            if (t + 2 < n_tiles) FA_DMA_KV(t + 2, 0)
+            FA_DQ_TILE(t + 1, 1)
+            __syncthreads();
+        }
+    }
+#undef FA_DMA_KV
+#undef FA_DQ_TILE
+
+    if (!wave_active || qrow >= L) return;
+    T* __restrict__ og = (T*)p.dq + (int64_t)bb * p.dq_sb + (int64_t)hh * p.dq_sh + (int64_t)qrow * p.dq_sl;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            vec4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (T)(dq[dt][4 * rg + j] * p.scale);
+            *(vec4*)(og + 32 * dt + 8 * rg + 4 * h) = w;
+        }
+    }
+}
+
+template <typename T, int D, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dq_kernel(const BwdParams p) {
+    fa_bwd_dq_body<T, D, NWAVES>(p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dK, dV: one workgroup = NWAVES x 32 keys; streams Q and dO tiles of 64 query rows
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int NWAVES>
+__device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
+    using E = Elt<T>;
+    using vec8 = typename E::vec8;
+    using GM = BwdGeom<T, D, NWAVES>;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int BKW = NWAVES * 32, BQ = 64, KS = GM::KS, DT = GM::DT, IMG_B = GM::IMG_B, PPW = GM::PPW;
+
+    // Q0 Q1 dO0 dO1 images, then per-buffer row constants: lse2[64], dsum[64]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * IMG_B + 2 * 512];
+    unsigned char* const smem_g = smem + 2 * IMG_B;
+    float* const rowc = (float*)(smem + 4 * IMG_B);      // [buf][ lse2 0..63 | dsum 0..63 ]
+
+    int g, kb;
+    if (!bwd_block_map(p.G8, p.G, p.sched, p.nk_tiles, false, g, kb)) return;   // key block 0 is the heaviest
+
+    const int L = p.L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bb = g / p.H, hh = g - bb * p.H;
+    const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
+    const T* __restrict__ gg = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh;
+
+    const int key0 = kb * BKW + wave * 32;        // first key of this wave
+    const int key = key0 + r;                     // this lane's key (both halves hold the same key)
+    const bool wave_active = key0 < L;
+    const int kr = key < L ? key : L - 1;
+
+    // B operands: K^T and V^T fragments of this lane's key
+    vec8 kf[KS], vf[KS];
+    {
+        const T* kp = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh + (int64_t)kr * p.k_sl + 8 * h;
+        const T* vp = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh + (int64_t)kr * p.v_sl + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *(const vec8*)(kp + 16 * ks);
+            vf[ks] = *(const vec8*)(vp + 16 * ks);
+        }
+    }
+    const float c = p.scale_log2;
+
+    const unsigned q_slb = (unsigned)p.q_sl * 2, g_slb = (unsigned)p.do_sl * 2;
+    unsigned q_vo[PPW], g_vo[PPW];
+    int dst[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pc = wave + j * NWAVES;
+        const int row = (2 * (pc & 3) + (lane >> 5)) * 8 + ((lane >> 2) & 7);
+        const int chunk = (pc >> 2) * 4 + ((lane & 3) ^ ((row >> 2) & 3));
+        q_vo[j] = (unsigned)row * q_slb + (chunk << 4);
+        g_vo[j] = (unsigned)row * g_slb + (chunk << 4);
+        dst[j] = (pc >> 2) * 4096 + (pc & 3) * 1024;
+    }
+    const unsigned q_bytes = ((unsigned)(L - 1) * (unsigned)p.q_sl + D) * 2;
+    const unsigned g_bytes = ((unsigned)(L - 1) * (unsigned)p.do_sl + D) * 2;
+#define FA_DMA_QG(I_, BUF_)                                                                        \
+    {                                                                                              \
+        const unsigned qo_ = (unsigned)(I_) * BQ * q_slb, go_ = (unsigned)(I_) * BQ * g_slb;       \
+        const auto qr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)qg + qo_), (short)0, \
+                                                           (int)(q_bytes - qo_), 0x00020000);      \
+        const auto gr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)gg + go_), (short)0, \
+                                                           (int)(g_bytes - go_), 0x00020000);      \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                qr_, (__attribute__((address_space(3))) void*)(smem + (BUF_) * IMG_B + dst[j]), 16, q_vo[j], 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                gr_, (__attribute__((address_space(3))) void*)(smem_g + (BUF_) * IMG_B + dst[j]), 16, g_vo[j], 0, 0, 0); \
+        }                                                                                          \
+    }
+    // row constants of q tile I_: threads 0..63 fetch lse*log2e, 64..127 fetch Dsum; rows past L get
+    // lse2 = +inf (P = 0) and Dsum = 0
+    const float* __restrict__ lse_g = p.lse + (int64_t)g * L;
+    const float* __restrict__ dsum_g = p.dsum + (int64_t)g * L;
+#define FA_ROWC_LOAD(I_)                                                                           \
+    {                                                                                              \
+        const int rr_ = (I_) * BQ + (tid & 63);                                                    \
+        rc_stage = (tid < 64) ? INFINITY : 0.f;                                                    \
+        if (tid < 64 && rr_ < L) rc_stage = lse_g[rr_] * LOG2E;                                    \
+        if (tid >= 64 && tid < 128 && rr_ < L) rc_stage = dsum_g[rr_];                             \
+    }
+#define FA_ROWC_STORE(BUF_) \
+    if (tid < 128) rowc[(BUF_) * 128 + tid] = rc_stage;
+
+    int a_rd[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a_rd[ks] = img_addr(r, 2 * ks + h);
+    const int rowin8 = 4 * h + ((lane & 15) >> 2);
+    const int c4 = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+    const int trb0 = rowin8 * 64 + ((c4 ^ h) << 4) + (lane & 1) * 8;
+    const int trb1 = rowin8 * 64 + ((c4 ^ (2 + h)) << 4) + (lane & 1) * 8;
+
+    // query tiles that can see this workgroup's keys: i0 .. n_qt-1
+    const int n_qt = (L + BQ - 1) / BQ;
+    const int i0 = (kb * BKW) / BQ;
+
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
+    float rc_stage = 0.f;
+
+#define FA_DKDV_TILE(I_, BUF_)                                                                     \
+    {                                                                                              \
+        const int q0 = (I_) * BQ;                                                                  \
+        if (wave_active && q0 + BQ - 1 >= key0) {                                                  \
+            const unsigned char* qb_ = smem + (BUF_) * IMG_B;                                      \
+            const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
+            const float* rc_ = rowc + (BUF_) * 128;                                                \
+            f32x16 s0, s1, t0, t1;                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; t0[e] = 0.f; t1[e] = 0.f; } \
+            /* S = Q K^T and dP = dO V^T, key on the lane, query rows in the registers */          \
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                    \
+                s0 = E::mfma(*(const vec8*)(qb_ + a_rd[ks]), kf[ks], s0);                          \
+                s1 = E::mfma(*(const vec8*)(qb_ + 2048 + a_rd[ks]), kf[ks], s1);                   \
+                t0 = E::mfma(*(const vec8*)(gb_ + a_rd[ks]), vf[ks], t0);                          \
+                t1 = E::mfma(*(const vec8*)(gb_ + 2048 + a_rd[ks]), vf[ks], t1);                   \
+            }                                                                                      \
+            if (q0 < key0 + 31) { /* diagonal tile: query < key is masked */                       \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                   \
+                    const int qq = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;                            \
+                    if (qq < key) s0[e] = -INFINITY;                                               \
+                    if (qq + 32 < key) s1[e] = -INFINITY;                                          \
+                }                                                                                  \
+            }                                                                                      \
+            /* P = 2^(S c - lse2[q]) ; dS = P o (dP - Dsum[q]) : row constants vary along registers */ \
+            _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                     \
+                const f32x4 la = *(const f32x4*)(rc_ + 8 * gq + 4 * h);                            \
+                const f32x4 lb = *(const f32x4*)(rc_ + 32 + 8 * gq + 4 * h);                       \
+                const f32x4 da = *(const f32x4*)(rc_ + 64 + 8 * gq + 4 * h);                       \
+                const f32x4 db = *(const f32x4*)(rc_ + 96 + 8 * gq + 4 * h);                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
+                    const int e = 4 * gq + j;                                                      \
+                    s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -la[j]));                           \
+                    s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -lb[j]));                           \
+                    t0[e] = s0[e] * (t0[e] - da[j]);                                               \
+                    t1[e] = s1[e] * (t1[e] - db[j]);                                               \
+                }                                                                                  \
+            }                                                                                      \
+            vec8 pf[4], dsf[4];                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
+                pf[0][j] = (T)s0[j];  pf[1][j] = (T)s0[8 + j];  pf[2][j] = (T)s1[j];  pf[3][j] = (T)s1[8 + j]; \
+                dsf[0][j] = (T)t0[j]; dsf[1][j] = (T)t0[8 + j]; dsf[2][j] = (T)t1[j]; dsf[3][j] = (T)t1[8 + j]; \
+            }                                                                                      \
+            /* dV^T += dO^T P   and   dK^T += Q^T dS */                                            \
+            _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                    \
+                _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                 \
+                    const unsigned char* gp_ = gb_ + dt * 4096 + kk * 1024;                        \
+                    const unsigned char* qp_ = qb_ + dt * 4096 + kk * 1024;                        \
+                    const i16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                     \
+                        (i16x4 __attribute__((address_space(3)))*)(gp_ + trb0));                   \
+                    const i16x4 ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                     \
+                        (i16x4 __attribute__((address_space(3)))*)(gp_ + 512 + trb1));             \
+                    const i16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                     \
+                        (i16x4 __attribute__((address_space(3)))*)(qp_ + trb0));                   \
+                    const i16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                     \
+                        (i16x4 __attribute__((address_space(3)))*)(qp_ + 512 + trb1));             \
+                    const i16x8 g8 = __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7);    \
+                    const i16x8 q8 = __builtin_shufflevector(qlo, qhi, 0, 1, 2, 3, 4, 5, 6, 7);    \
+                    dv[dt] = E::mfma(__builtin_bit_cast(vec8, g8), pf[kk], dv[dt]);                \
+                    dk[dt] = E::mfma(__builtin_bit_cast(vec8, q8), dsf[kk], dk[dt]);               \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+    if (i0 < n_qt) {
+        FA_DMA_QG(i0, 0)
+        FA_ROWC_LOAD(i0)
+        FA_ROWC_STORE(0)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));   // row operands landed
+
+    for (int i = i0; i < n_qt; i += 2) {
+        if (i + 1 < n_qt) {
+            FA_DMA_QG(i + 1, 1)
+            FA_ROWC_LOAD(i + 1)
+        }
+        FA_DKDV_TILE(i, 0)
+        if (i + 1 < n_qt) FA_ROWC_STORE(1)
+        __syncthreads();
+        if (i + 1 < n_qt) {
+            if (i + 2 < n_qt) {
+                FA_DMA_QG(i + 2, 0)
+                FA_ROWC_LOAD(i + 2)
+            }
+            FA_DKDV_TILE(i + 1, 1)
+            if (i + 2 < n_qt) FA_ROWC_STORE(0)
+            __syncthreads();
+        }
+    }
+#undef FA_DMA_QG
+#undef FA_ROWC_LOAD
+#undef FA_ROWC_STORE
+#undef FA_DKDV_TILE
+
+    if (!wave_active || key >= L) return;
+    T* __restrict__ dkg = (T*)p.dk + (int64_t)bb * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)key * p.dk_sl;
+    T* __restrict__ dvg = (T*)p.dv + (int64_t)bb * p.dv_sb + (int64_t)hh * p.dv_sh + (int64_t)key * p.dv_sl;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            vec4 wk, wv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wk[j] = (T)(dk[dt][4 * rg + j] * p.scale);
+                wv[j] = (T)dv[dt][4 * rg + j];
+            }
+            *(vec4*)(dkg + 32 * dt + 8 * rg + 4 * h) = wk;
+            *(vec4*)(dvg + 32 * dt + 8 * rg + 4 * h) = wv;
+        }
+    }
+}
+
+template <typename T, int D, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dkdv_kernel(const BwdParams p) {
+    fa_bwd_dkdv_body<T, D, NWAVES>(p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launcher: Dsum, then dQ, then dK/dV on the same stream (4-wave workgroups)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+static hipError_t launch_bwd_t(const BwdParams& p, hipStream_t stream) {
+    constexpr int RPB = 256 / (D / 8);
+    const int64_t rows = (int64_t)p.G * p.L;
+    hipLaunchKernelGGL((fa_bwd_dsum_kernel<T, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nk_tiles)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream) {
+    if (dtype == 1) return p.D == 64 ? launch_bwd_t<__bf16, 64>(p, stream) : launch_bwd_t<__bf16, 128>(p, stream);
+    return p.D == 64 ? launch_bwd_t<_Float16, 64>(p, stream) : launch_bwd_t<_Float16, 128>(p, stream);
+}
+
+}  // namespace fa

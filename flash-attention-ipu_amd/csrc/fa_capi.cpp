@@ -194,6 +194,56 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     return FA_OK;
 }
 
+int fa_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+           void* dq, void* dk, void* dv, float* dsum_workspace,
+           int64_t G, int64_t L, int64_t D, int64_t heads, const int64_t strides[8][3],
+           int32_t dtype, float softmax_scale, int32_t causal, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !dsum_workspace || !strides)
+        return fail(FA_ERR_NULL_POINTER, "fa_bwd: every pointer argument must be non-null");
+    if (!causal) return fail(FA_ERR_NOT_CAUSAL, "only causal attention is supported (reference: sdpa.py:29-32)");
+    if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1");
+    if (heads < 1 || G % heads != 0) return fail(FA_ERR_BAD_SHAPE, "G=%lld must be a positive multiple of heads=%lld", (long long)G, (long long)heads);
+    if (!(dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16)) return fail(FA_ERR_BAD_DTYPE, "fa_bwd supports f16 and bf16 (got dtype %d)", dtype);
+    if (!(D == 64 || D == 128)) return fail(FA_ERR_BAD_SHAPE, "fa_bwd supports head_dim 64 and 128 (got %lld)", (long long)D);
+    if (L > (1ll << 30) || G > (1ll << 30)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30");
+    const void* const ptrs[8] = {q, k, v, out, dout, dq, dk, dv};
+    for (int i = 0; i < 8; ++i) {
+        if (reinterpret_cast<uintptr_t>(ptrs[i]) & 15) return fail(FA_ERR_MISALIGNED, "fa_bwd: tensor %d is not 16-byte aligned", i);
+        for (int j = 0; j < 3; ++j) {
+            if (strides[i][j] < 0) return fail(FA_ERR_BAD_STRIDE, "negative strides are not supported");
+            if (strides[i][j] % 8) return fail(FA_ERR_MISALIGNED, "fa_bwd: strides must be multiples of 8 elements");
+        }
+        if (L * strides[i][2] >= (1ll << 31)) return fail(FA_ERR_TOO_LARGE, "fa_bwd: L * row stride must be < 2^31 elements");
+    }
+    fa::BwdParams p;
+    p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse = lse; p.dsum = dsum_workspace;
+    p.dq = dq; p.dk = dk; p.dv = dv;
+    p.q_sb = strides[0][0]; p.q_sh = strides[0][1]; p.q_sl = strides[0][2];
+    p.k_sb = strides[1][0]; p.k_sh = strides[1][1]; p.k_sl = strides[1][2];
+    p.v_sb = strides[2][0]; p.v_sh = strides[2][1]; p.v_sl = strides[2][2];
+    p.o_sb = strides[3][0]; p.o_sh = strides[3][1]; p.o_sl = strides[3][2];
+    p.do_sb = strides[4][0]; p.do_sh = strides[4][1]; p.do_sl = strides[4][2];
+    p.dq_sb = strides[5][0]; p.dq_sh = strides[5][1]; p.dq_sl = strides[5][2];
+    p.dk_sb = strides[6][0]; p.dk_sh = strides[6][1]; p.dk_sl = strides[6][2];
+    p.dv_sb = strides[7][0]; p.dv_sh = strides[7][1]; p.dv_sl = strides[7][2];
+    p.G = (int32_t)G; p.G8 = (int32_t)((G + 7) / 8 * 8); p.H = (int32_t)heads; p.L = (int32_t)L; p.D = (int32_t)D;
+    p.nq_tiles = (int32_t)((L + 127) / 128);
+    p.nk_tiles = (int32_t)((L + 127) / 128);
+    {
+        int64_t bunch = (8ll << 20) / (2 * L * D * 2);
+        const int64_t ng = p.G8 / 8;
+        if (bunch < 1) bunch = 1;
+        if (bunch > ng) bunch = ng;
+        p.sched = (int32_t)bunch;
+    }
+    if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
+    p.scale = softmax_scale;
+    p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    hipError_t e = fa::launch_bwd(p, dtype, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
 int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,
                       int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, void* stream) {
     if (!qkv || !out) return fail(FA_ERR_NULL_POINTER, "qkv and out must be non-null");

@@ -29,6 +29,22 @@ struct FwdParams {
     float scale_log2;      // scale * log2(e)
 };
 
+// backward (fa_bwd_kernels.hip)
+struct BwdParams {
+    const void* q; const void* k; const void* v; const void* o; const void* dout;
+    const float* lse;      // [G, L] from the forward
+    float* dsum;           // [G, L] workspace: rowsum(dO o O)
+    void* dq; void* dk; void* dv;
+    int64_t q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl, do_sb, do_sh, do_sl;
+    int64_t dq_sb, dq_sh, dq_sl, dk_sb, dk_sh, dk_sl, dv_sb, dv_sh, dv_sl;
+    int32_t G, G8, H, L, D;
+    int32_t nq_tiles;      // 128-row query blocks per group
+    int32_t nk_tiles;      // 128-key blocks per group
+    int32_t sched;         // groups per XCD bunch
+    float scale, scale_log2;
+};
+hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream);
+
 hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream);

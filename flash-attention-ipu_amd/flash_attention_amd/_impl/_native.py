@@ -81,6 +81,8 @@ def _declare(lib):
     lib.fa_fwd.restype = ctypes.c_int
     lib.fa_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, p64, p64, p64, p64,
                            i32, i32, i32, ctypes.c_float, i32, vp]
+    lib.fa_bwd.restype = ctypes.c_int
+    lib.fa_bwd.argtypes = [vp] * 10 + [i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32, vp]
     lib.fa_fwd_qkv_packed.restype = ctypes.c_int
     lib.fa_fwd_qkv_packed.argtypes = [vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
 
@@ -129,3 +131,32 @@ def fwd_strided(q, k, v, out, lse, G, L, D, heads, qs, ks, vs, os_, num_chunks_q
                         num_chunks_q, num_chunks_kv, FA_DTYPE[q.dtype], float(scale), 1, stream)
     if rc != 0:
         _raise(rc)
+
+
+def group_strides(t: torch.Tensor, heads: int):
+    """(outer, inner, row) element strides of a [G, L, D] (heads == 1) or [B, H, L, D] tensor."""
+    if t.ndim == 3:
+        return (t.stride(0), 0, t.stride(1))
+    return (t.stride(0), t.stride(1), t.stride(2))
+
+
+def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale):
+    """Backward through the C ABI (fa_bwd).  Tensors are [G,L,D] or [B,H,L,D] views with unit inner stride."""
+    lib = load_native_library()
+    tensors = (q, k, v, out, dout, dq, dk, dv)
+    arr = ((ctypes.c_int64 * 3) * 8)()
+    for i, t in enumerate(tensors):
+        for j, sv in enumerate(group_strides(t, heads)):
+            arr[i][j] = sv
+    dsum = torch.empty((G, L), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.fa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                        dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(), G, L, D, heads, arr,
+                        FA_DTYPE[q.dtype], float(scale), 1, stream)
+    if rc != 0:
+        _raise(rc)
+
+
+def bwd_supported(dtype, D) -> bool:
+    return dtype in (torch.float16, torch.bfloat16) and D in (64, 128)

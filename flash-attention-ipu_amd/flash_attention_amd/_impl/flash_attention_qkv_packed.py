@@ -38,6 +38,8 @@ def flash_attention_qkv_packed(qkv: torch.Tensor, num_chunks_q: int, num_chunks_
         )
 
     if qkv.is_cuda:
+        if qkv.requires_grad and torch.is_grad_enabled():
+            return _PackedAttention.apply(qkv, int(num_chunks_q), int(num_chunks_kv))
         return _forward_gpu(qkv, num_chunks_q, num_chunks_kv)[0]
 
     # CPU tensors: the op's CPU branch (fa.py:47-53) - dense attention with an additive -10000 mask.
@@ -55,6 +57,33 @@ def flash_attention_qkv_packed_with_lse(qkv: torch.Tensor, num_chunks_q: int = 1
     if qkv.ndim != 4 or qkv.shape[0] != 3:
         raise ValueError("flash_attention_qkv_packed expects qkv of shape (3, N, L, D)")
     return _forward_gpu(qkv, num_chunks_q, num_chunks_kv, want_lse=True)
+
+
+class _PackedAttention(torch.autograd.Function):
+    """Autograd node of the packed op on GPU tensors: forward keeps (qkv, out, logsumexp), backward is
+    the HIP backward (fa_bwd), the counterpart of FlashAttentionQKVPackedGradOp (FA.cpp:522-558, :348-512).
+    The reference recomputes the forward inside its grad op; here the forward's stash is reused."""
+
+    @staticmethod
+    def forward(ctx, qkv, num_chunks_q, num_chunks_kv):
+        qkv = qkv.contiguous()
+        out, lse = _forward_gpu(qkv, num_chunks_q, num_chunks_kv, want_lse=True)
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        _, G, L, D = qkv.shape
+        if not _native.bwd_supported(qkv.dtype, D):
+            raise NotImplementedError(
+                "flash_attention_qkv_packed backward on GPU supports float16/bfloat16 with head_dim 64 or 128 "
+                f"(got {qkv.dtype}, head_dim {D})")
+        dqkv = torch.empty_like(qkv)
+        if dqkv.numel() > 0:
+            _native.bwd(qkv[0], qkv[1], qkv[2], out, dout.contiguous(), lse, dqkv[0], dqkv[1], dqkv[2],
+                        G, L, D, 1, 1.0)
+        return dqkv, None, None
 
 
 def _forward_gpu(qkv, num_chunks_q, num_chunks_kv, want_lse=False):

@@ -43,6 +43,40 @@ def _group_view(x: torch.Tensor):
     return flat, 1, (flat.stride(0), 0, flat.stride(1))
 
 
+class _SdpaAttention(torch.autograd.Function):
+    """Training path of the override: forward with the logsumexp stash, backward through fa_bwd.
+    Operands are made [G, L, D]-contiguous here (the no-copy strided path is the inference one)."""
+
+    @staticmethod
+    def forward(ctx, query, key, value, softmax_scale, num_chunks_q, num_chunks_kv):
+        L, D = query.shape[-2:]
+        q, k, v = (t.reshape(-1, L, D).contiguous() for t in (query, key, value))
+        G = q.shape[0]
+        out = torch.empty_like(q)
+        lse = torch.empty((G, L), dtype=torch.float32, device=q.device)
+        st = (L * D, 0, D)
+        if out.numel() > 0:
+            _native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, num_chunks_q, num_chunks_kv, softmax_scale)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.softmax_scale = softmax_scale
+        ctx.batch_shape = query.shape[:-2]
+        return out.view(*query.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        G, L, D = q.shape
+        if not _native.bwd_supported(q.dtype, D):
+            raise NotImplementedError(
+                "flash attention backward on GPU supports float16/bfloat16 with head_dim 64 or 128 "
+                f"(got {q.dtype}, head_dim {D})")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        if dq.numel() > 0:
+            _native.bwd(q, k, v, out, dout.reshape(G, L, D).contiguous(), lse, dq, dk, dv, G, L, D, 1, ctx.softmax_scale)
+        shape = (*ctx.batch_shape, L, D)
+        return dq.view(shape), dk.view(shape), dv.view(shape), None, None, None
+
+
 @patch_function(torch.nn.functional.scaled_dot_product_attention, [torch.nn.functional])
 def _scaled_dot_product_attention_amd(
     orig_fn: Callable,
@@ -100,6 +134,9 @@ def _scaled_dot_product_attention_amd(
         else:
             out = torch.empty((*batch_shape, L, D), dtype=query.dtype, device=query.device)
             os_ = (L * D * heads, L * D, D) if heads > 1 else (L * D, 0, D)
+        needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
+        if needs_grad:
+            return _SdpaAttention.apply(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv)
         if out.numel() > 0:
             _native.fwd_strided(q, k, v, out, None, G, L, D, heads, qs, ks, vs, os_,
                                 num_chunks_q, num_chunks_kv, softmax_scale)

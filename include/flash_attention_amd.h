@@ -24,6 +24,8 @@
  *   fa_plan             <- the reference's (num_chunks_q, num_chunks_kv) -> chunk-size arithmetic
  *                          flash_attention_qkv_packed.cpp:193-195 (chunkedQueryLen / chunkedKVLen);
  *                          reports the hardware tile this library maps the request to.
+ *   fa_bwd              <- flashAttentionQKVPackedGrad + FlashAttentionQKVPackedGradOp/Opx
+ *                          flash_attention_qkv_packed.cpp:348-512, :522-558, :643-673 (next-row scope)
  *   fa_abi_version / fa_last_error / fa_error_string
  *                       <- (no reference counterpart: the reference's .so ABI is static-init
  *                          registration only, flash_attention_ipu/__init__.py:4-23; its errors are C++
@@ -107,6 +109,23 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
            const int64_t o_strides[3],
            int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,
            float softmax_scale, int32_t causal, void* stream);
+
+/*
+ * Backward of fa_fwd (replaces flashAttentionQKVPackedGrad, flash_attention_qkv_packed.cpp:348-512, and
+ * FlashAttentionQKVPackedGradOpx::grow, :643-658).  Unlike the reference it does not recompute the
+ * forward: it takes the forward's `out` and `lse`.
+ *   q,k,v,out,dout : inputs; dq,dk,dv : outputs; all addressed like fa_fwd's tensors with
+ *                    strides[i] = {outer group stride, inner group stride, row stride} (elements),
+ *                    i = 0..7 for q, k, v, out, dout, dq, dk, dv
+ *   lse            : float32 [G, L] contiguous, as written by fa_fwd (log-sum-exp of the scaled logits)
+ *   dsum_workspace : float32 [G, L] contiguous scratch (rowsum(dout * out)), caller-owned
+ * Supported: dtype f16/bf16, D in {64, 128}, 16-byte aligned rows (FA_ERR_BAD_SHAPE / _MISALIGNED otherwise).
+ * Deterministic: no gradient is accumulated across workgroups.
+ */
+int fa_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+           void* dq, void* dk, void* dv, float* dsum_workspace,
+           int64_t G, int64_t L, int64_t D, int64_t heads, const int64_t strides[8][3],
+           int32_t dtype, float softmax_scale, int32_t causal, void* stream);
 
 /* Forward on a contiguous packed qkv [3,G,L,D] -> out [G,L,D] (scale 1, causal). */
 int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,

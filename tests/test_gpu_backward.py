@@ -1,0 +1,109 @@
+"""GPU tests of the backward kernels (flashAttentionQKVPackedGrad, FA.cpp:348-512) through
+autograd + the C ABI, against autograd through the fp64 oracle on the same 16-bit-rounded inputs.
+
+The reference's own backward bounds are loose: max|delta| <= 1e-4 fp32, <= 1.0 fp16 at G=8,L=2048,D=128
+(t_cpp:271-295) and atol/rtol 1e-2 on grads in the Python tests (t_fa.py:88-93, t_sdpa.py:96-113).
+Gradients are sums of many signed 16-bit-rounded products, so their error scales with the tensor's
+magnitude rather than with each element: the check is |delta| <= tol*max|ref| + 2e-2*|ref| with
+tol = 4e-3 (fp16) / 1.5e-2 (bf16: 3 fewer mantissa bits)."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SEED = 1123581321
+
+
+def _oracle_grads(qkv16, dout16, scale):
+    from oracle.dense_attention import MASK_VALUE
+
+    x = qkv16.double().requires_grad_(True)
+    q, k, v = x
+    L = q.shape[1]
+    mask = torch.triu(torch.full((L, L), MASK_VALUE, dtype=torch.float64), 1)
+    p = torch.softmax((q @ k.transpose(1, 2)) * scale + mask, dim=-1)
+    out = p @ v
+    out.backward(dout16.double())
+    return out.detach(), x.grad.detach()
+
+
+TOL = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2}
+
+
+def _close(got, ref, what):
+    tol = TOL[got.dtype]
+    got = got.detach().cpu().double()
+    err = (got - ref).abs()
+    floor = tol * max(1e-3, ref.abs().max().item())
+    bad = err > floor + 2e-2 * ref.abs()
+    assert torch.isfinite(got).all(), what
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max|d|={err.max().item():.3e}, ref max {ref.abs().max().item():.2f}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("G,L,D", [(2, 64, 64), (1, 128, 64), (3, 200, 64), (2, 257, 64), (2, 512, 128), (1, 1000, 128), (2, 1024, 64)])
+def test_packed_backward_vs_oracle(dtype, G, L, D):
+    import flash_attention_amd as fa
+    from oracle import frozen_randn
+
+    qkv = (frozen_randn(SEED + L + D, (3, G, L, D)) * 0.5).to(dtype)   # logits std ~ sqrt(D)/4: softmax not one-hot
+    dout = frozen_randn(SEED + 1, (G, L, D)).to(dtype)
+    ref_out, ref_grad = _oracle_grads(qkv, dout, 1.0)
+    x = qkv.cuda().requires_grad_(True)
+    out = fa.flash_attention_qkv_packed(x, 1, 1)
+    out.backward(dout.cuda())
+    _close(out, ref_out, "out")
+    for i, name in enumerate("qkv"):
+        _close(x.grad[i], ref_grad[i], f"d{name} {dtype} {G}x{L}x{D}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_sdpa_backward_vs_stock(dtype):
+    """t_sdpa.py:96-113: dq, dk, dv of the patched SDPA vs stock SDPA math (fp64 here), batch shape (2,3)."""
+    import torch.nn.functional as F
+
+    import flash_attention_amd.auto  # noqa: F401
+    from oracle import frozen_randn
+
+    L, D = 256, 64
+    q, k, v = frozen_randn(SEED + 5, (3, 2, 3, L, D)).to(dtype)
+    dout = frozen_randn(SEED + 6, (2, 3, L, D)).to(dtype)
+    ref_out, ref_grad = _oracle_grads(torch.stack([q, k, v]).reshape(3, 6, L, D), dout.reshape(6, L, D), D ** -0.5)
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = F.scaled_dot_product_attention(qc, kc, vc, is_causal=True)
+    out.backward(dout.cuda())
+    _close(out.reshape(6, L, D), ref_out, "sdpa out")
+    for t, r, name in zip((qc, kc, vc), ref_grad, "qkv"):
+        _close(t.grad.reshape(6, L, D), r, f"sdpa d{name}")
+
+
+def test_backward_is_deterministic_and_group_independent():
+    import flash_attention_amd as fa
+
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    qkv = (torch.randn(3, 16, 2048, 64, device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    dout = torch.randn(16, 2048, 64, device="cuda", generator=gen).to(torch.bfloat16)
+
+    def grads(x):
+        x = x.clone().requires_grad_(True)
+        fa.flash_attention_qkv_packed(x, 1, 1).backward(dout)
+        return x.grad
+
+    g1, g2 = grads(qkv), grads(qkv)
+    assert torch.equal(g1, g2)                                  # no atomics: bitwise reproducible
+    perm = torch.randperm(16, device="cuda", generator=gen)
+    x = qkv[:, perm].clone().requires_grad_(True)
+    fa.flash_attention_qkv_packed(x, 1, 1).backward(dout[perm])
+    assert torch.equal(x.grad, g1[:, perm])                     # groups never interact
+    assert torch.isfinite(g1).all()
+    # dV of the last key only sees the last query row: dV[L-1] = P[L-1,L-1] * dO[L-1]
+    assert torch.all(g1[2, :, -1].abs() <= dout[:, -1].abs().float() * 1.01 + 1e-3)
+
+
+def test_backward_unsupported_shapes_fail_loudly():
+    import flash_attention_amd as fa
+
+    x = torch.randn(3, 2, 32, 32, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    out = fa.flash_attention_qkv_packed(x, 1, 1)
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
