@@ -1,8 +1,9 @@
 /*
- * flash_attention_amd.h - C ABI of libflash_attention.so (MI355X / gfx950 FlashAttention forward).
+ * flash_attention_amd.h - C ABI of libflash_attention.so (MI355X / gfx950 FlashAttention).
  *
  * This is the drop-in boundary for the ONE hot path of graphcore-research/flash-attention-ipu:
- * the forward of `flash_attention_qkv_packed` and the causal SDPA override.  Every entry point is
+ * the forward of `flash_attention_qkv_packed` and the causal SDPA override (plus, as the first
+ * widening step, its backward).  Every entry point is
  * `extern "C"`, takes plain pointers and sizes (device pointers unless stated), owns no memory,
  * never throws and never synchronises the host: kernels are enqueued on the caller's HIP stream.
  *
