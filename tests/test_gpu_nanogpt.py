@@ -93,3 +93,38 @@ def test_gpt2_small_forward_through_override(dtype):
     err = (logits.float() - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert math.isfinite(err) and err <= 3e-2 * max(1.0, scale), (err, scale)
+
+
+def test_gpt_training_step_gradients_through_override():
+    """SURVEY 8f-3 (demo/train.py:226 counterpart, reduced): one fwd+bwd step of a 4-layer GPT-2-width model
+    with the override (HIP forward + HIP backward) vs the same step with the override undone."""
+    import flash_attention_amd.auto  # noqa: F401
+
+    patched = F.scaled_dot_product_attention
+    torch.manual_seed(1)
+    model = TinyGPT(vocab=8192, block=512, n_layer=4).cuda()
+    for p in model.parameters():
+        if p.dim() > 1:
+            nn.init.normal_(p, std=0.02)
+    idx = torch.randint(0, 8192, (4, 512), device="cuda")
+    tgt = torch.randint(0, 8192, (4, 512), device="cuda")
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = model(idx)
+        loss = F.cross_entropy(logits.float().view(-1, 8192), tgt.view(-1))
+        loss.backward()
+        return loss.item(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+
+    loss_a, grads_a = step()
+    F.scaled_dot_product_attention = patched.__wrapped__
+    try:
+        loss_b, grads_b = step()
+    finally:
+        F.scaled_dot_product_attention = patched
+    assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_b), (loss_a, loss_b)
+    for n in grads_a:
+        ga, gb = grads_a[n], grads_b[n]
+        denom = gb.norm().item() + 1e-12
+        assert (ga - gb).norm().item() / denom <= 3e-2, (n, (ga - gb).norm().item() / denom)
