@@ -283,3 +283,52 @@ def test_error_paths_through_c_abi():
     lib = native.load_native_library()
     rc = lib.fa_fwd_qkv_packed(None, None, None, 1, 8, 64, 1, 1, 1, None)
     assert rc == -1 and b"non-null" in lib.fa_last_error()
+
+
+def test_stream_and_graph_capture():
+    """The C ABI enqueues on the caller's stream and neither allocates nor synchronises: the forward can be
+    issued on a side stream and captured into a HIP graph (replayed with new input contents)."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    G, L, D = 4, 512, 64
+    x1 = frozen_randn(SEED + 21, (3, G, L, D)).to(torch.bfloat16)
+    x2 = frozen_randn(SEED + 22, (3, G, L, D)).to(torch.bfloat16)
+    qkv = x1.cuda()
+    out = torch.empty(G, L, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        native.fwd_packed(qkv, out, lse, 1, 1)          # warm-up on the side stream
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            native.fwd_packed(qkv, out, lse, 1, 1)
+    torch.cuda.current_stream().wait_stream(side)
+    for x in (x1, x2):
+        qkv.copy_(x.cuda())
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        ref, ref_lse = _oracle(x)
+        _check(out, ref, torch.bfloat16, "graph replay")
+        torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+
+
+def test_noncontiguous_and_offset_inputs():
+    """Packed op on a non-contiguous qkv view (made contiguous by the wrapper) and fa_fwd on views that
+    start at a non-zero, 16-byte aligned offset inside a larger buffer."""
+    fa, native, _ = _mods()
+    from oracle import frozen_randn
+
+    G, L, D = 3, 200, 64
+    big = frozen_randn(SEED + 31, (3, G, L, 2 * D)).to(torch.float16)
+    view = big[..., D:]                                   # stride 2D along rows: not contiguous
+    ref, _ = _oracle(view.contiguous())
+    _check(fa.flash_attention_qkv_packed(view.cuda(), 1, 1), ref, torch.float16, "non-contiguous packed")
+    bg = big.cuda()
+    q, k, v = (bg[i][..., D:] for i in range(3))          # row stride 2D, base offset D elements (128 B)
+    out = torch.empty(G, L, D, device="cuda", dtype=torch.float16)
+    st = (L * 2 * D, 0, 2 * D)
+    native.fwd_strided(q, k, v, out, None, G, L, D, 1, st, st, st, (L * D, 0, D), 1, 1, 1.0)
+    _check(out, ref, torch.float16, "strided offset views")
