@@ -152,17 +152,15 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 #define FA_DMA_KV(T_, BUF_)                                                                        \
     {                                                                                              \
         const unsigned ko_ = (unsigned)(T_) * BK * k_slb, vo_ = (unsigned)(T_) * BK * v_slb;       \
-        const auto kr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)kg + ko_), (short)0, \
-                                                           (int)(k_bytes - ko_), 0x00020000);      \
-        const auto vr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)vg + vo_), (short)0, \
-                                                           (int)(v_bytes - vo_), 0x00020000);      \
+        const i32x4 kr_ = make_raw_rsrc((const char*)kg + ko_, k_bytes - ko_);                     \
+        const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-                kr_, (__attribute__((address_space(3))) void*)(smem + (BUF_) * IMG_B + dst[j]), 16, k_vo[j], 0, 0, 0); \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-                vr_, (__attribute__((address_space(3))) void*)(smem_v + (BUF_) * IMG_B + dst[j]), 16, v_vo[j], 0, 0, 0); \
+            lds_dma_b128(kr_, smem_lds + (BUF_) * IMG_B + dst[j], k_vo[j]);                        \
+            lds_dma_b128(vr_, smem_lds + (2 + (BUF_)) * IMG_B + dst[j], v_vo[j]);                  \
         }                                                                                          \
     }
+#define FA_TILE_BARRIER() { lds_dma_wait_all(); __syncthreads(); }
+    const unsigned smem_lds = lds_offset(smem);
 
     // LDS read addresses: row reads (A operand rows = 32*blk + r) and transposed reads
     int a_rd[KS];
@@ -231,21 +229,22 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     }
 
     FA_DMA_KV(0, 0)
-    __syncthreads();
+    FA_TILE_BARRIER()
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));   // row operands landed
 
     for (int t = 0; t < n_tiles; t += 2) {
         if (t + 1 < n_tiles) FA_DMA_KV(t + 1, 1)
         FA_DQ_TILE(t, 0)
-        __syncthreads();
+        FA_TILE_BARRIER()
         if (t + 1 < n_tiles) {
             if (t + 2 < n_tiles) FA_DMA_KV(t + 2, 0)
             FA_DQ_TILE(t + 1, 1)
-            __syncthreads();
+            FA_TILE_BARRIER()
         }
     }
 #undef FA_DMA_KV
+#undef FA_TILE_BARRIER
 #undef FA_DQ_TILE
 
     if (!wave_active || qrow >= L) return;
@@ -330,17 +329,14 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #define FA_DMA_QG(I_, BUF_)                                                                        \
     {                                                                                              \
         const unsigned qo_ = (unsigned)(I_) * BQ * q_slb, go_ = (unsigned)(I_) * BQ * g_slb;       \
-        const auto qr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)qg + qo_), (short)0, \
-                                                           (int)(q_bytes - qo_), 0x00020000);      \
-        const auto gr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)gg + go_), (short)0, \
-                                                           (int)(g_bytes - go_), 0x00020000);      \
+        const i32x4 qr_ = make_raw_rsrc((const char*)qg + qo_, q_bytes - qo_);                     \
+        const i32x4 gr_ = make_raw_rsrc((const char*)gg + go_, g_bytes - go_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-                qr_, (__attribute__((address_space(3))) void*)(smem + (BUF_) * IMG_B + dst[j]), 16, q_vo[j], 0, 0, 0); \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-                gr_, (__attribute__((address_space(3))) void*)(smem_g + (BUF_) * IMG_B + dst[j]), 16, g_vo[j], 0, 0, 0); \
+            lds_dma_b128(qr_, smem_lds + (BUF_) * IMG_B + dst[j], q_vo[j]);                        \
+            lds_dma_b128(gr_, smem_lds + (2 + (BUF_)) * IMG_B + dst[j], g_vo[j]);                  \
         }                                                                                          \
     }
+    const unsigned smem_lds = lds_offset(smem);
     // row constants of q tile I_: threads 0..63 fetch lse*log2e, 64..127 fetch Dsum; rows past L get
     // lse2 = +inf (P = 0) and Dsum = 0
     const float* __restrict__ lse_g = p.lse + (int64_t)g * L;
@@ -443,6 +439,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         FA_ROWC_LOAD(i0)
         FA_ROWC_STORE(0)
     }
+    lds_dma_wait_all();
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));   // row operands landed
@@ -454,6 +451,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         }
         FA_DKDV_TILE(i, 0)
         if (i + 1 < n_qt) FA_ROWC_STORE(1)
+        lds_dma_wait_all();
         __syncthreads();
         if (i + 1 < n_qt) {
             if (i + 2 < n_qt) {
@@ -462,6 +460,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             }
             FA_DKDV_TILE(i + 1, 1)
             if (i + 2 < n_qt) FA_ROWC_STORE(0)
+            lds_dma_wait_all();
             __syncthreads();
         }
     }

@@ -64,6 +64,45 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 // MFMA tile kernel.  T in {__bf16, _Float16}, D in {64, 128}, NWAVES in {1, 2, 4, 8}.
 // ---------------------------------------------------------------------------------------------
 
+// ---- LDS-DMA through inline asm -------------------------------------------------------------------
+// `buffer_load_dwordx4 ... lds`: 16 bytes per lane from (descriptor base + voffset) straight into
+// LDS[lds_base + 16*lane]; no VGPR destination.  Issued by asm on purpose: hipcc tracks an LDS-DMA
+// issued through its builtin as a pending LDS write and drains `vmcnt(0)` in front of the first
+// ds_read_b64_tr_b16 that follows - i.e. it waits for the NEXT tile's prefetch in the middle of the
+// current tile.  An asm statement is invisible to that bookkeeping, so the wait is placed by hand
+// (lds_dma_wait_all() right before the workgroup barrier that publishes the tile).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor over [base, base + num_bytes): stride 0, reads past the end return zeros
+__device__ __forceinline__ i32x4 make_raw_rsrc(const void* base, unsigned num_bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+    r[2] = (int)num_bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+
+// lds_base and rsrc must be wave-uniform (they travel in SGPRs; M0 carries the LDS base and is
+// written and restored inside the same statement, as the compiler reserves it)
+__device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned lds_base, unsigned voffset) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_base), "v"(voffset), "s"(rsrc)
+        : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
 // Lazy rescale threshold in log2 units: the running max m is only raised (and O, l rescaled) when a
 // tile's row max exceeds it by more than this, so P = 2^((s-m)c) stays <= 2^8 - exact in fp32
 // accumulators, harmless in bf16/f16 P (same relative rounding), and normalised away by O/l.

@@ -105,19 +105,16 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #define FA_DMA_TILE(T_, BUF_)                                                                      \
     {                                                                                              \
         const unsigned ko_ = (unsigned)(T_) * BK * k_slb, vo_ = (unsigned)(T_) * BK * v_slb;       \
-        const auto kr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)kg + ko_), (short)0, \
-                                                           (int)(k_bytes - ko_), 0x00020000);      \
-        const auto vr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)vg + vo_), (short)0, \
-                                                           (int)(v_bytes - vo_), 0x00020000);      \
+        const i32x4 kr_ = make_raw_rsrc((const char*)kg + ko_, k_bytes - ko_);                     \
+        const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-                kr_, (__attribute__((address_space(3))) void*)(smem + (BUF_) * KTILE_B + k_dst[j]), \
-                16, k_vo[j], 0, 0, 0);                                                             \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-                vr_, (__attribute__((address_space(3))) void*)(smem_v + (BUF_) * VTILE_B + v_dst[j]), \
-                16, v_vo[j], 0, 0, 0);                                                             \
+            lds_dma_b128(kr_, smem_lds + (BUF_) * KTILE_B + k_dst[j], k_vo[j]);                    \
+            lds_dma_b128(vr_, smem_lds + 2 * KTILE_B + (BUF_) * VTILE_B + v_dst[j], v_vo[j]);      \
         }                                                                                          \
     }
+    // publish a DMA'd tile: drain this wave's DMA, then the workgroup barrier
+#define FA_TILE_BARRIER() { lds_dma_wait_all(); __syncthreads(); }
+    const unsigned smem_lds = lds_offset(smem);
 
     int k_rd[KS];
     {
@@ -223,21 +220,22 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     }
 
     FA_DMA_TILE(0, 0)
-    __syncthreads();   // (drains the DMA: an LDS-DMA is a pending LDS write on the vector-memory counter)
+    FA_TILE_BARRIER()
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q landed (see fa_fwd_tile_kernel)
 
     for (int t = 0; t < n_tiles; t += 2) {
         if (t + 1 < n_tiles) FA_DMA_TILE(t + 1, 1)
         FA_COMPUTE(t, 0)
-        __syncthreads();
+        FA_TILE_BARRIER()
         if (t + 1 < n_tiles) {
             if (t + 2 < n_tiles) FA_DMA_TILE(t + 2, 0)
             FA_COMPUTE(t + 1, 1)
-            __syncthreads();
+            FA_TILE_BARRIER()
         }
     }
 #undef FA_DMA_TILE
+#undef FA_TILE_BARRIER
 #undef FA_COMPUTE
 #undef FA_QK
 #undef FA_MAX_RESCALE
