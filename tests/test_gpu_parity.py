@@ -332,3 +332,18 @@ def test_noncontiguous_and_offset_inputs():
     st = (L * 2 * D, 0, 2 * D)
     native.fwd_strided(q, k, v, out, None, G, L, D, 1, st, st, st, (L * D, 0, D), 1, 1, 1.0)
     _check(out, ref, torch.float16, "strided offset views")
+
+
+def test_cpp_caller_of_the_c_abi(tmp_path):
+    """tests/cpp/test_capi.cpp: plain C++ (no torch) links libflash_attention.so and checks it against a dense
+    fp64 host computation - the counterpart of the reference's C++ test binary (t_cpp:34-102)."""
+    import pathlib
+    import subprocess
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    lib_dir = root / "flash-attention-ipu_amd" / "build"
+    exe = tmp_path / "test_capi"
+    subprocess.check_call(["hipcc", "-O2", f"-I{root / 'include'}", str(root / "tests" / "cpp" / "test_capi.cpp"),
+                           f"-L{lib_dir}", "-lflash_attention", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "PASSED" in res.stdout, res.stdout + res.stderr
