@@ -203,18 +203,22 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
     if (!causal) return fail(FA_ERR_NOT_CAUSAL, "only causal attention is supported (reference: sdpa.py:29-32)");
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1");
     if (heads < 1 || G % heads != 0) return fail(FA_ERR_BAD_SHAPE, "G=%lld must be a positive multiple of heads=%lld", (long long)G, (long long)heads);
-    if (!(dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16)) return fail(FA_ERR_BAD_DTYPE, "fa_bwd supports f16 and bf16 (got dtype %d)", dtype);
-    if (!(D == 64 || D == 128)) return fail(FA_ERR_BAD_SHAPE, "fa_bwd supports head_dim 64 and 128 (got %lld)", (long long)D);
+    if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     if (L > (1ll << 30) || G > (1ll << 30)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30");
     const void* const ptrs[8] = {q, k, v, out, dout, dq, dk, dv};
+    // MFMA kernels: 16-bit dtypes, head_dim 64/128, 16-byte aligned rows; everything else -> generic kernels
+    bool mfma = (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128);
     for (int i = 0; i < 8; ++i) {
-        if (reinterpret_cast<uintptr_t>(ptrs[i]) & 15) return fail(FA_ERR_MISALIGNED, "fa_bwd: tensor %d is not 16-byte aligned", i);
+        if (reinterpret_cast<uintptr_t>(ptrs[i]) % elt_size(dtype)) return fail(FA_ERR_MISALIGNED, "fa_bwd: tensor %d is not element aligned", i);
+        if (reinterpret_cast<uintptr_t>(ptrs[i]) & 15) mfma = false;
         for (int j = 0; j < 3; ++j) {
             if (strides[i][j] < 0) return fail(FA_ERR_BAD_STRIDE, "negative strides are not supported");
-            if (strides[i][j] % 8) return fail(FA_ERR_MISALIGNED, "fa_bwd: strides must be multiples of 8 elements");
+            if (strides[i][j] % 8) mfma = false;
         }
-        if (L * strides[i][2] >= (1ll << 31)) return fail(FA_ERR_TOO_LARGE, "fa_bwd: L * row stride must be < 2^31 elements");
+        if (L * strides[i][2] >= (1ll << 31)) mfma = false;
     }
+    if (!mfma && D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic backward supports D <= 1024 (got %lld)", (long long)D);
+    if (!mfma && G * L > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     fa::BwdParams p;
     p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse = lse; p.dsum = dsum_workspace;
     p.dq = dq; p.dk = dk; p.dv = dv;
@@ -239,7 +243,7 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
     if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    hipError_t e = fa::launch_bwd(p, dtype, (hipStream_t)stream);
+    hipError_t e = mfma ? fa::launch_bwd(p, dtype, (hipStream_t)stream) : fa::launch_bwd_generic(p, dtype, (hipStream_t)stream);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
 }

@@ -44,6 +44,7 @@ struct BwdParams {
     float scale, scale_log2;
 };
 hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream);
+hipError_t launch_bwd_generic(const BwdParams& p, int dtype, hipStream_t stream);
 
 hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, hipStream_t stream);

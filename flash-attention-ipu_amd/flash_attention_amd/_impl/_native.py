@@ -156,7 +156,3 @@ def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale):
                         FA_DTYPE[q.dtype], float(scale), 1, stream)
     if rc != 0:
         _raise(rc)
-
-
-def bwd_supported(dtype, D) -> bool:
-    return dtype in (torch.float16, torch.bfloat16) and D in (64, 128)

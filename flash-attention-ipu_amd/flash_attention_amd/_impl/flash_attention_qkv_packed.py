@@ -75,10 +75,6 @@ class _PackedAttention(torch.autograd.Function):
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
         _, G, L, D = qkv.shape
-        if not _native.bwd_supported(qkv.dtype, D):
-            raise NotImplementedError(
-                "flash_attention_qkv_packed backward on GPU supports float16/bfloat16 with head_dim 64 or 128 "
-                f"(got {qkv.dtype}, head_dim {D})")
         dqkv = torch.empty_like(qkv)
         if dqkv.numel() > 0:
             _native.bwd(qkv[0], qkv[1], qkv[2], out, dout.contiguous(), lse, dqkv[0], dqkv[1], dqkv[2],

@@ -66,10 +66,6 @@ class _SdpaAttention(torch.autograd.Function):
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
         G, L, D = q.shape
-        if not _native.bwd_supported(q.dtype, D):
-            raise NotImplementedError(
-                "flash attention backward on GPU supports float16/bfloat16 with head_dim 64 or 128 "
-                f"(got {q.dtype}, head_dim {D})")
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         if dq.numel() > 0:
             _native.bwd(q, k, v, out, dout.reshape(G, L, D).contiguous(), lse, dq, dk, dv, G, L, D, 1, ctx.softmax_scale)

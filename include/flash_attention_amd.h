@@ -120,7 +120,8 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
  *                    i = 0..7 for q, k, v, out, dout, dq, dk, dv
  *   lse            : float32 [G, L] contiguous, as written by fa_fwd (log-sum-exp of the scaled logits)
  *   dsum_workspace : float32 [G, L] contiguous scratch (rowsum(dout * out)), caller-owned
- * Supported: dtype f16/bf16, D in {64, 128}, 16-byte aligned rows (FA_ERR_BAD_SHAPE / _MISALIGNED otherwise).
+ * f16/bf16 with D in {64, 128} and 16-byte aligned rows run the MFMA kernels; every other case
+ * (fp32, other D <= 1024, unaligned rows) runs generic fp32-arithmetic kernels.
  * Deterministic: no gradient is accumulated across workgroups.
  */
 int fa_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,

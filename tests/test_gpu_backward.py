@@ -100,10 +100,24 @@ def test_backward_is_deterministic_and_group_independent():
     assert torch.all(g1[2, :, -1].abs() <= dout[:, -1].abs().float() * 1.01 + 1e-3)
 
 
-def test_backward_unsupported_shapes_fail_loudly():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("G,L,D", [(4, 6, 2), (2, 33, 7), (2, 70, 24), (8, 256, 128), (2, 300, 80), (1, 1200, 32)])
+def test_generic_backward(dtype, G, L, D):
+    """Shapes/dtypes only the generic backward kernels serve, incl. the reference's fp32 C++ cases
+    4x6x2 and 8x256x128 (t_cpp:273-287, bound 1e-4 there)."""
     import flash_attention_amd as fa
+    from oracle import frozen_randn
 
-    x = torch.randn(3, 2, 32, 32, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    if dtype != torch.float32 and D in (64, 128):
+        pytest.skip("served by the MFMA kernels")
+    qkv = (frozen_randn(SEED + L + D, (3, G, L, D)) * (0.5 if D > 16 else 1.0)).to(dtype)
+    dout = frozen_randn(SEED + 2, (G, L, D)).to(dtype)
+    ref_out, ref_grad = _oracle_grads(qkv, dout, 1.0)
+    x = qkv.cuda().requires_grad_(True)
     out = fa.flash_attention_qkv_packed(x, 1, 1)
-    with pytest.raises(NotImplementedError):
-        out.sum().backward()
+    out.backward(dout.cuda())
+    if dtype == torch.float32:
+        assert (x.grad.cpu().double() - ref_grad).abs().max().item() <= 1e-4 * max(1.0, ref_grad.abs().max().item())
+    else:
+        for i, name in enumerate("qkv"):
+            _close(x.grad[i], ref_grad[i], f"generic d{name} {dtype} {G}x{L}x{D}")
