@@ -4,7 +4,7 @@ behind the C ABI in include/flash_attention_amd.h."""
 
 import torch
 
-from . import _native
+from . import _native, ops
 
 
 def flash_attention_qkv_packed(qkv: torch.Tensor, num_chunks_q: int, num_chunks_kv: int) -> torch.Tensor:
@@ -38,9 +38,10 @@ def flash_attention_qkv_packed(qkv: torch.Tensor, num_chunks_q: int, num_chunks_
         )
 
     if qkv.is_cuda:
-        if qkv.requires_grad and torch.is_grad_enabled():
-            return _PackedAttention.apply(qkv, int(num_chunks_q), int(num_chunks_kv))
-        return _forward_gpu(qkv, num_chunks_q, num_chunks_kv)[0]
+        if qkv.dtype not in _native.FA_DTYPE:
+            raise TypeError(f"flash_attention_qkv_packed: unsupported dtype {qkv.dtype} on GPU")
+        # one opaque custom op (HIP forward; HIP backward through its registered autograd formula)
+        return ops.fwd_qkv_packed(qkv, int(num_chunks_q), int(num_chunks_kv))[0]
 
     # CPU tensors: the op's CPU branch (fa.py:47-53) - dense attention with an additive -10000 mask.
     q, k, v = qkv
@@ -56,43 +57,9 @@ def flash_attention_qkv_packed_with_lse(qkv: torch.Tensor, num_chunks_q: int = 1
         raise ValueError("flash_attention_qkv_packed_with_lse needs a GPU tensor")
     if qkv.ndim != 4 or qkv.shape[0] != 3:
         raise ValueError("flash_attention_qkv_packed expects qkv of shape (3, N, L, D)")
-    return _forward_gpu(qkv, num_chunks_q, num_chunks_kv, want_lse=True)
-
-
-class _PackedAttention(torch.autograd.Function):
-    """Autograd node of the packed op on GPU tensors: forward keeps (qkv, out, logsumexp), backward is
-    the HIP backward (fa_bwd), the counterpart of FlashAttentionQKVPackedGradOp (FA.cpp:522-558, :348-512).
-    The reference recomputes the forward inside its grad op; here the forward's stash is reused."""
-
-    @staticmethod
-    def forward(ctx, qkv, num_chunks_q, num_chunks_kv):
-        qkv = qkv.contiguous()
-        out, lse = _forward_gpu(qkv, num_chunks_q, num_chunks_kv, want_lse=True)
-        ctx.save_for_backward(qkv, out, lse)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        qkv, out, lse = ctx.saved_tensors
-        _, G, L, D = qkv.shape
-        dqkv = torch.empty_like(qkv)
-        if dqkv.numel() > 0:
-            _native.bwd(qkv[0], qkv[1], qkv[2], out, dout.contiguous(), lse, dqkv[0], dqkv[1], dqkv[2],
-                        G, L, D, 1, 1.0)
-        return dqkv, None, None
-
-
-def _forward_gpu(qkv, num_chunks_q, num_chunks_kv, want_lse=False):
     if qkv.dtype not in _native.FA_DTYPE:
         raise TypeError(f"flash_attention_qkv_packed: unsupported dtype {qkv.dtype} on GPU")
-    if not qkv.is_contiguous():
-        qkv = qkv.contiguous()
-    _, G, L, D = qkv.shape
-    out = torch.empty((G, L, D), dtype=qkv.dtype, device=qkv.device)
-    lse = torch.empty((G, L), dtype=torch.float32, device=qkv.device) if want_lse else None
-    if out.numel() > 0:
-        _native.fwd_packed(qkv, out, lse, int(num_chunks_q), int(num_chunks_kv))
-    return out, lse
+    return ops.fwd_qkv_packed(qkv, int(num_chunks_q), int(num_chunks_kv))
 
 
 __all__ = ["flash_attention_qkv_packed"]

@@ -1,0 +1,151 @@
+"""The HIP kernels as `torch.library` custom ops (`flash_attention_amd::*`).
+
+The reference registers its op with the framework by name/domain/version so that the tracer can carry it
+(`poptorch.custom_op(name="FlashAttentionQKVPacked", domain="ai.graphcore", ...)`, fa.py:39-46, and the
+PopART OpCreator, FA.cpp:609-625, with shape inference in Op::setup(), FA.cpp:571-577).  The PyTorch-ROCm
+counterpart is a `torch.library.custom_op` with a fake (meta) implementation for shape inference and a
+registered autograd formula: eager, autograd and `torch.compile` all see one opaque op and the ctypes call
+into the C ABI stays out of the traced graph.
+"""
+
+from typing import Tuple
+
+import torch
+from torch.library import custom_op
+
+from . import _native
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """[G, L, D] view usable by the C ABI: unit stride on D (copy only if it is not)."""
+    return t if t.stride(-1) == 1 or t.shape[-1] == 1 else t.contiguous()
+
+
+def _st3(t):
+    return (t.stride(0), 0, t.stride(1))
+
+
+# ---- packed qkv [3, G, L, D] ------------------------------------------------------------------------
+@custom_op("flash_attention_amd::fwd_qkv_packed", mutates_args=())
+def fwd_qkv_packed(qkv: torch.Tensor, num_chunks_q: int, num_chunks_kv: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    qkv = qkv.contiguous()
+    _, G, L, D = qkv.shape
+    out = torch.empty((G, L, D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((G, L), dtype=torch.float32, device=qkv.device)
+    if out.numel() > 0:
+        _native.fwd_packed(qkv, out, lse, num_chunks_q, num_chunks_kv)
+    return out, lse
+
+
+@fwd_qkv_packed.register_fake
+def _(qkv, num_chunks_q, num_chunks_kv):
+    _, G, L, D = qkv.shape
+    return qkv.new_empty((G, L, D)), qkv.new_empty((G, L), dtype=torch.float32)
+
+
+@custom_op("flash_attention_amd::bwd_qkv_packed", mutates_args=())
+def bwd_qkv_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor) -> torch.Tensor:
+    qkv = qkv.contiguous()
+    _, G, L, D = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    if dqkv.numel() > 0:
+        _native.bwd(qkv[0], qkv[1], qkv[2], out.contiguous(), dout.contiguous(), lse, dqkv[0], dqkv[1], dqkv[2],
+                    G, L, D, 1, 1.0)
+    return dqkv
+
+
+@bwd_qkv_packed.register_fake
+def _(qkv, out, dout, lse):
+    return torch.empty_like(qkv, memory_format=torch.contiguous_format)
+
+
+def _packed_setup(ctx, inputs, output):
+    qkv, _, _ = inputs
+    out, lse = output
+    ctx.save_for_backward(qkv, out, lse)
+
+
+def _packed_backward(ctx, dout, _dlse):
+    qkv, out, lse = ctx.saved_tensors
+    return bwd_qkv_packed(qkv, out, dout, lse), None, None
+
+
+fwd_qkv_packed.register_autograd(_packed_backward, setup_context=_packed_setup)
+
+
+# ---- three [G, L, D] operands with a softmax scale (training path of the SDPA override) ---------------
+@custom_op("flash_attention_amd::fwd", mutates_args=())
+def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, softmax_scale: float,
+        num_chunks_q: int, num_chunks_kv: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    q, k, v = _rows(q), _rows(k), _rows(v)
+    G, L, D = q.shape
+    out = torch.empty((G, L, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((G, L), dtype=torch.float32, device=q.device)
+    if out.numel() > 0:
+        _native.fwd_strided(q, k, v, out, lse, G, L, D, 1, _st3(q), _st3(k), _st3(v), _st3(out),
+                            num_chunks_q, num_chunks_kv, softmax_scale)
+    return out, lse
+
+
+@fwd.register_fake
+def _(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv):
+    G, L, D = q.shape
+    return q.new_empty((G, L, D)), q.new_empty((G, L), dtype=torch.float32)
+
+
+@custom_op("flash_attention_amd::bwd", mutates_args=())
+def bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor,
+        lse: torch.Tensor, softmax_scale: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    q, k, v, out, dout = (_rows(t) for t in (q, k, v, out, dout))
+    G, L, D = q.shape
+    dq, dk, dv = (torch.empty((G, L, D), dtype=q.dtype, device=q.device) for _ in range(3))
+    if dq.numel() > 0:
+        _native.bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, 1, softmax_scale)
+    return dq, dk, dv
+
+
+@bwd.register_fake
+def _(q, k, v, out, dout, lse, softmax_scale):
+    return q.new_empty(q.shape), q.new_empty(q.shape), q.new_empty(q.shape)
+
+
+def _fwd_setup(ctx, inputs, output):
+    q, k, v, softmax_scale, _, _ = inputs
+    out, lse = output
+    ctx.save_for_backward(q, k, v, out, lse)
+    ctx.softmax_scale = softmax_scale
+
+
+def _fwd_backward(ctx, dout, _dlse):
+    q, k, v, out, lse = ctx.saved_tensors
+    dq, dk, dv = bwd(q, k, v, out, dout, lse, ctx.softmax_scale)
+    return dq, dk, dv, None, None, None
+
+
+fwd.register_autograd(_fwd_backward, setup_context=_fwd_setup)
+
+
+# ---- inference on [B, H, L, D] views without any copy (strided heads, head-inner output) ---------------
+def _bhld_out_like(query: torch.Tensor) -> torch.Tensor:
+    B, H, L, D = query.shape
+    if query.stride(1) < query.stride(2):   # head-inner input ([B, L, H, D] viewed [B, H, L, D]): same layout out
+        return query.new_empty((B, L, H, D)).transpose(1, 2)
+    return query.new_empty((B, H, L, D))
+
+
+@custom_op("flash_attention_amd::fwd_bhld", mutates_args=())
+def fwd_bhld(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, softmax_scale: float,
+             num_chunks_q: int, num_chunks_kv: int) -> torch.Tensor:
+    q, k, v = _rows(q), _rows(k), _rows(v)
+    B, H, L, D = q.shape
+    out = _bhld_out_like(q)
+    if out.numel() > 0:
+        st = lambda t: (t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
+        _native.fwd_strided(q, k, v, out, None, B * H, L, D, H, st(q), st(k), st(v), st(out),
+                            num_chunks_q, num_chunks_kv, softmax_scale)
+    return out
+
+
+@fwd_bhld.register_fake
+def _(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv):
+    return _bhld_out_like(q)

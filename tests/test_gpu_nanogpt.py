@@ -128,3 +128,30 @@ def test_gpt_training_step_gradients_through_override():
         ga, gb = grads_a[n], grads_b[n]
         denom = gb.norm().item() + 1e-12
         assert (ga - gb).norm().item() / denom <= 3e-2, (n, (ga - gb).norm().item() / denom)
+
+
+def test_torch_compile_traces_through_the_custom_ops():
+    """The kernels are torch.library custom ops with fake implementations: torch.compile (fullgraph, no graph
+    break) must carry them for inference and for a training step."""
+    import flash_attention_amd as fa
+    import flash_attention_amd.auto  # noqa: F401
+
+    torch.manual_seed(2)
+    attn = CausalSelfAttention(768, 12).cuda().to(torch.bfloat16)
+    x = torch.randn(2, 512, 768, device="cuda", dtype=torch.bfloat16)
+    ref = attn(x)
+    compiled = torch.compile(attn, fullgraph=True, backend="aot_eager")
+    torch.testing.assert_close(compiled(x), ref, atol=2e-2, rtol=2e-2)
+
+    xg = x.clone().requires_grad_(True)
+    attn(xg).float().pow(2).sum().backward()
+    g_ref = xg.grad.clone()
+    xg2 = x.clone().requires_grad_(True)
+    compiled(xg2).float().pow(2).sum().backward()
+    torch.testing.assert_close(xg2.grad, g_ref, atol=5e-2, rtol=5e-2)
+
+    def packed(qkv):
+        return fa.flash_attention_qkv_packed(qkv, 4, 4) * 2.0
+
+    qkv = (torch.randn(3, 4, 256, 64, device="cuda") * 0.5).to(torch.bfloat16)
+    torch.testing.assert_close(torch.compile(packed, fullgraph=True, backend="aot_eager")(qkv), packed(qkv))

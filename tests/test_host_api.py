@@ -163,16 +163,22 @@ def test_sdpa_override_guards_and_passthrough(meta):
         assert chunk_heuristic(L, D) == (nq, nk)
 
 
-def test_group_view_never_copies_for_common_layouts():
-    from flash_attention_amd._impl.scaled_dot_product_attention import _group_view
+def test_custom_ops_shape_inference_on_meta_tensors():
+    """The fake (meta) implementations = the reference's Op::setup() shape inference (FA.cpp:571-577):
+    [3,G,L,D] -> [G,L,D]; the [B,H,L,D] inference op keeps a head-inner input layout on its output."""
+    from flash_attention_amd._impl import ops
 
-    x = torch.zeros(2, 16, 3 * 4 * 8)
-    q = x.split(32, dim=2)[1].view(2, 16, 4, 8).transpose(1, 2)   # nanoGPT-style [B,H,T,hs] view
-    t, heads, strides = _group_view(q)
-    assert t.data_ptr() == q.data_ptr() and heads == 4 and strides == (16 * 96, 8, 96)
-    c = torch.zeros(2, 3, 5, 16, 8)
-    t, heads, strides = _group_view(c)
-    assert t.data_ptr() == c.data_ptr() and heads == 1 and strides == (128, 0, 8)
+    qkv = torch.empty(3, 5, 200, 64, device="meta", dtype=torch.bfloat16)
+    out, lse = torch.ops.flash_attention_amd.fwd_qkv_packed(qkv, 1, 1)
+    assert out.shape == (5, 200, 64) and out.dtype == torch.bfloat16 and lse.shape == (5, 200) and lse.dtype == torch.float32
+    x = torch.empty(2, 16, 3 * 4 * 8, device="meta", dtype=torch.float16)
+    q = x.split(32, dim=2)[1].view(2, 16, 4, 8).transpose(1, 2)          # nanoGPT-style [B,H,T,hs] view
+    o = ops.fwd_bhld(q, q, q, 0.35, 1, 1)
+    assert o.shape == (2, 4, 16, 8) and o.transpose(1, 2).is_contiguous()
+    c = torch.empty(2, 4, 16, 8, device="meta", dtype=torch.float16)
+    assert ops.fwd_bhld(c, c, c, 0.35, 1, 1).is_contiguous()
+    dq, dk, dv = torch.ops.flash_attention_amd.bwd(c[0], c[0], c[0], c[0], c[0], torch.empty(4, 16, device="meta"), 1.0)
+    assert dq.shape == dk.shape == dv.shape == (4, 16, 8)
 
 
 def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
