@@ -74,8 +74,11 @@ def cpu_baseline(L, D, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ramp-ms", type=float, default=150.0,
+                    help="untimed clock ramp before the W warm-up steps: an idle MI355X needs ~30-100 ms of load "
+                         "to reach its sustained clock (measured: 784 TFLOP/s after 10 warm-up launches, 886 after 400)")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of O (kernel only)")
@@ -135,6 +138,15 @@ def main():
                 pending[b][1].wait()
                 pending[b] = None
 
+    t_ramp = time.perf_counter()
+    i_ramp = 0
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:   # untimed: bring the chip to its sustained clock
+        step(i_ramp)
+        i_ramp += 1
+        if i_ramp % 16 == 0:
+            torch.cuda.synchronize()
+    drain()
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     drain()
