@@ -242,10 +242,16 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #undef FA_SOFTMAX
 #undef FA_PV
 
-    if (!wave_active || qrow >= L) return;
+    // ---- epilogue: O /= l, staged through LDS so that every store instruction writes whole rows.
+    // (A lane owns 8-byte pieces of ONE row at a 16-byte pitch; stored directly, one instruction touches
+    // 32 rows x 2 pieces.)  The K buffers are free after the last barrier; each wave uses a private
+    // 32-row slab [32][D] with the 16-byte chunk index XORed by the row, so writes and reads are
+    // conflict-free and no workgroup barrier is needed.
+    if (!wave_active) return;
     const float lt = half_swap_sum(l);
     const float inv = __builtin_amdgcn_rcpf(lt);
-    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)qrow * p.o_sl;
+    unsigned char* slab = smem + wave * (32 * ROWB);
+    constexpr int CPR = D / 8;   // 16-byte chunks per row
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -253,10 +259,19 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             vec4 w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = (T)(o[dt][4 * rg + j] * inv);
-            *(vec4*)(og + 32 * dt + 8 * rg + 4 * h) = w;
+            const int ch = 4 * dt + rg;                                   // chunk holding d = 32dt + 8rg + 4h ..+3
+            *(vec4*)(slab + r * ROWB + ((ch ^ (r & (CPR - 1))) << 4) + 8 * h) = w;
         }
     }
-    if (p.lse != nullptr && h == 0) p.lse[(int64_t)g * L + qrow] = m * p.scale + __logf(lt);
+    if (p.lse != nullptr && h == 0 && qrow < L) p.lse[(int64_t)g * L + qrow] = m * p.scale + __logf(lt);
+    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
+    constexpr int RPI = 64 / CPR;   // rows per store instruction (8 at D=64, 4 at D=128)
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int rr = i * RPI + lane / CPR, ch = lane % CPR;
+        const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
+        if (q_row0 + rr < L) *(u32x4*)(og + (int64_t)(q_row0 + rr) * p.o_sl + ch * 8) = val;
+    }
 }
 
 // D=64 at 4+ waves per workgroup is built for 4 waves per SIMD (<= 128 VGPRs)
