@@ -20,12 +20,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <typename T> struct Elt;
 template <> struct Elt<__bf16> {
     using vec8 = bf16x8;
+    static constexpr bool is_f16 = false;
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
 };
 template <> struct Elt<_Float16> {
     using vec8 = f16x8;
+    static constexpr bool is_f16 = true;
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }

@@ -17,6 +17,14 @@
 
 #include "fa_device.h"
 
+// 1: no per-tile row max (bf16).  The reference max m is set exactly on a wave's first tile and then left
+// alone; a tile whose row-sum part exceeds P_LIMIT (some P outgrew the safe range) is redone with an
+// exact max.  Any reference value cancels in O/l; it only has to keep P finite.  Worth +7 % at D=64:
+// the 16-deep v_max3 chain, the half-wave swap and the rescale decision leave every tile.
+#ifndef FA_DMA_SKIPMAX
+#define FA_DMA_SKIPMAX 1
+#endif
+
 namespace fa {
 
 // (the body lives in a __device__ function: the buffer/LDS-DMA builtins do not exist for the host pass,
@@ -135,6 +143,11 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     float m = -INFINITY;
     float l = 0.f;
     const float c = p.scale_log2;
+    // bf16 only: bf16 P keeps the fp32 exponent range, so the reference max may lag by 2^60 before a tile
+    // has to be redone.  f16 P must stay below 65504: on unscaled logits the redo would fire every few tiles
+    // (measured -4 %), so f16 keeps the per-tile max with the 2^8 lazy-rescale threshold.
+    constexpr bool SKIPMAX = FA_DMA_SKIPMAX && !E::is_f16;
+    constexpr float P_LIMIT = 1152921504606846976.0f;   // 2^60
 
     // ---- the pieces of one kv tile (buffer index BUF_ is compile-time); same arithmetic as fa_fwd_tile_kernel
 #define FA_QK(BUF_)                                                                                \
@@ -212,8 +225,22 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             f32x16 s0, s1;                                                                         \
             float ls;                                                                              \
             FA_QK(BUF_)                                                                            \
-            FA_MAX_RESCALE(RESCALE_THR)                                                            \
-            FA_SOFTMAX()                                                                           \
+            if (SKIPMAX) {                                                                         \
+                if (kv0 == 0) FA_MAX_RESCALE(0.0f)       /* first tile: m = -inf -> exact max */    \
+                FA_SOFTMAX()                                                                       \
+                /* (the fences keep hipcc from hoisting the PV operand reads above the rare branch, \
+                   which costs 26 VGPRs and a wave per SIMD) */                                    \
+                asm volatile("" ::: "memory");                                                     \
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(ls > P_LIMIT) != 0, 0)) {         \
+                    FA_QK(BUF_)                                                                    \
+                    FA_MAX_RESCALE(0.0f)                                                           \
+                    FA_SOFTMAX()                                                                   \
+                }                                                                                  \
+                asm volatile("" ::: "memory");                                                     \
+            } else {                                                                               \
+                FA_MAX_RESCALE(RESCALE_THR)                                                        \
+                FA_SOFTMAX()                                                                       \
+            }                                                                                      \
             l += ls;                                                                               \
             FA_PV(BUF_)                                                                            \
         }                                                                                          \

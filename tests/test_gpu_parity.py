@@ -347,3 +347,28 @@ def test_cpp_caller_of_the_c_abi(tmp_path):
                            f"-L{lib_dir}", "-lflash_attention", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
     res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "PASSED" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
+def test_growing_logits_force_the_redo_branch(dtype, step):
+    """The bf16 kernel keeps its reference max from the first tile and only redoes a tile (exact max +
+    rescale) when a row sum shows that some P left the safe range (cdna guide rule 26: a rare,
+    data-dependent branch needs inputs that FORCE it and a full-tensor independent reference).
+    Logits grow by `step` per 64-key tile: 3 never triggers, 25 triggers once the lag passes 2^60
+    (every other tile), 100 overflows exp2 to +inf inside a single tile."""
+    fa, _, _ = _mods()
+    from oracle import frozen_randn
+
+    G, L, D = 2, 1024, 64
+    x = frozen_randn(SEED + 55, (3, G, L, D)) * 0.05
+    u = torch.zeros(D)
+    u[:4] = 1.0                                           # |u|^2 = 4
+    tile = torch.arange(L) // 64
+    x[0] += u                                             # q = u + noise
+    x[1] += u[None, None, :] * (step / 4.0) * tile[None, :, None]   # k_c = u * step/4 * tile(c): s grows by `step` per tile
+    x = x.to(dtype)
+    ref, ref_lse = _oracle(x)
+    out2, lse = _mods()[2](x.cuda(), 1, 1)
+    _check(out2, ref, dtype, f"growing logits step={step}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
