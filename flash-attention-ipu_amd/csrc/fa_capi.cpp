@@ -182,6 +182,10 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     }
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    // f16 skip-max pays off when logits are small against the 2^15 headroom of f16 P: a softmax scale
+    // <= 0.25 means 1/sqrt(D)-style scaled attention (D >= 16); the packed op (scale 1) keeps the row max
+    p.skipmax = softmax_scale <= 0.25f ? 1 : 0;
+    if (const char* sm = getenv("FA_AMD_SKIPMAX")) p.skipmax = atoi(sm);
 
     // MFMA kernels: "dma" (LDS-DMA staged, default: 1.13-1.15x the register-staged one on every shape
     // measured) or "tile" (register-staged; FA_AMD_KERNEL=tile selects it for A/B runs)

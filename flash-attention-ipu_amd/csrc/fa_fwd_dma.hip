@@ -29,7 +29,7 @@ namespace fa {
 
 // (the body lives in a __device__ function: the buffer/LDS-DMA builtins do not exist for the host pass,
 // and a __global__ template that names them loses its host-side launch stub)
-template <typename T, int D, int NWAVES>
+template <typename T, int D, int NWAVES, bool SKIP>
 __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -143,11 +143,13 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     float m = -INFINITY;
     float l = 0.f;
     const float c = p.scale_log2;
-    // bf16 only: bf16 P keeps the fp32 exponent range, so the reference max may lag by 2^60 before a tile
-    // has to be redone.  f16 P must stay below 65504: on unscaled logits the redo would fire every few tiles
-    // (measured -4 %), so f16 keeps the per-tile max with the 2^8 lazy-rescale threshold.
-    constexpr bool SKIPMAX = FA_DMA_SKIPMAX && !E::is_f16;
-    constexpr float P_LIMIT = 1152921504606846976.0f;   // 2^60
+    // bf16 P keeps the fp32 exponent range, so the reference max may lag by 2^60 before a tile has to be
+    // redone.  f16 P must stay below 65504 (limit 2^15): on unscaled logits (std sqrt(D)) the redo fires
+    // every few tiles (measured -4 %), on 1/sqrt(D)-scaled logits it practically never does (+7 %).
+    // bf16 always takes the skip-max path; f16 has both instantiations and the host picks one from the
+    // softmax scale (fa_capi.cpp)
+    constexpr bool SKIPMAX = FA_DMA_SKIPMAX && SKIP;
+    constexpr float P_LIMIT = E::is_f16 ? 32768.0f : 1152921504606846976.0f;   // 2^15 | 2^60
 
     // ---- the pieces of one kv tile (buffer index BUF_ is compile-time); same arithmetic as fa_fwd_tile_kernel
 #define FA_QK(BUF_)                                                                                \
@@ -301,29 +303,31 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     }
 }
 
-// D=64 at 4+ waves per workgroup is built for 4 waves per SIMD (<= 128 VGPRs)
-template <typename T, int D, int NWAVES>
+template <typename T, int D, int NWAVES, bool SKIP>
 __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_dma_kernel(const FwdParams p) {
-    fa_fwd_dma_body<T, D, NWAVES>(p);
+    fa_fwd_dma_body<T, D, NWAVES, SKIP>(p);
 }
 
-template <typename T, int D>
+template <typename T, int D, bool SKIP>
 static hipError_t launch_dma_w(const FwdParams& p, int waves, hipStream_t stream) {
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
     switch (waves) {
-        case 8: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 8>), dim3((unsigned)grid), dim3(512), 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 2>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
-        default: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
+        case 8: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 8, SKIP>), dim3((unsigned)grid), dim3(512), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 4, SKIP>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 2, SKIP>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
+        default: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 1, SKIP>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
-    if (dtype == 1) {
-        return p.D == 64 ? launch_dma_w<__bf16, 64>(p, waves, stream) : launch_dma_w<__bf16, 128>(p, waves, stream);
+    if (dtype == 1) {   // bf16: always skip-max
+        return p.D == 64 ? launch_dma_w<__bf16, 64, true>(p, waves, stream) : launch_dma_w<__bf16, 128, true>(p, waves, stream);
     }
-    return p.D == 64 ? launch_dma_w<_Float16, 64>(p, waves, stream) : launch_dma_w<_Float16, 128>(p, waves, stream);
+    if (p.skipmax) {
+        return p.D == 64 ? launch_dma_w<_Float16, 64, true>(p, waves, stream) : launch_dma_w<_Float16, 128, true>(p, waves, stream);
+    }
+    return p.D == 64 ? launch_dma_w<_Float16, 64, false>(p, waves, stream) : launch_dma_w<_Float16, 128, false>(p, waves, stream);
 }
 
 }  // namespace fa

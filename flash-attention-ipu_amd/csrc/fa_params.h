@@ -25,6 +25,7 @@ struct FwdParams {
     int32_t D;
     int32_t nq_tiles;      // q tiles per group
     int32_t sched;         // groups per XCD bunch (>= 1): heavy-first order inside a bunch
+    int32_t skipmax;       // f16 only: 1 = reference max from the first tile + overflow-triggered redo
     float scale;           // softmax scale
     float scale_log2;      // scale * log2(e)
 };
