@@ -177,6 +177,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = t[0].item(), t[1].item()
 
+    measured_peak = None
+    if rank == 0:
+        with torch.cuda.device(dev):
+            mp = _native.load_native_library().fa_probe_mfma_peak(_native.FA_DTYPE[dtype], 4000)
+        measured_peak = round(mp, 1) if mp > 0 else None
     if rank == 0:
         total_tflops = world * flops_step * args.steps / elapsed / 1e12
         achieved = flops_step / (kernel_ms * 1e-3) / 1e12
@@ -198,10 +203,15 @@ def main():
                        "groups_per_gpu": G, "seq_len": L, "head_dim": D,
                        "tile": f"{plan.block_q}x{plan.block_kv} ({plan.waves} waves)",
                        "exchange": "rccl all-gather of O, overlapped" if do_gather else "none",
-                       "flops_per_step_per_gpu": flops_step},
+                       "flops_per_step_per_gpu": flops_step,
+                       "device": {"name": torch.cuda.get_device_name(dev),
+                                  "compute_units": torch.cuda.get_device_properties(dev).multi_processor_count,
+                                  "clock_mhz": getattr(torch.cuda.get_device_properties(dev), "clock_rate", 0) // 1000 or None}},
             "pct_mfma_peak": round(100.0 * total_tflops / (world * PEAK_TFLOPS), 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
+                         "measured_mfma_peak": measured_peak,
+                         "frac_of_measured_peak": round(achieved / measured_peak, 4) if measured_peak else None,
                          "kernel": "fa_fwd_dma_kernel", "avg_launch_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": 4 * G * L * D * 2},
         }

@@ -114,6 +114,11 @@ const char* fa_error_string(int code) {
     }
 }
 
+double fa_probe_mfma_peak(int32_t dtype, int32_t iters) {
+    if (!(dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) || iters < 1) return -1.0;
+    return fa::probe_mfma_peak(dtype, iters);
+}
+
 int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_shape[3]) {
     if (!qkv_shape || !out_shape) return fail(FA_ERR_NULL_POINTER, "null shape pointer");
     if (rank != 4) return fail(FA_ERR_BAD_SHAPE, "qkv must have 4 dimensions (got %d)", rank);

@@ -51,5 +51,7 @@ hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream);
 
+double probe_mfma_peak(int dtype, int iters);   // fa_probe.hip
+
 }  // namespace fa
 #endif
