@@ -177,11 +177,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = t[0].item(), t[1].item()
 
-    measured_peak = None
+    measured_peak = measured_peak_random = None
     if rank == 0:
         with torch.cuda.device(dev):
-            mp = _native.load_native_library().fa_probe_mfma_peak(_native.FA_DTYPE[dtype], 4000)
+            lib_ = _native.load_native_library()
+            mp = lib_.fa_probe_mfma_peak(_native.FA_DTYPE[dtype], 4000, 0)
+            mpr = lib_.fa_probe_mfma_peak(_native.FA_DTYPE[dtype], 40000, 1)   # ~30 ms per repetition: clock settles
         measured_peak = round(mp, 1) if mp > 0 else None
+        measured_peak_random = round(mpr, 1) if mpr > 0 else None
     if rank == 0:
         total_tflops = world * flops_step * args.steps / elapsed / 1e12
         achieved = flops_step / (kernel_ms * 1e-3) / 1e12
@@ -212,6 +215,8 @@ def main():
                          "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
                          "measured_mfma_peak": measured_peak,
                          "frac_of_measured_peak": round(achieved / measured_peak, 4) if measured_peak else None,
+                         "measured_mfma_peak_random_operands": measured_peak_random,
+                         "frac_of_measured_peak_random_operands": round(achieved / measured_peak_random, 4) if measured_peak_random else None,
                          "kernel": "fa_fwd_dma_kernel", "avg_launch_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": 4 * G * L * D * 2},
         }

@@ -114,9 +114,9 @@ const char* fa_error_string(int code) {
     }
 }
 
-double fa_probe_mfma_peak(int32_t dtype, int32_t iters) {
+double fa_probe_mfma_peak(int32_t dtype, int32_t iters, int32_t random_data) {
     if (!(dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) || iters < 1) return -1.0;
-    return fa::probe_mfma_peak(dtype, iters);
+    return fa::probe_mfma_peak(dtype, iters, random_data);
 }
 
 int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_shape[3]) {
@@ -196,8 +196,11 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     // measured) or "tile" (register-staged; FA_AMD_KERNEL=tile selects it for A/B runs)
     char which = 'd';
     const char* kv = getenv("FA_AMD_KERNEL");
-    if (kv && (kv[0] == 't' || kv[0] == 'd')) which = kv[0];
+    if (kv && (kv[0] == 't' || kv[0] == 'd' || kv[0] == 'p')) which = kv[0];
+    // "pipe": software-pipelined 32-key steps; skip-max arithmetic only, at most 4 waves
+    if (which == 'p' && !(plan.waves <= 4 && (dtype == FA_DTYPE_BF16 || p.skipmax))) which = 'd';
     hipError_t e = plan.kernel != 0 ? fa::launch_fwd_generic(p, dtype, (hipStream_t)stream)
+                   : which == 'p'   ? fa::launch_fwd_pipe(p, dtype, plan.waves, (hipStream_t)stream)
                    : which == 'd'   ? fa::launch_fwd_dma(p, dtype, plan.waves, (hipStream_t)stream)
                                     : fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

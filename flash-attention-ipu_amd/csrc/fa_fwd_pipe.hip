@@ -1,0 +1,463 @@
+// FlashAttention forward for MI355X (gfx950): software-pipelined 32-key steps.
+//
+// Same LDS images, MFMA operand maps, LDS-DMA staging and arithmetic as fa_fwd_dma_kernel (read
+// fa_fwd_kernels.hip and fa_fwd_dma.hip first).  What changes is the ORDER of work inside a wave.
+// fa_fwd_dma_kernel runs  QK^T (8 MFMA) -> softmax (~110 VALU) -> PV (8 MFMA)  strictly one after the other
+// per 64-key tile, so a wave's matrix work never overlaps its own vector work and the SIMD relies on the other
+// three waves to fill the gaps (measured: VALU issue port 71 % busy).  Here the kv loop advances in steps of
+// 32 keys and iteration i of a wave issues, interleaved by sched_group_barrier,
+//
+//        MFMA:  S(i+1) = K(i+1) Q^T          and      O^T += V(i-1)^T P(i-1)^T
+//        VALU:  P(i)   = 2^(c S(i) - c m),  row sums, bf16/f16 packing
+//
+// i.e. the matrix pipe works on the next and the previous step while the vector pipe exponentiates the current
+// one; the accumulators of S(i) and S(i+1) are the two halves of what used to be one 64-key tile, so the
+// register budget (and 4 waves per SIMD at head_dim 64) is unchanged.  scripts/microbench/pipe_half.hip has the
+// instruction-mix measurement that motivated it (0.444 -> 0.396 us per wave-tile per SIMD).
+//
+// Only the skip-max arithmetic is implemented (reference max fixed on the first step, overflow-triggered
+// redo; see fa_fwd_dma.hip): bf16 always, f16 when the host selects it.  K and V live in rings of four 32-key
+// slots; step i reads K(i+1), V(i-1) (and K(i) if it has to redo), while the DMA fills K(i+3) and V(i+2).
+// One workgroup barrier per step; the DMA issued in a step may stay in flight across that step's barrier
+// (s_waitcnt vmcnt(2*PPW)), so a slot has two full steps to land.
+
+#include "fa_device.h"
+
+// steady step: LDS operands (K rows / V^T fragments) are requested this many MFMAs ahead of their use
+#ifndef FA_PIPE_PF
+#define FA_PIPE_PF 6
+#endif
+// timing-only ablations (wrong results): -DFA_PIPE_ABL=1 no per-step barrier, 2 no per-step DMA
+#ifndef FA_PIPE_ABL
+#define FA_PIPE_ABL 0
+#endif
+#if FA_PIPE_ABL == 1
+#define FA_PIPE_BARRIER() asm volatile("" ::: "memory")
+#else
+#define FA_PIPE_BARRIER() __syncthreads()
+#endif
+
+namespace fa {
+
+template <typename T, int D, int NWAVES>
+__device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
+    using E = Elt<T>;
+    using vec8 = typename E::vec8;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    constexpr int BQ = NWAVES * 32;
+    constexpr int HK = 32;                      // keys per step
+    constexpr int ROWB = D * 2;
+    constexpr int KH_B = HK * ROWB;             // K slot
+    constexpr int VBLK_B = HK * 64 + 64;        // one 32-column d-block of a V slot (+64 B stagger)
+    constexpr int VH_B = (D / 32) * VBLK_B;     // V slot
+    constexpr int PIECES = KH_B / 1024;         // 1 KiB DMA pieces per K (or V) slot
+    constexpr int PPW = PIECES / NWAVES;
+    constexpr int KS = D / 16;
+    constexpr int DT = D / 32;
+    static_assert(PIECES % NWAVES == 0 && PPW >= 1, "pieces must split evenly over the waves");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * KH_B + 4 * VH_B];   // K0..K3 V0..V3
+    unsigned char* const smem_v = smem + 4 * KH_B;
+    __shared__ int flags[NWAVES];
+
+    const int b = blockIdx.x;
+    const int nq = p.nq_tiles;
+    int g, qi;
+    {
+        const int xcd = b & 7, slot = b >> 3;
+        const int ng = p.G8 >> 3;
+        const int per_bunch = p.sched * nq;
+        const int bunch = slot / per_bunch;
+        const int rem = slot - bunch * per_bunch;
+        const int g0 = bunch * p.sched;
+        const int bc = (ng - g0) < p.sched ? (ng - g0) : p.sched;
+        const int qd = rem / bc;
+        qi = nq - 1 - qd;
+        g = (g0 + (rem - qd * bc)) * 8 + xcd;
+    }
+    if (g >= p.G) return;
+
+    const int L = p.L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bb = g / p.H, hh = g - bb * p.H;
+    const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
+    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
+    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+
+    const int q_row0 = qi * BQ + wave * 32;
+    const int qrow = q_row0 + r;
+    const bool wave_active = q_row0 < L;
+
+    vec8 qf[KS];
+    {
+        const int qr = qrow < L ? qrow : L - 1;
+        const T* qp = qg + (int64_t)qr * p.q_sl + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const vec8*)(qp + 16 * ks);
+    }
+
+    // ---- LDS-DMA geometry (as fa_fwd_dma_kernel, for 32-key slots)
+    const unsigned k_slb = (unsigned)p.k_sl * 2, v_slb = (unsigned)p.v_sl * 2;
+    unsigned k_vo[PPW], v_vo[PPW];
+    int k_dst[PPW], v_dst[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pc = wave + j * NWAVES;
+        const int row = pc * (1024 / ROWB) + lane / (ROWB / 16);
+        const int cp = lane % (ROWB / 16);
+        const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+        k_vo[j] = (unsigned)row * k_slb + ((cp ^ sw) << 4);
+        k_dst[j] = pc * 1024;
+        const int dblk = pc >> 1, q2 = pc & 1;   // a piece = two 8-key blocks of one d-block
+        const int key = (2 * q2 + (lane >> 5)) * 8 + ((lane >> 2) & 7);
+        v_vo[j] = (unsigned)key * v_slb + ((dblk * 4 + (lane & 3)) << 4);
+        v_dst[j] = dblk * VBLK_B + q2 * 1024;
+    }
+    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;
+    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
+    const unsigned smem_lds = lds_offset(smem);
+
+#define FA_DMA_K(J_, SLOT_)                                                                        \
+    {                                                                                              \
+        const unsigned ko_ = (unsigned)(J_) * HK * k_slb;                                          \
+        const i32x4 kr_ = make_raw_rsrc((const char*)kg + ko_, k_bytes - ko_);                     \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
+            lds_dma_b128(kr_, smem_lds + (SLOT_) * KH_B + k_dst[j], k_vo[j]);                      \
+    }
+#define FA_DMA_V(J_, SLOT_)                                                                        \
+    {                                                                                              \
+        const unsigned vo_ = (unsigned)(J_) * HK * v_slb;                                          \
+        const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
+            lds_dma_b128(vr_, smem_lds + 4 * KH_B + (SLOT_) * VH_B + v_dst[j], v_vo[j]);           \
+    }
+
+    int k_rd[KS];
+    {
+        const int sw = (D == 64) ? ((r >> 1) & 7) : (r & 15);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * ROWB + (((2 * ks + h) ^ sw) << 4);
+    }
+    const int v_rd = (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    const int nh_wg = (kv_end + HK - 1) / HK;                 // steps the workgroup streams
+    const int nh_w = wave_active ? q_row0 / HK + 1 : 0;       // steps this wave computes (last = diagonal)
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    float m = -INFINITY;
+    float l = 0.f;
+    const float c = p.scale_log2;
+    constexpr float P_LIMIT = E::is_f16 ? 32768.0f : 1152921504606846976.0f;   // 2^15 | 2^60
+
+    // S = K(slot) Q^T for one 32-key step
+#define FA_QK_H(S_, SLOT_)                                                                         \
+    {                                                                                              \
+        const unsigned char* kb_ = smem + (SLOT_) * KH_B;                                          \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) S_[e] = 0.f;                                \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                          \
+            S_ = E::mfma(*(const vec8*)(kb_ + k_rd[ks]), qf[ks], S_);                              \
+    }
+    // O^T += V(slot)^T P^T
+#define FA_PV_H(P_, SLOT_)                                                                         \
+    {                                                                                              \
+        const unsigned char* vb_ = smem_v + (SLOT_) * VH_B;                                        \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                         \
+            _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                    \
+                const unsigned char* vp = vb_ + dt * VBLK_B + kk * 1024 + v_rd;                    \
+                const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
+                    (i16x4 __attribute__((address_space(3)))*)(vp));                               \
+                const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
+                    (i16x4 __attribute__((address_space(3)))*)(vp + 512));                         \
+                const i16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);          \
+                o[dt] = E::mfma(__builtin_bit_cast(vec8, v8), P_[kk], o[dt]);                      \
+            }                                                                                      \
+        }                                                                                          \
+    }
+#define FA_MASK_H(S_, J_)                                                                          \
+    {                                                                                              \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                           \
+            const int key = (J_) * HK + (e & 3) + 8 * (e >> 2) + 4 * h;                            \
+            if (key > qrow) S_[e] = -INFINITY;                                                     \
+        }                                                                                          \
+    }
+    // exact row max of the step; raise m (rescaling O and l) wherever it is exceeded
+#define FA_MAXR_H(S_)                                                                              \
+    {                                                                                              \
+        float mx = max2(S_[0], S_[1]);                                                             \
+        _Pragma("unroll") for (int e = 2; e < 16; e += 2) mx = max3(mx, S_[e], S_[e + 1]);         \
+        mx = half_swap_max(mx);                                                                    \
+        if (__builtin_amdgcn_ballot_w64((mx - m) * c > 0.0f) != 0) {                               \
+            const float m_new = max2(m, mx);                                                       \
+            const float alpha = fast_exp2((m - m_new) * c);                                        \
+            m = m_new;                                                                             \
+            l *= alpha;                                                                            \
+            _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                      \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;                  \
+        }                                                                                          \
+    }
+#define FA_SM_H(S_)                                                                                \
+    {                                                                                              \
+        const float mc = m * c;                                                                    \
+        ls = 0.f;                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                           \
+            S_[e] = fast_exp2(__builtin_fmaf(S_[e], c, -mc));                                      \
+            ls += S_[e];                                                                           \
+        }                                                                                          \
+    }
+#define FA_PACK_H(P_, S_)                                                                          \
+    {                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+            P_[0][j] = (T)S_[j];                                                                   \
+            P_[1][j] = (T)S_[8 + j];                                                               \
+        }                                                                                          \
+    }
+    // every step: issue the DMA for K(i+3), V(i+2); compute; publish (everything issued before this step has
+    // landed - this step's own DMA may fly on across the barrier)
+#define FA_ISSUE(I_, KSLOT_, VSLOT_)                                                               \
+        const bool dk_ = (I_) + 3 < nh_wg, dv_ = (I_) + 2 < nh_wg;                                 \
+        if (dk_ && FA_PIPE_ABL != 2) FA_DMA_K((I_) + 3, KSLOT_)                                    \
+        if (dv_ && FA_PIPE_ABL != 2) FA_DMA_V((I_) + 2, VSLOT_)
+#define FA_PUBLISH()                                                                               \
+        if (dk_ && dv_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");             \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        FA_PIPE_BARRIER();
+    // steady-state step I_ (ring index R_ = I_ & 3 at compile time): S(I_) is in SC_, SN_ receives S(I_+1),
+    // PP_ holds P(I_-1), PC_ receives P(I_); no mask, all three stages, no branch: a P that outgrew the safe
+    // range only raises `bad` (any rare path in here costs phi copies of the accumulators on every step).
+    // The instruction order is written out by hand and frozen with sched_barrier(0): NM = KS + 2 DT MFMAs
+    // (S(I_+1) first - the next step's vector work needs it first - then O += V P), each followed by its share
+    // of the softmax of S(I_): score pair p (two registers -> one packed dword of P) goes fma -> exp -> add,
+    // cvt, skewed over three groups so that nothing waits for the transcendental unit; LDS operands are
+    // requested FA_PIPE_PF MFMAs ahead.
+#define FA_OPND_LOAD(IDX_)                                                                         \
+        if ((IDX_) < KS) {                                                                         \
+            opnd[(IDX_)] = *(const vec8*)(kb_ + k_rd[(IDX_) < KS ? (IDX_) : 0]);                   \
+        } else {                                                                                   \
+            const int t_ = (IDX_) - KS;                                                            \
+            const unsigned char* vp = vb_ + (t_ % DT) * VBLK_B + (t_ / DT) * 1024 + v_rd;          \
+            const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                              \
+                (i16x4 __attribute__((address_space(3)))*)(vp));                                   \
+            const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                              \
+                (i16x4 __attribute__((address_space(3)))*)(vp + 512));                             \
+            opnd[(IDX_)] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); \
+        }
+#define FA_PAIR_FMA(SC_, P_) { SC_[2 * (P_)] = __builtin_fmaf(SC_[2 * (P_)], c, -mc); SC_[2 * (P_) + 1] = __builtin_fmaf(SC_[2 * (P_) + 1], c, -mc); }
+#define FA_PAIR_EXP(SC_, P_) { SC_[2 * (P_)] = fast_exp2(SC_[2 * (P_)]); SC_[2 * (P_) + 1] = fast_exp2(SC_[2 * (P_) + 1]); }
+#define FA_PAIR_SUM(SC_, PC_, P_)                                                                  \
+        {                                                                                          \
+            ls += SC_[2 * (P_)];                                                                   \
+            ls += SC_[2 * (P_) + 1];                                                               \
+            PC_[(P_) >> 2][2 * ((P_) & 3)] = (T)SC_[2 * (P_)];                                     \
+            PC_[(P_) >> 2][2 * ((P_) & 3) + 1] = (T)SC_[2 * (P_) + 1];                             \
+        }
+#define FA_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                      \
+    {                                                                                              \
+        FA_ISSUE(I_, ((R_) + 3) & 3, ((R_) + 2) & 3)                                               \
+        constexpr int NM = KS + 2 * DT, STRIDE = NM / 8;                                           \
+        const unsigned char* kb_ = smem + (((R_) + 1) & 3) * KH_B;                                 \
+        const unsigned char* vb_ = smem_v + (((R_) + 3) & 3) * VH_B;                               \
+        vec8 opnd[NM];                                                                             \
+        _Pragma("unroll") for (int x_ = 0; x_ < FA_PIPE_PF; ++x_) { FA_OPND_LOAD(x_) }             \
+        const float mc = m * c;                                                                    \
+        float ls = 0.f;                                                                            \
+        FA_PAIR_FMA(SC_, 0)                                                                        \
+        FA_PAIR_EXP(SC_, 0)                                                                        \
+        FA_PAIR_FMA(SC_, 1)                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        _Pragma("unroll") for (int g_ = 0; g_ < NM; ++g_) {                                        \
+            if (g_ < KS) {                                                                         \
+                if (g_ == 0) {                                                                     \
+                    f32x16 z_;                                                                     \
+                    _Pragma("unroll") for (int e = 0; e < 16; ++e) z_[e] = 0.f;                    \
+                    SN_ = E::mfma(opnd[g_], qf[g_ < KS ? g_ : 0], z_);                             \
+                } else {                                                                           \
+                    SN_ = E::mfma(opnd[g_], qf[g_ < KS ? g_ : 0], SN_);                            \
+                }                                                                                  \
+            } else {                                                                               \
+                o[(g_ - KS) % DT] = E::mfma(opnd[g_], PP_[(g_ < KS ? 0 : g_ - KS) / DT], o[(g_ - KS) % DT]); \
+            }                                                                                      \
+            if (g_ + FA_PIPE_PF < NM) { FA_OPND_LOAD(g_ + FA_PIPE_PF) }                            \
+            if (g_ % STRIDE == 0) {                                                                \
+                const int pr_ = g_ / STRIDE;                                                       \
+                if (pr_ + 1 < 8) { FA_PAIR_EXP(SC_, (pr_ + 1 < 8 ? pr_ + 1 : 0)) }                  \
+                FA_PAIR_SUM(SC_, PC_, pr_)                                                         \
+                if (pr_ + 2 < 8) { FA_PAIR_FMA(SC_, (pr_ + 2 < 8 ? pr_ + 2 : 0)) }                  \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+        bad |= !(ls <= P_LIMIT);                                                                   \
+        l += ls;                                                                                   \
+        /* pin this step's vector work to this step (hipcc otherwise sinks it below the barrier,  \
+           in front of the PV that needs it) */                                                   \
+        asm volatile("" : "+v"(PC_[0]), "+v"(PC_[1]), "+v"(l));                                    \
+        FA_PUBLISH()                                                                               \
+    }
+    // generic step (runtime ring slots, compiler's own schedule): the first step, the up to three steps left
+    // over by the groups of four, the diagonal step, the drain step and the idle steps of a finished wave.
+    // SAFE_ = the fallback pass: a step whose P outgrew the safe range is redone with an exact max.
+#define FA_GENERIC(I_, SC_, SN_, PP_, PC_, SAFE_)                                                  \
+    {                                                                                              \
+        const int i_ = (I_);                                                                       \
+        FA_ISSUE(i_, (i_ + 3) & 3, (i_ + 2) & 3)                                                   \
+        if (i_ + 1 < nh_w) FA_QK_H(SN_, (i_ + 1) & 3)                                              \
+        if (i_ >= 1 && i_ <= nh_w) FA_PV_H(PP_, (i_ + 3) & 3)                                      \
+        if (i_ < nh_w) {                                                                           \
+            float ls;                                                                              \
+            const bool diag_ = i_ == nh_w - 1;                                                     \
+            if (diag_) FA_MASK_H(SC_, i_)                                                          \
+            if (i_ == 0) FA_MAXR_H(SC_)                                                            \
+            FA_SM_H(SC_)                                                                           \
+            if (SAFE_) {                                                                           \
+                if (__builtin_amdgcn_ballot_w64(!(ls <= P_LIMIT)) != 0) {                          \
+                    FA_QK_H(SC_, i_ & 3)                                                           \
+                    if (diag_) FA_MASK_H(SC_, i_)                                                  \
+                    FA_MAXR_H(SC_)                                                                 \
+                    FA_SM_H(SC_)                                                                   \
+                }                                                                                  \
+            } else {                                                                               \
+                bad |= !(ls <= P_LIMIT);                                                           \
+            }                                                                                      \
+            l += ls;                                                                               \
+            FA_PACK_H(PC_, SC_)                                                                    \
+        }                                                                                          \
+        FA_PUBLISH()                                                                               \
+    }
+    // one pass over the kv steps of this workgroup.  S(i) lives in sa for even i and in sb for odd i; P(i) in
+    // pa / pb likewise.  Groups of four steady steps start at i = 1: steps i .. i+3 all have a predecessor and
+    // a successor.
+#define FA_RUN(SAFE_)                                                                              \
+    {                                                                                              \
+        FA_DMA_K(0, 0)                                                                             \
+        FA_DMA_V(0, 0)                                                                             \
+        if (1 < nh_wg) {                                                                           \
+            FA_DMA_K(1, 1)                                                                         \
+            FA_DMA_V(1, 1)                                                                         \
+        }                                                                                          \
+        if (2 < nh_wg) FA_DMA_K(2, 2)                                                              \
+        lds_dma_wait_all();                                                                        \
+        __syncthreads();                                                                           \
+        if (nh_w >= 1) FA_QK_H(sa, 0)                                                              \
+        FA_GENERIC(0, sa, sb, pb, pa, SAFE_)                                                       \
+        int i = 1;                                                                                 \
+        if (!(SAFE_)) {                                                                            \
+            for (; i + 4 < nh_w; i += 4) {                                                         \
+                FA_STEADY(i, 1, sb, sa, pa, pb)                                                    \
+                FA_STEADY(i + 1, 2, sa, sb, pb, pa)                                                \
+                FA_STEADY(i + 2, 3, sb, sa, pa, pb)                                                \
+                FA_STEADY(i + 3, 0, sa, sb, pb, pa)                                                \
+            }                                                                                      \
+        }                                                                                          \
+        for (; i <= nh_wg; i += 2) {                                                               \
+            FA_GENERIC(i, sb, sa, pa, pb, SAFE_)                                                   \
+            if (i + 1 <= nh_wg) FA_GENERIC(i + 1, sa, sb, pb, pa, SAFE_)                           \
+        }                                                                                          \
+    }
+
+    f32x16 sa, sb;
+    vec8 pa[2], pb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pa[0][j] = (T)0.f; pa[1][j] = (T)0.f; pb[0][j] = (T)0.f; pb[1][j] = (T)0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q landed (see fa_fwd_tile_kernel)
+
+    bool bad = false;
+    FA_RUN(false)
+    // Did any row of the workgroup leave the safe range?  (All waves must agree: the fallback pass re-streams
+    // K/V through the same barriers.)  Practically never taken: logits must outgrow the first step's row max
+    // by 2^60 (bf16) / 2^15 (f16, 1/sqrt(D)-scaled logits only).
+    flags[wave] = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
+    __syncthreads();
+    int any_bad = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) any_bad |= flags[w];
+    if (any_bad) {
+        __syncthreads();   // (flags are rewritten only by a later launch; this orders the LDS ring reuse)
+        m = -INFINITY;
+        l = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+        FA_RUN(true)
+    }
+#undef FA_ISSUE
+#undef FA_PUBLISH
+#undef FA_STEADY
+#undef FA_OPND_LOAD
+#undef FA_PAIR_FMA
+#undef FA_PAIR_EXP
+#undef FA_PAIR_SUM
+#undef FA_GENERIC
+#undef FA_RUN
+#undef FA_DMA_K
+#undef FA_DMA_V
+#undef FA_QK_H
+#undef FA_PV_H
+#undef FA_MASK_H
+#undef FA_MAXR_H
+#undef FA_SM_H
+#undef FA_PACK_H
+
+    // ---- epilogue: O /= l through LDS, whole-row stores (as fa_fwd_dma_kernel; the K ring is free now)
+    if (!wave_active) return;
+    const float lt = half_swap_sum(l);
+    const float inv = __builtin_amdgcn_rcpf(lt);
+    unsigned char* slab = smem + wave * (32 * ROWB);
+    constexpr int CPR = D / 8;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            vec4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (T)(o[dt][4 * rg + j] * inv);
+            const int ch = 4 * dt + rg;
+            *(vec4*)(slab + r * ROWB + ((ch ^ (r & (CPR - 1))) << 4) + 8 * h) = w;
+        }
+    }
+    if (p.lse != nullptr && h == 0 && qrow < L) p.lse[(int64_t)g * L + qrow] = m * p.scale + __logf(lt);
+    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
+    constexpr int RPI = 64 / CPR;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int rr = i * RPI + lane / CPR, ch = lane % CPR;
+        const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
+        if (q_row0 + rr < L) *(u32x4*)(og + (int64_t)(q_row0 + rr) * p.o_sl + ch * 8) = val;
+    }
+}
+
+#ifndef FA_PIPE_MIN_WAVES
+#define FA_PIPE_MIN_WAVES 1
+#endif
+template <typename T, int D, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, (D == 64 && NWAVES == 4) ? FA_PIPE_MIN_WAVES : 1) void fa_fwd_pipe_kernel(const FwdParams p) {
+    fa_fwd_pipe_body<T, D, NWAVES>(p);
+}
+
+template <typename T, int D>
+static hipError_t launch_pipe_w(const FwdParams& p, int waves, hipStream_t stream) {
+    const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
+    switch (waves) {
+        case 4: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 2>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
+        default: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
+    }
+    return hipGetLastError();
+}
+
+// callers guarantee: D in {64, 128}, waves in {1, 2, 4}, skip-max arithmetic wanted (bf16, or f16 with p.skipmax)
+hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
+    if (dtype == 1) return p.D == 64 ? launch_pipe_w<__bf16, 64>(p, waves, stream) : launch_pipe_w<__bf16, 128>(p, waves, stream);
+    return p.D == 64 ? launch_pipe_w<_Float16, 64>(p, waves, stream) : launch_pipe_w<_Float16, 128>(p, waves, stream);
+}
+
+}  // namespace fa

@@ -51,7 +51,8 @@ hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream);
 
-double probe_mfma_peak(int dtype, int iters);   // fa_probe.hip
+hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, hipStream_t stream);   // fa_fwd_pipe.hip
+double probe_mfma_peak(int dtype, int iters, int random_data);   // fa_probe.hip
 
 }  // namespace fa
 #endif

@@ -8,11 +8,21 @@
 namespace fa {
 
 template <typename T>
-__global__ __launch_bounds__(256) void fa_mfma_peak_kernel(float* out, int iters) {
+__global__ __launch_bounds__(256) void fa_mfma_peak_kernel(float* out, int iters, int random_data) {
     using E = Elt<T>;
     typename E::vec8 a, b;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a[j] = (T)(0.001f * (float)(threadIdx.x + j)); b[j] = (T)(0.002f * (float)(j + 1)); }
+    if (random_data) {   // N(0,1)-like operands, different in every lane: realistic switching activity (power)
+        unsigned s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s = s * 1664525u + 1013904223u;
+            a[j] = (T)(((float)(s >> 8) * (1.0f / 16777216.0f) - 0.5f) * 3.4f);
+            s = s * 1664525u + 1013904223u;
+            b[j] = (T)(((float)(s >> 8) * (1.0f / 16777216.0f) - 0.5f) * 3.4f);
+        }
+    }
     f32x16 c0, c1, c2, c3;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { c0[e] = 0.f; c1[e] = 0.f; c2[e] = 0.f; c3[e] = 0.f; }
@@ -32,7 +42,7 @@ __global__ __launch_bounds__(256) void fa_mfma_peak_kernel(float* out, int iters
 }
 
 // returns TFLOP/s (<= 0 on failure); synchronises the device - a bench utility, not a data-path call
-double probe_mfma_peak(int dtype, int iters) {
+double probe_mfma_peak(int dtype, int iters, int random_data) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1.0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return -1.0;
@@ -45,8 +55,8 @@ double probe_mfma_peak(int dtype, int iters) {
     double best = -1.0;
     for (int rep = 0; rep < 6; ++rep) {   // rep 0 warms the clock up
         (void)hipEventRecord(e0, nullptr);
-        if (dtype == 1) hipLaunchKernelGGL(fa_mfma_peak_kernel<__bf16>, dim3(grid), dim3(256), 0, nullptr, buf, iters);
-        else hipLaunchKernelGGL(fa_mfma_peak_kernel<_Float16>, dim3(grid), dim3(256), 0, nullptr, buf, iters);
+        if (dtype == 1) hipLaunchKernelGGL(fa_mfma_peak_kernel<__bf16>, dim3(grid), dim3(256), 0, nullptr, buf, iters, random_data);
+        else hipLaunchKernelGGL(fa_mfma_peak_kernel<_Float16>, dim3(grid), dim3(256), 0, nullptr, buf, iters, random_data);
         (void)hipEventRecord(e1, nullptr);
         if (hipEventSynchronize(e1) != hipSuccess) break;
         float ms = 0.f;

@@ -84,7 +84,7 @@ def _declare(lib):
     lib.fa_bwd.restype = ctypes.c_int
     lib.fa_bwd.argtypes = [vp] * 10 + [i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32, vp]
     lib.fa_probe_mfma_peak.restype = ctypes.c_double
-    lib.fa_probe_mfma_peak.argtypes = [i32, i32]
+    lib.fa_probe_mfma_peak.argtypes = [i32, i32, i32]
     lib.fa_fwd_qkv_packed.restype = ctypes.c_int
     lib.fa_fwd_qkv_packed.argtypes = [vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
 

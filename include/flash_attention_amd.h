@@ -87,9 +87,11 @@ const char* fa_error_string(int code);
 
 /* Bench utility (NOT a data-path call: allocates a scratch buffer and synchronises the device): measured
  * dense MFMA throughput of the current device in TFLOP/s for FA_DTYPE_BF16 / FA_DTYPE_F16, from a register-only
- * loop of v_mfma_f32_32x32x16 at 4 waves per SIMD on every CU; <= 0 on failure.  bench.py reports the
- * attention kernel against this as well as against the nominal 2.5 PFLOP/s. */
-double fa_probe_mfma_peak(int32_t dtype, int32_t iters);
+ * loop of v_mfma_f32_32x32x16 at 4 waves per SIMD on every CU; <= 0 on failure.  random_data = 0 feeds
+ * near-constant operands (the device holds its full clock), 1 feeds N(0,1)-like operands that differ in every
+ * lane (realistic switching activity: the device drops its clock to stay inside its power limit).  bench.py
+ * reports the attention kernel against both as well as against the nominal 2.5 PFLOP/s. */
+double fa_probe_mfma_peak(int32_t dtype, int32_t iters, int32_t random_data);
 
 /* [3,G,L,D] -> [G,L,D]; returns FA_OK or FA_ERR_BAD_SHAPE (rank != 4 or dim0 != 3). */
 int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_shape[3]);
