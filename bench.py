@@ -204,7 +204,7 @@ def main():
             "config": {"workload": f"{args.config}: packed qkv [3,{G},{L},{D}] {dname} per GPU, causal, "
                                    f"num_chunks=({nq},{nk}), flash_attention_qkv_packed forward",
                        "groups_per_gpu": G, "seq_len": L, "head_dim": D,
-                       "tile": f"{plan.block_q}x{plan.block_kv} ({plan.waves} waves)",
+                       "tile": f"{plan.block_q} query rows x {plan.block_kv} keys per workgroup step ({plan.waves} waves)",
                        "exchange": "rccl all-gather of O, overlapped" if do_gather else "none",
                        "flops_per_step_per_gpu": flops_step,
                        "device": {"name": torch.cuda.get_device_name(dev),
@@ -217,7 +217,7 @@ def main():
                          "frac_of_measured_peak": round(achieved / measured_peak, 4) if measured_peak else None,
                          "measured_mfma_peak_random_operands": measured_peak_random,
                          "frac_of_measured_peak_random_operands": round(achieved / measured_peak_random, 4) if measured_peak_random else None,
-                         "kernel": "fa_fwd_dma_kernel", "avg_launch_ms": round(kernel_ms, 4),
+                         "kernel": "fa_fwd_pipe_kernel" if plan.kernel == 2 else "fa_fwd_dma_kernel", "avg_launch_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": 4 * G * L * D * 2},
         }
         if not args.no_cpu_baseline and world == 1:

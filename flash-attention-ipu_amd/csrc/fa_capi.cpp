@@ -58,7 +58,34 @@ bool tile_kernel_ok(int64_t D, int dtype, const void* const ptrs[4], const int64
     return true;
 }
 
-int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, bool tile_ok, fa_plan_t* plan) {
+// Which MFMA kernel serves a request:
+//   'd' fa_fwd_dma_kernel   64-key tiles, LDS-DMA staged (fa_fwd_dma.hip)
+//   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic only
+//   't' fa_fwd_tile_kernel  register-staged A/B baseline (FA_AMD_KERNEL=tile)
+// and qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
+// Default: head_dim 64 with 4 waves, skip-max arithmetic and L >= 4096 -> 'p' with qb 2 (256-row workgroups:
+// +1..8 % measured at L 4096 .. 32768; slower below); everything else -> 'd' with qb 1.
+// FA_AMD_KERNEL=dma|pipe|tile and FA_AMD_QB=1|2 override (developer knobs).
+struct KernelChoice { char which; int qb; };
+KernelChoice pick_kernel(int64_t L, int64_t D, int waves, bool skip_ok) {
+    const char* kv = getenv("FA_AMD_KERNEL");
+    const char forced = (kv && (kv[0] == 't' || kv[0] == 'd' || kv[0] == 'p')) ? kv[0] : 0;
+    const char* qe = getenv("FA_AMD_QB");
+    const int qb_env = (qe && *qe) ? atoi(qe) : 0;
+    KernelChoice kc{'d', 1};
+    const bool pipe_ok = skip_ok && waves <= 4;
+    if (forced == 't') return KernelChoice{'t', 1};
+    if (forced == 'p' && pipe_ok) kc.which = 'p';
+    if (forced == 0 && pipe_ok && D == 64 && waves == 4 && L >= 4096) kc = KernelChoice{'p', 2};
+    const bool qb2_ok = D == 64 && L >= 256 && (waves == 4 || (waves == 2 && kc.which == 'p'));
+    if (qb_env == 1) kc.qb = 1;
+    if (qb_env == 2 && qb2_ok) kc.qb = 2;
+    if (forced == 'p' && kc.which == 'p' && qb_env == 0) kc.qb = (qb2_ok && waves == 4) ? 2 : 1;
+    return kc;
+}
+
+int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, bool tile_ok, bool skip_ok, fa_plan_t* plan,
+              KernelChoice* choice) {
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1 (got %lld, %lld, %lld)", (long long)G, (long long)L, (long long)D);
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     if (nq < 1 || L % nq != 0) return fail(FA_ERR_CHUNKS_Q, "sequence length %lld is not divisible by num_chunks_q=%d", (long long)L, nq);
@@ -68,14 +95,17 @@ int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
     if (tile_ok) {
-        plan->kernel = 0;
         plan->waves = pick_waves(L, plan->chunk_q);
-        plan->block_q = 32 * plan->waves;
-        plan->block_kv = 64;
+        const KernelChoice kc = pick_kernel(L, D, plan->waves, skip_ok);
+        if (choice) *choice = kc;
+        plan->kernel = kc.which == 'p' ? 2 : 0;
+        plan->block_q = 32 * plan->waves * kc.qb;
+        plan->block_kv = kc.which == 'p' ? 32 : 64;
         const int64_t nqt = (L + plan->block_q - 1) / plan->block_q;
         const int64_t g8 = (G + 7) / 8 * 8;
         plan->grid = g8 * nqt;
-        plan->lds_bytes = 2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64);
+        plan->lds_bytes = kc.which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * plan->waves
+                                          : 2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64);
     } else {
         if (D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic kernel supports D <= 1024 (got %lld)", (long long)D);
         plan->kernel = 1;
@@ -133,7 +163,8 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
     if (!plan) return fail(FA_ERR_NULL_POINTER, "null plan pointer");
     const void* const ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
     const int64_t* const strides[4] = {nullptr, nullptr, nullptr, nullptr};
-    return make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_kernel_ok(D, dtype, ptrs, strides), plan);
+    // (the packed op has softmax scale 1: f16 keeps the per-tile row max, bf16 runs the skip-max arithmetic)
+    return make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_kernel_ok(D, dtype, ptrs, strides), dtype == FA_DTYPE_BF16, plan, nullptr);
 }
 
 int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
@@ -158,7 +189,12 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     bool tile_ok = tile_kernel_ok(D, dtype, ptrs, strides);
     // the MFMA kernel addresses K/V rows with 32-bit element offsets from the group base
     if (tile_ok && (L * k_strides[2] >= (1ll << 31) || L * v_strides[2] >= (1ll << 31))) tile_ok = false;
-    int rc = make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_ok, &plan);
+    // f16 skip-max pays off when logits are small against the 2^15 headroom of f16 P: a softmax scale
+    // <= 0.25 means 1/sqrt(D)-style scaled attention (D >= 16); the packed op (scale 1) keeps the row max
+    int skipmax = softmax_scale <= 0.25f ? 1 : 0;
+    if (const char* sm = getenv("FA_AMD_SKIPMAX")) skipmax = atoi(sm);
+    KernelChoice kc{'d', 1};
+    int rc = make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_ok, dtype == FA_DTYPE_BF16 || skipmax != 0, &plan, &kc);
     if (rc != FA_OK) return rc;
 
     fa::FwdParams p;
@@ -172,7 +208,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     p.H = (int32_t)heads;
     p.L = (int32_t)L;
     p.D = (int32_t)D;
-    p.nq_tiles = plan.kernel == 0 ? (int32_t)((L + plan.block_q - 1) / plan.block_q) : 0;
+    p.nq_tiles = plan.kernel != 1 ? (int32_t)((L + plan.block_q - 1) / plan.block_q) : 0;
     // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
     // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
     {
@@ -187,22 +223,11 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     }
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    // f16 skip-max pays off when logits are small against the 2^15 headroom of f16 P: a softmax scale
-    // <= 0.25 means 1/sqrt(D)-style scaled attention (D >= 16); the packed op (scale 1) keeps the row max
-    p.skipmax = softmax_scale <= 0.25f ? 1 : 0;
-    if (const char* sm = getenv("FA_AMD_SKIPMAX")) p.skipmax = atoi(sm);
-
-    // MFMA kernels: "dma" (LDS-DMA staged, default: 1.13-1.15x the register-staged one on every shape
-    // measured) or "tile" (register-staged; FA_AMD_KERNEL=tile selects it for A/B runs)
-    char which = 'd';
-    const char* kv = getenv("FA_AMD_KERNEL");
-    if (kv && (kv[0] == 't' || kv[0] == 'd' || kv[0] == 'p')) which = kv[0];
-    // "pipe": software-pipelined 32-key steps; skip-max arithmetic only, at most 4 waves
-    if (which == 'p' && !(plan.waves <= 4 && (dtype == FA_DTYPE_BF16 || p.skipmax))) which = 'd';
-    hipError_t e = plan.kernel != 0 ? fa::launch_fwd_generic(p, dtype, (hipStream_t)stream)
-                   : which == 'p'   ? fa::launch_fwd_pipe(p, dtype, plan.waves, (hipStream_t)stream)
-                   : which == 'd'   ? fa::launch_fwd_dma(p, dtype, plan.waves, (hipStream_t)stream)
-                                    : fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream);
+    p.skipmax = skipmax;
+    hipError_t e = plan.kernel == 1    ? fa::launch_fwd_generic(p, dtype, (hipStream_t)stream)
+                   : kc.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, kc.qb, (hipStream_t)stream)
+                   : kc.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves, kc.qb, (hipStream_t)stream)
+                                     : fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
 }

@@ -3,6 +3,7 @@
 #define FA_DEVICE_H
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "fa_params.h"
@@ -111,4 +112,13 @@ __device__ __forceinline__ unsigned lds_offset(const void* p) {
 constexpr float RESCALE_THR = 8.0f;
 
 }  // namespace fa
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) - indices usable in `if constexpr`
+template <int B, int E, typename F>
+__device__ __forceinline__ void fa_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        fa_static_for<B + 1, E>(f);
+    }
+}
+
 #endif

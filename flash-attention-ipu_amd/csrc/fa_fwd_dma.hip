@@ -29,12 +29,13 @@ namespace fa {
 
 // (the body lives in a __device__ function: the buffer/LDS-DMA builtins do not exist for the host pass,
 // and a __global__ template that names them loses its host-side launch stub)
-template <typename T, int D, int NWAVES, bool SKIP>
+template <typename T, int D, int NWAVES, bool SKIP, int QB>
 __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
-    constexpr int BQ = NWAVES * 32;
+    constexpr int WQ = 32 * QB;                 // query rows per wave: QB blocks of 32 sharing every K/V operand read
+    constexpr int BQ = NWAVES * WQ;
     constexpr int BK = 64;
     constexpr int ROWB = D * 2;
     constexpr int KTILE_B = BK * ROWB;
@@ -75,16 +76,17 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
     const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
 
-    const int q_row0 = qi * BQ + wave * 32;
-    const int qrow = q_row0 + r;
+    const int q_row0 = qi * BQ + wave * WQ;
+    const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
     const bool wave_active = q_row0 < L;
 
-    vec8 qf[KS];
-    {
-        const int qr = qrow < L ? qrow : L - 1;
+    vec8 qf[QB][KS];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qr = qrow + 32 * b < L ? qrow + 32 * b : L - 1;
         const T* qp = qg + (int64_t)qr * p.q_sl + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const vec8*)(qp + 16 * ks);
+        for (int ks = 0; ks < KS; ++ks) qf[b][ks] = *(const vec8*)(qp + 16 * ks);
     }
 
     // ---- LDS-DMA geometry: piece pc = wave + j*NWAVES of a tile, lane -> source byte offset
@@ -135,13 +137,17 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
     const int n_tiles = (kv_end + BK - 1) / BK;
 
-    f32x16 o[DT];
+    f32x16 o[QB][DT];
+    float m[QB], l[QB];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int b = 0; b < QB; ++b) {
+        m[b] = -INFINITY;
+        l[b] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-    float m = -INFINITY;
-    float l = 0.f;
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[b][dt][e] = 0.f;
+    }
     const float c = p.scale_log2;
     // bf16 P keeps the fp32 exponent range, so the reference max may lag by 2^60 before a tile has to be
     // redone.  f16 P must stay below 65504 (limit 2^15): on unscaled logits (std sqrt(D)) the redo fires
@@ -155,58 +161,65 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #define FA_QK(BUF_)                                                                                \
     {                                                                                              \
         const unsigned char* kb_ = smem + (BUF_) * KTILE_B;                                        \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }               \
+        _Pragma("unroll") for (int b = 0; b < QB; ++b)                                             \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[b][e] = 0.f; s1[b][e] = 0.f; }     \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                        \
             const vec8 k0 = *(const vec8*)(kb_ + k_rd[ks]);                                        \
             const vec8 k1 = *(const vec8*)(kb_ + 32 * ROWB + k_rd[ks]);                            \
-            s0 = E::mfma(k0, qf[ks], s0);                                                          \
-            s1 = E::mfma(k1, qf[ks], s1);                                                          \
+            _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                       \
+                s0[b] = E::mfma(k0, qf[b][ks], s0[b]);                                             \
+                s1[b] = E::mfma(k1, qf[b][ks], s1[b]);                                             \
+            }                                                                                      \
         }                                                                                          \
-        if (kv0 + BK - 1 > q_row0) { /* the wave's diagonal tile */                                \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                       \
-                const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;                              \
-                if (key > qrow) s0[e] = -INFINITY;                                                 \
-                if (key + 32 > qrow) s1[e] = -INFINITY;                                            \
+        if (kv0 + BK - 1 > q_row0) { /* a diagonal tile of the wave */                             \
+            _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                       \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                   \
+                    const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;                          \
+                    if (key > qrow + 32 * b) s0[b][e] = -INFINITY;                                 \
+                    if (key + 32 > qrow + 32 * b) s1[b][e] = -INFINITY;                            \
+                }                                                                                  \
             }                                                                                      \
         }                                                                                          \
     }
     // row max of the tile, then raise the reference max m (rescaling O and l) where it is outgrown by
     // more than THR_ (log2 units); decided BEFORE the tile's P is formed
 #define FA_MAX_RESCALE(THR_)                                                                       \
-    {                                                                                              \
-        float mx = max2(s0[0], s1[0]);                                                             \
-        _Pragma("unroll") for (int e = 1; e < 16; ++e) mx = max3(mx, s0[e], s1[e]);                \
+    _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
+        float mx = max2(s0[b][0], s1[b][0]);                                                       \
+        _Pragma("unroll") for (int e = 1; e < 16; ++e) mx = max3(mx, s0[b][e], s1[b][e]);          \
         mx = half_swap_max(mx);                                                                    \
-        if (__builtin_amdgcn_ballot_w64((mx - m) * c > (THR_)) != 0) {                             \
-            const float m_new = max2(m, mx);                                                       \
-            const float alpha = fast_exp2((m - m_new) * c);                                        \
-            m = m_new;                                                                             \
-            l *= alpha;                                                                            \
+        if (__builtin_amdgcn_ballot_w64((mx - m[b]) * c > (THR_)) != 0) {                          \
+            const float m_new = max2(m[b], mx);                                                    \
+            const float alpha = fast_exp2((m[b] - m_new) * c);                                     \
+            m[b] = m_new;                                                                          \
+            l[b] *= alpha;                                                                         \
             _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                      \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;                  \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) o[b][dt][e] *= alpha;               \
         }                                                                                          \
     }
     // P = 2^(s*c - m*c) in place, ls = this lane's part of the row sum
 #define FA_SOFTMAX()                                                                               \
-    {                                                                                              \
-        const float mc = m * c;                                                                    \
-        ls = 0.f;                                                                                  \
+    _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
+        const float mc = m[b] * c;                                                                 \
+        ls[b] = 0.f;                                                                               \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                           \
-            s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -mc));                                      \
-            s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -mc));                                      \
-            ls += s0[e];                                                                           \
-            ls += s1[e];                                                                           \
+            s0[b][e] = fast_exp2(__builtin_fmaf(s0[b][e], c, -mc));                                \
+            s1[b][e] = fast_exp2(__builtin_fmaf(s1[b][e], c, -mc));                                \
+            ls[b] += s0[b][e];                                                                     \
+            ls[b] += s1[b][e];                                                                     \
         }                                                                                          \
     }
 #define FA_PV(BUF_)                                                                                \
     {                                                                                              \
         const unsigned char* vb_ = smem_v + (BUF_) * VTILE_B;                                      \
-        vec8 pf[4];                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
-            pf[0][j] = (T)s0[j];                                                                   \
-            pf[1][j] = (T)s0[8 + j];                                                               \
-            pf[2][j] = (T)s1[j];                                                                   \
-            pf[3][j] = (T)s1[8 + j];                                                               \
+        vec8 pf[QB][4];                                                                            \
+        _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                           \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
+                pf[b][0][j] = (T)s0[b][j];                                                         \
+                pf[b][1][j] = (T)s0[b][8 + j];                                                     \
+                pf[b][2][j] = (T)s1[b][j];                                                         \
+                pf[b][3][j] = (T)s1[b][8 + j];                                                     \
+            }                                                                                      \
         }                                                                                          \
         _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                        \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                     \
@@ -216,16 +229,17 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                 const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
                     (i16x4 __attribute__((address_space(3)))*)(vp + 512));                         \
                 const i16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);          \
-                o[dt] = E::mfma(__builtin_bit_cast(vec8, v8), pf[kk], o[dt]);                      \
+                _Pragma("unroll") for (int b = 0; b < QB; ++b)                                     \
+                    o[b][dt] = E::mfma(__builtin_bit_cast(vec8, v8), pf[b][kk], o[b][dt]);         \
             }                                                                                      \
         }                                                                                          \
     }
 #define FA_COMPUTE(T_, BUF_)                                                                       \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
-        if (wave_active && kv0 <= q_row0 + 31) {                                                   \
-            f32x16 s0, s1;                                                                         \
-            float ls;                                                                              \
+        if (wave_active && kv0 <= q_row0 + WQ - 1) {                                               \
+            f32x16 s0[QB], s1[QB];                                                                 \
+            float ls[QB];                                                                          \
             FA_QK(BUF_)                                                                            \
             if (SKIPMAX) {                                                                         \
                 if (kv0 == 0) FA_MAX_RESCALE(0.0f)       /* first tile: m = -inf -> exact max */    \
@@ -233,7 +247,9 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                 /* (the fences keep hipcc from hoisting the PV operand reads above the rare branch, \
                    which costs 26 VGPRs and a wave per SIMD) */                                    \
                 asm volatile("" ::: "memory");                                                     \
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(ls > P_LIMIT) != 0, 0)) {         \
+                bool over_ = ls[0] > P_LIMIT;                                                      \
+                _Pragma("unroll") for (int b = 1; b < QB; ++b) over_ |= ls[b] > P_LIMIT;           \
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(over_) != 0, 0)) {                \
                     FA_QK(BUF_)                                                                    \
                     FA_MAX_RESCALE(0.0f)                                                           \
                     FA_SOFTMAX()                                                                   \
@@ -243,7 +259,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                 FA_MAX_RESCALE(RESCALE_THR)                                                        \
                 FA_SOFTMAX()                                                                       \
             }                                                                                      \
-            l += ls;                                                                               \
+            _Pragma("unroll") for (int b = 0; b < QB; ++b) l[b] += ls[b];                          \
             FA_PV(BUF_)                                                                            \
         }                                                                                          \
     }
@@ -251,7 +267,9 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     FA_DMA_TILE(0, 0)
     FA_TILE_BARRIER()
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q landed (see fa_fwd_tile_kernel)
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int b = 0; b < QB; ++b) asm volatile("" : "+v"(qf[b][ks]));   // Q landed (see fa_fwd_tile_kernel)
 
     for (int t = 0; t < n_tiles; t += 2) {
         if (t + 1 < n_tiles) FA_DMA_TILE(t + 1, 1)
@@ -277,57 +295,71 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // 32-row slab [32][D] with the 16-byte chunk index XORed by the row, so writes and reads are
     // conflict-free and no workgroup barrier is needed.
     if (!wave_active) return;
-    const float lt = half_swap_sum(l);
-    const float inv = __builtin_amdgcn_rcpf(lt);
     unsigned char* slab = smem + wave * (32 * ROWB);
     constexpr int CPR = D / 8;   // 16-byte chunks per row
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            vec4 w;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = (T)(o[dt][4 * rg + j] * inv);
-            const int ch = 4 * dt + rg;                                   // chunk holding d = 32dt + 8rg + 4h ..+3
-            *(vec4*)(slab + r * ROWB + ((ch ^ (r & (CPR - 1))) << 4) + 8 * h) = w;
-        }
-    }
-    if (p.lse != nullptr && h == 0 && qrow < L) p.lse[(int64_t)g * L + qrow] = m * p.scale + __logf(lt);
-    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
     constexpr int RPI = 64 / CPR;   // rows per store instruction (8 at D=64, 4 at D=128)
+    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
 #pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
-        const int rr = i * RPI + lane / CPR, ch = lane % CPR;
-        const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
-        if (q_row0 + rr < L) *(u32x4*)(og + (int64_t)(q_row0 + rr) * p.o_sl + ch * 8) = val;
+    for (int b = 0; b < QB; ++b) {
+        const float lt = half_swap_sum(l[b]);
+        const float inv = __builtin_amdgcn_rcpf(lt);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                vec4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (T)(o[b][dt][4 * rg + j] * inv);
+                const int ch = 4 * dt + rg;                                   // chunk holding d = 32dt + 8rg + 4h ..+3
+                *(vec4*)(slab + r * ROWB + ((ch ^ (r & (CPR - 1))) << 4) + 8 * h) = w;
+            }
+        }
+        const int row_b = qrow + 32 * b;
+        if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * p.scale + __logf(lt);
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int rr = i * RPI + lane / CPR, ch = lane % CPR;
+            const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
+            const int orow = q_row0 + 32 * b + rr;
+            if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
+        }
     }
 }
 
-template <typename T, int D, int NWAVES, bool SKIP>
+template <typename T, int D, int NWAVES, bool SKIP, int QB>
 __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_dma_kernel(const FwdParams p) {
-    fa_fwd_dma_body<T, D, NWAVES, SKIP>(p);
+    fa_fwd_dma_body<T, D, NWAVES, SKIP, QB>(p);
 }
 
 template <typename T, int D, bool SKIP>
-static hipError_t launch_dma_w(const FwdParams& p, int waves, hipStream_t stream) {
+static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, hipStream_t stream) {
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
+    if (qb == 2) {   // 64 query rows per wave (head_dim 64, 4 waves): half the LDS operand reads and half the K/V DMA per FLOP
+        if constexpr (D == 64) {
+            hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 4, SKIP, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     switch (waves) {
-        case 8: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 8, SKIP>), dim3((unsigned)grid), dim3(512), 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 4, SKIP>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 2, SKIP>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
-        default: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 1, SKIP>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
+        case 8: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 8, SKIP, 1>), dim3((unsigned)grid), dim3(512), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 4, SKIP, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 2, SKIP, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
+        default: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 1, SKIP, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
+// qb = 32-row query blocks per wave (1, or 2 for head_dim 64 with 4 waves; the host sized p.nq_tiles for it)
+hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream) {
     if (dtype == 1) {   // bf16: always skip-max
-        return p.D == 64 ? launch_dma_w<__bf16, 64, true>(p, waves, stream) : launch_dma_w<__bf16, 128, true>(p, waves, stream);
+        return p.D == 64 ? launch_dma_w<__bf16, 64, true>(p, waves, qb, stream) : launch_dma_w<__bf16, 128, true>(p, waves, qb, stream);
     }
     if (p.skipmax) {
-        return p.D == 64 ? launch_dma_w<_Float16, 64, true>(p, waves, stream) : launch_dma_w<_Float16, 128, true>(p, waves, stream);
+        return p.D == 64 ? launch_dma_w<_Float16, 64, true>(p, waves, qb, stream) : launch_dma_w<_Float16, 128, true>(p, waves, qb, stream);
     }
-    return p.D == 64 ? launch_dma_w<_Float16, 64, false>(p, waves, stream) : launch_dma_w<_Float16, 128, false>(p, waves, stream);
+    return p.D == 64 ? launch_dma_w<_Float16, 64, false>(p, waves, qb, stream) : launch_dma_w<_Float16, 128, false>(p, waves, qb, stream);
 }
 
 }  // namespace fa

@@ -20,6 +20,13 @@
 // slots; step i reads K(i+1), V(i-1) (and K(i) if it has to redo), while the DMA fills K(i+3) and V(i+2).
 // One workgroup barrier per step; the DMA issued in a step may stay in flight across that step's barrier
 // (s_waitcnt vmcnt(2*PPW)), so a slot has two full steps to land.
+//
+// QB = 32-row query blocks per wave.  With QB = 2 (head_dim 64) a wave owns 64 query rows and every K row /
+// V^T fragment it reads from LDS feeds two MFMAs, and a workgroup of 4 waves covers 256 rows per streamed K/V
+// step: half the LDS operand traffic and half the L2->LDS DMA traffic per FLOP.  That matters because this
+// kernel is POWER-bound, not issue-bound: scripts/microbench/clock_under_load.hip shows the device holding
+// only ~1.7 GHz (of 2.4) while it runs; energy per FLOP, not instruction slots, sets the speed.  Two blocks
+// double the accumulators, so 2 waves per SIMD - which the in-wave pipelining makes sufficient.
 
 #include "fa_device.h"
 
@@ -39,12 +46,13 @@
 
 namespace fa {
 
-template <typename T, int D, int NWAVES>
+template <typename T, int D, int NWAVES, int QB>
 __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
-    constexpr int BQ = NWAVES * 32;
+    constexpr int WQ = 32 * QB;                 // query rows per wave
+    constexpr int BQ = NWAVES * WQ;
     constexpr int HK = 32;                      // keys per step
     constexpr int ROWB = D * 2;
     constexpr int KH_B = HK * ROWB;             // K slot
@@ -86,16 +94,17 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
     const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
 
-    const int q_row0 = qi * BQ + wave * 32;
-    const int qrow = q_row0 + r;
+    const int q_row0 = qi * BQ + wave * WQ;
+    const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
     const bool wave_active = q_row0 < L;
 
-    vec8 qf[KS];
-    {
-        const int qr = qrow < L ? qrow : L - 1;
+    vec8 qf[QB][KS];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qr = qrow + 32 * b < L ? qrow + 32 * b : L - 1;
         const T* qp = qg + (int64_t)qr * p.q_sl + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const vec8*)(qp + 16 * ks);
+        for (int ks = 0; ks < KS; ++ks) qf[b][ks] = *(const vec8*)(qp + 16 * ks);
     }
 
     // ---- LDS-DMA geometry (as fa_fwd_dma_kernel, for 32-key slots)
@@ -144,27 +153,36 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 
     const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
     const int nh_wg = (kv_end + HK - 1) / HK;                 // steps the workgroup streams
-    const int nh_w = wave_active ? q_row0 / HK + 1 : 0;       // steps this wave computes (last = diagonal)
+    // steps this wave computes: block b's diagonal step is q_row0/32 + b, so the last QB steps carry a mask
+    // (a block whose rows all lie before a step's keys gets P = 0 there)
+    const int nh_w = wave_active ? q_row0 / HK + QB : 0;
 
-    f32x16 o[DT];
+    f32x16 o[QB][DT];
+    float m[QB], l[QB];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int b = 0; b < QB; ++b) {
+        m[b] = -INFINITY;
+        l[b] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-    float m = -INFINITY;
-    float l = 0.f;
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[b][dt][e] = 0.f;
+    }
     const float c = p.scale_log2;
     constexpr float P_LIMIT = E::is_f16 ? 32768.0f : 1152921504606846976.0f;   // 2^15 | 2^60
 
-    // S = K(slot) Q^T for one 32-key step
+    // S[b] = K(slot) Q_b^T for one 32-key step (every K row read feeds all blocks)
 #define FA_QK_H(S_, SLOT_)                                                                         \
     {                                                                                              \
         const unsigned char* kb_ = smem + (SLOT_) * KH_B;                                          \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) S_[e] = 0.f;                                \
-        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                          \
-            S_ = E::mfma(*(const vec8*)(kb_ + k_rd[ks]), qf[ks], S_);                              \
+        _Pragma("unroll") for (int b = 0; b < QB; ++b)                                             \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) S_[b][e] = 0.f;                         \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                        \
+            const vec8 kf_ = *(const vec8*)(kb_ + k_rd[ks]);                                       \
+            _Pragma("unroll") for (int b = 0; b < QB; ++b) S_[b] = E::mfma(kf_, qf[b][ks], S_[b]); \
+        }                                                                                          \
     }
-    // O^T += V(slot)^T P^T
+    // O_b^T += V(slot)^T P_b^T
 #define FA_PV_H(P_, SLOT_)                                                                         \
     {                                                                                              \
         const unsigned char* vb_ = smem_v + (SLOT_) * VH_B;                                        \
@@ -176,46 +194,48 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
                     (i16x4 __attribute__((address_space(3)))*)(vp + 512));                         \
                 const i16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);          \
-                o[dt] = E::mfma(__builtin_bit_cast(vec8, v8), P_[kk], o[dt]);                      \
+                _Pragma("unroll") for (int b = 0; b < QB; ++b)                                     \
+                    o[b][dt] = E::mfma(__builtin_bit_cast(vec8, v8), P_[b][kk], o[b][dt]);         \
             }                                                                                      \
         }                                                                                          \
     }
 #define FA_MASK_H(S_, J_)                                                                          \
-    {                                                                                              \
+    _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                           \
             const int key = (J_) * HK + (e & 3) + 8 * (e >> 2) + 4 * h;                            \
-            if (key > qrow) S_[e] = -INFINITY;                                                     \
+            if (key > qrow + 32 * b) S_[b][e] = -INFINITY;                                         \
         }                                                                                          \
     }
-    // exact row max of the step; raise m (rescaling O and l) wherever it is exceeded
+    // exact row max of the step; raise m (rescaling O and l) wherever it is exceeded.  (A fully masked block -
+    // block 0 in the wave's last step when QB = 2 - has mx = -inf and keeps its m.)
 #define FA_MAXR_H(S_)                                                                              \
-    {                                                                                              \
-        float mx = max2(S_[0], S_[1]);                                                             \
-        _Pragma("unroll") for (int e = 2; e < 16; e += 2) mx = max3(mx, S_[e], S_[e + 1]);         \
+    _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
+        float mx = max2(S_[b][0], S_[b][1]);                                                       \
+        _Pragma("unroll") for (int e = 2; e < 16; e += 2) mx = max3(mx, S_[b][e], S_[b][e + 1]);   \
         mx = half_swap_max(mx);                                                                    \
-        if (__builtin_amdgcn_ballot_w64((mx - m) * c > 0.0f) != 0) {                               \
-            const float m_new = max2(m, mx);                                                       \
-            const float alpha = fast_exp2((m - m_new) * c);                                        \
-            m = m_new;                                                                             \
-            l *= alpha;                                                                            \
+        if (__builtin_amdgcn_ballot_w64((mx - m[b]) * c > 0.0f) != 0) {                            \
+            const float m_new = max2(m[b], mx);                                                    \
+            const float alpha = fast_exp2((m[b] - m_new) * c);                                     \
+            m[b] = m_new;                                                                          \
+            l[b] *= alpha;                                                                         \
             _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                      \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;                  \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) o[b][dt][e] *= alpha;               \
         }                                                                                          \
     }
 #define FA_SM_H(S_)                                                                                \
-    {                                                                                              \
-        const float mc = m * c;                                                                    \
-        ls = 0.f;                                                                                  \
+    _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
+        const float mc = m[b] * c;                                                                 \
+        ls[b] = 0.f;                                                                               \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                           \
-            S_[e] = fast_exp2(__builtin_fmaf(S_[e], c, -mc));                                      \
-            ls += S_[e];                                                                           \
+            S_[b][e] = fast_exp2(__builtin_fmaf(S_[b][e], c, -mc));                                \
+            ls[b] += S_[b][e];                                                                     \
         }                                                                                          \
     }
 #define FA_PACK_H(P_, S_)                                                                          \
-    {                                                                                              \
+    _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
-            P_[0][j] = (T)S_[j];                                                                   \
-            P_[1][j] = (T)S_[8 + j];                                                               \
+            P_[b][0][j] = (T)S_[b][j];                                                             \
+            P_[b][1][j] = (T)S_[b][8 + j];                                                         \
         }                                                                                          \
     }
     // every step: issue the DMA for K(i+3), V(i+2); compute; publish (everything issued before this step has
@@ -231,74 +251,116 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // steady-state step I_ (ring index R_ = I_ & 3 at compile time): S(I_) is in SC_, SN_ receives S(I_+1),
     // PP_ holds P(I_-1), PC_ receives P(I_); no mask, all three stages, no branch: a P that outgrew the safe
     // range only raises `bad` (any rare path in here costs phi copies of the accumulators on every step).
-    // The instruction order is written out by hand and frozen with sched_barrier(0): NM = KS + 2 DT MFMAs
-    // (S(I_+1) first - the next step's vector work needs it first - then O += V P), each followed by its share
-    // of the softmax of S(I_): score pair p (two registers -> one packed dword of P) goes fma -> exp -> add,
-    // cvt, skewed over three groups so that nothing waits for the transcendental unit; LDS operands are
-    // requested FA_PIPE_PF MFMAs ahead.
-#define FA_OPND_LOAD(IDX_)                                                                         \
-        if ((IDX_) < KS) {                                                                         \
-            opnd[(IDX_)] = *(const vec8*)(kb_ + k_rd[(IDX_) < KS ? (IDX_) : 0]);                   \
+    // The instruction order is written out by hand and frozen with sched_barrier(0): NM = KS + 2 DT LDS
+    // operands (K rows first - the next step's vector work needs S(I_+1) first - then V^T fragments), each
+    // feeding QB MFMAs, each MFMA followed by its share of the softmax of S(I_): score pair p of block b (two
+    // registers -> one packed dword of P) goes fma -> exp -> add, cvt, skewed over three groups so that nothing
+    // waits for the transcendental unit; LDS operands are requested FA_PIPE_PF operands ahead.
+#define FA_OPND_LOAD(X_, NK_)                                                                      \
+        if constexpr ((X_) < (NK_)) {                                                              \
+            opnd[(X_)] = *(const vec8*)(kb_ + k_rd[(X_) < KS ? (X_) : 0]);                         \
         } else {                                                                                   \
-            const int t_ = (IDX_) - KS;                                                            \
+            constexpr int t_ = (X_) - (NK_);                                                       \
             const unsigned char* vp = vb_ + (t_ % DT) * VBLK_B + (t_ / DT) * 1024 + v_rd;          \
             const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                              \
                 (i16x4 __attribute__((address_space(3)))*)(vp));                                   \
             const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                              \
                 (i16x4 __attribute__((address_space(3)))*)(vp + 512));                             \
-            opnd[(IDX_)] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); \
+            opnd[(X_)] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); \
         }
-#define FA_PAIR_FMA(SC_, P_) { SC_[2 * (P_)] = __builtin_fmaf(SC_[2 * (P_)], c, -mc); SC_[2 * (P_) + 1] = __builtin_fmaf(SC_[2 * (P_) + 1], c, -mc); }
-#define FA_PAIR_EXP(SC_, P_) { SC_[2 * (P_)] = fast_exp2(SC_[2 * (P_)]); SC_[2 * (P_) + 1] = fast_exp2(SC_[2 * (P_) + 1]); }
-#define FA_PAIR_SUM(SC_, PC_, P_)                                                                  \
+    // vector work item V_ (0 .. 8 QB - 1) = score pair V_ % 8 of block V_ / 8
+#define FA_ITEM_FMA(SC_, V_, MASK_)                                                                \
         {                                                                                          \
-            ls += SC_[2 * (P_)];                                                                   \
-            ls += SC_[2 * (P_) + 1];                                                               \
-            PC_[(P_) >> 2][2 * ((P_) & 3)] = (T)SC_[2 * (P_)];                                     \
-            PC_[(P_) >> 2][2 * ((P_) & 3) + 1] = (T)SC_[2 * (P_) + 1];                             \
+            constexpr int b_ = (V_) / 8, e_ = 2 * ((V_) % 8);                                      \
+            if constexpr (MASK_) {   /* key of element e: (e & 3) + 8 (e >> 2) + 4 h within the step */ \
+                const int key_ = key0_ + (e_ & 3) + 8 * (e_ >> 2);                                 \
+                if (key_ > qrow + 32 * b_) SC_[b_][e_] = -INFINITY;                                \
+                if (key_ + 1 > qrow + 32 * b_) SC_[b_][e_ + 1] = -INFINITY;                        \
+            }                                                                                      \
+            SC_[b_][e_] = __builtin_fmaf(SC_[b_][e_], c, -mc[b_]);                                 \
+            SC_[b_][e_ + 1] = __builtin_fmaf(SC_[b_][e_ + 1], c, -mc[b_]);                         \
         }
-#define FA_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                      \
+#define FA_ITEM_EXP(SC_, V_)                                                                       \
+        {                                                                                          \
+            constexpr int b_ = (V_) / 8, e_ = 2 * ((V_) % 8);                                      \
+            SC_[b_][e_] = fast_exp2(SC_[b_][e_]);                                                  \
+            SC_[b_][e_ + 1] = fast_exp2(SC_[b_][e_ + 1]);                                          \
+        }
+#define FA_ITEM_SUM(SC_, PC_, V_)                                                                  \
+        {                                                                                          \
+            constexpr int b_ = (V_) / 8, p_ = (V_) % 8, e_ = 2 * p_;                               \
+            ls[b_] += SC_[b_][e_];                                                                 \
+            ls[b_] += SC_[b_][e_ + 1];                                                             \
+            PC_[b_][p_ >> 2][2 * (p_ & 3)] = (T)SC_[b_][e_];                                       \
+            PC_[b_][p_ >> 2][2 * (p_ & 3) + 1] = (T)SC_[b_][e_ + 1];                               \
+        }
+    // KN_ / VP_ / KI_ / VI_: ring slots of K(I_+1), V(I_-1) and of the DMA targets K(I_+3), V(I_+2) - compile-time
+    // constants in the 4-step groups, i-dependent values in the ragged steps; MASK_: causal mask on S(I_)
+    // (the wave's last QB steps; also used, harmlessly, for the <= 3 steps the groups of four leave over);
+    // QK_: a next step exists
+#define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_)                             \
     {                                                                                              \
-        FA_ISSUE(I_, ((R_) + 3) & 3, ((R_) + 2) & 3)                                               \
-        constexpr int NM = KS + 2 * DT, STRIDE = NM / 8;                                           \
-        const unsigned char* kb_ = smem + (((R_) + 1) & 3) * KH_B;                                 \
-        const unsigned char* vb_ = smem_v + (((R_) + 3) & 3) * VH_B;                               \
+        FA_ISSUE(I_, KI_, VI_)                                                                     \
+        constexpr int NK = (QK_) ? KS : 0, NM = NK + 2 * DT, NMF = NM * QB, NV = 8 * QB;           \
+        constexpr int PF_ = FA_PIPE_PF < NM ? FA_PIPE_PF : NM;                                     \
+        const unsigned char* kb_ = smem + (KN_) * KH_B;                                            \
+        const unsigned char* vb_ = smem_v + (VP_) * VH_B;                                          \
+        const int key0_ = (I_) * HK + 4 * h;                                                       \
+        (void)kb_; (void)key0_;                                                                    \
         vec8 opnd[NM];                                                                             \
-        _Pragma("unroll") for (int x_ = 0; x_ < FA_PIPE_PF; ++x_) { FA_OPND_LOAD(x_) }             \
-        const float mc = m * c;                                                                    \
-        float ls = 0.f;                                                                            \
-        FA_PAIR_FMA(SC_, 0)                                                                        \
-        FA_PAIR_EXP(SC_, 0)                                                                        \
-        FA_PAIR_FMA(SC_, 1)                                                                        \
+        fa_static_for<0, PF_>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; FA_OPND_LOAD(x_, NK) }); \
+        float mc[QB], ls[QB];                                                                      \
+        _Pragma("unroll") for (int b = 0; b < QB; ++b) { mc[b] = m[b] * c; ls[b] = 0.f; }          \
+        FA_ITEM_FMA(SC_, 0, MASK_)                                                                 \
+        FA_ITEM_EXP(SC_, 0)                                                                        \
+        FA_ITEM_FMA(SC_, 1, MASK_)                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        _Pragma("unroll") for (int g_ = 0; g_ < NM; ++g_) {                                        \
-            if (g_ < KS) {                                                                         \
-                if (g_ == 0) {                                                                     \
+        fa_static_for<0, NMF>([&](auto gi_) {                                                      \
+            constexpr int n_ = decltype(gi_)::value, g_ = n_ / QB, b_ = n_ % QB;                   \
+            if constexpr (g_ < NK) {                                                               \
+                if constexpr (g_ == 0) {                                                           \
                     f32x16 z_;                                                                     \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) z_[e] = 0.f;                    \
-                    SN_ = E::mfma(opnd[g_], qf[g_ < KS ? g_ : 0], z_);                             \
+                    SN_[b_] = E::mfma(opnd[g_], qf[b_][g_ < KS ? g_ : 0], z_);                     \
                 } else {                                                                           \
-                    SN_ = E::mfma(opnd[g_], qf[g_ < KS ? g_ : 0], SN_);                            \
+                    SN_[b_] = E::mfma(opnd[g_], qf[b_][g_ < KS ? g_ : 0], SN_[b_]);                \
                 }                                                                                  \
             } else {                                                                               \
-                o[(g_ - KS) % DT] = E::mfma(opnd[g_], PP_[(g_ < KS ? 0 : g_ - KS) / DT], o[(g_ - KS) % DT]); \
+                constexpr int t_ = g_ - NK;                                                        \
+                o[b_][t_ % DT] = E::mfma(opnd[g_], PP_[b_][t_ / DT], o[b_][t_ % DT]);              \
             }                                                                                      \
-            if (g_ + FA_PIPE_PF < NM) { FA_OPND_LOAD(g_ + FA_PIPE_PF) }                            \
-            if (g_ % STRIDE == 0) {                                                                \
-                const int pr_ = g_ / STRIDE;                                                       \
-                if (pr_ + 1 < 8) { FA_PAIR_EXP(SC_, (pr_ + 1 < 8 ? pr_ + 1 : 0)) }                  \
-                FA_PAIR_SUM(SC_, PC_, pr_)                                                         \
-                if (pr_ + 2 < 8) { FA_PAIR_FMA(SC_, (pr_ + 2 < 8 ? pr_ + 2 : 0)) }                  \
-            }                                                                                      \
+            if constexpr (b_ == QB - 1 && g_ + PF_ < NM) { FA_OPND_LOAD(g_ + PF_, NK) }            \
+            /* this MFMA's share of the vector work items */                                      \
+            fa_static_for<(n_ * NV) / NMF, ((n_ + 1) * NV) / NMF>([&](auto vi_) {                  \
+                constexpr int v_ = decltype(vi_)::value;                                           \
+                if constexpr (v_ + 1 < NV) { FA_ITEM_EXP(SC_, v_ + 1) }                            \
+                FA_ITEM_SUM(SC_, PC_, v_)                                                          \
+                if constexpr (v_ + 2 < NV) { FA_ITEM_FMA(SC_, v_ + 2, MASK_) }                     \
+            });                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                     \
+        });                                                                                        \
+        _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                           \
+            bad |= !(ls[b] <= P_LIMIT);                                                            \
+            l[b] += ls[b];                                                                         \
+            /* pin this step's vector work to this step (hipcc otherwise sinks it below the       \
+               barrier, in front of the PV that needs it) */                                      \
+            asm volatile("" : "+v"(PC_[b][0]), "+v"(PC_[b][1]), "+v"(l[b]));                       \
         }                                                                                          \
-        bad |= !(ls <= P_LIMIT);                                                                   \
-        l += ls;                                                                                   \
-        /* pin this step's vector work to this step (hipcc otherwise sinks it below the barrier,  \
-           in front of the PV that needs it) */                                                   \
-        asm volatile("" : "+v"(PC_[0]), "+v"(PC_[1]), "+v"(l));                                    \
         FA_PUBLISH()                                                                               \
     }
+#define FA_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                      \
+    FA_FAST(I_, ((R_) + 1) & 3, ((R_) + 3) & 3, ((R_) + 3) & 3, ((R_) + 2) & 3, SC_, SN_, PP_, PC_, false, true)
+    // The ragged steps and the generic steps after the groups of four use FIXED register roles (S(i) in sa,
+    // S(i+1) -> sb, P(i-1) in pb, P(i) -> pa) and rotate by copying afterwards: one instantiation each instead of
+    // one per parity (parity branches make hipcc shuffle the whole accumulator state through phi copies)
+#define FA_ROTATE()                                                                                \
+    _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
+        sa[b] = sb[b];                                                                             \
+        pb[b][0] = pa[b][0];                                                                       \
+        pb[b][1] = pa[b][1];                                                                       \
+    }
+#define FA_RAGGED(I_, QK_)                                                                         \
+    FA_FAST(I_, ((I_) + 1) & 3, ((I_) + 3) & 3, ((I_) + 3) & 3, ((I_) + 2) & 3, sa, sb, pb, pa, true, QK_)
     // generic step (runtime ring slots, compiler's own schedule): the first step, the up to three steps left
     // over by the groups of four, the diagonal step, the drain step and the idle steps of a finished wave.
     // SAFE_ = the fallback pass: a step whose P outgrew the safe range is redone with an exact max.
@@ -309,22 +371,24 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         if (i_ + 1 < nh_w) FA_QK_H(SN_, (i_ + 1) & 3)                                              \
         if (i_ >= 1 && i_ <= nh_w) FA_PV_H(PP_, (i_ + 3) & 3)                                      \
         if (i_ < nh_w) {                                                                           \
-            float ls;                                                                              \
-            const bool diag_ = i_ == nh_w - 1;                                                     \
+            float ls[QB];                                                                          \
+            const bool diag_ = i_ >= nh_w - QB;                                                    \
             if (diag_) FA_MASK_H(SC_, i_)                                                          \
             if (i_ == 0) FA_MAXR_H(SC_)                                                            \
             FA_SM_H(SC_)                                                                           \
+            bool over_ = false;                                                                    \
+            _Pragma("unroll") for (int b = 0; b < QB; ++b) over_ |= !(ls[b] <= P_LIMIT);           \
             if (SAFE_) {                                                                           \
-                if (__builtin_amdgcn_ballot_w64(!(ls <= P_LIMIT)) != 0) {                          \
+                if (__builtin_amdgcn_ballot_w64(over_) != 0) {                                     \
                     FA_QK_H(SC_, i_ & 3)                                                           \
                     if (diag_) FA_MASK_H(SC_, i_)                                                  \
                     FA_MAXR_H(SC_)                                                                 \
                     FA_SM_H(SC_)                                                                   \
                 }                                                                                  \
             } else {                                                                               \
-                bad |= !(ls <= P_LIMIT);                                                           \
+                bad |= over_;                                                                      \
             }                                                                                      \
-            l += ls;                                                                               \
+            _Pragma("unroll") for (int b = 0; b < QB; ++b) l[b] += ls[b];                          \
             FA_PACK_H(PC_, SC_)                                                                    \
         }                                                                                          \
         FA_PUBLISH()                                                                               \
@@ -347,27 +411,42 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         FA_GENERIC(0, sa, sb, pb, pa, SAFE_)                                                       \
         int i = 1;                                                                                 \
         if (!(SAFE_)) {                                                                            \
-            for (; i + 4 < nh_w; i += 4) {                                                         \
+            for (; i + 3 + QB < nh_w; i += 4) {       /* steps i .. i+3 carry no mask */           \
                 FA_STEADY(i, 1, sb, sa, pa, pb)                                                    \
                 FA_STEADY(i + 1, 2, sa, sb, pb, pa)                                                \
                 FA_STEADY(i + 2, 3, sb, sa, pa, pb)                                                \
                 FA_STEADY(i + 3, 0, sa, sb, pb, pa)                                                \
             }                                                                                      \
         }                                                                                          \
-        for (; i <= nh_wg; i += 2) {                                                               \
-            FA_GENERIC(i, sb, sa, pa, pb, SAFE_)                                                   \
-            if (i + 1 <= nh_wg) FA_GENERIC(i + 1, sa, sb, pb, pa, SAFE_)                           \
+        FA_ROTATE()                                            /* i is odd: S(i) sb -> sa, P(i-1) pa -> pb */ \
+        if (!(SAFE_)) {                                                                            \
+            for (; i + 1 < nh_w; ++i) {                        /* left-over and masked steps */    \
+                FA_RAGGED(i, true)                                                                 \
+                FA_ROTATE()                                                                        \
+            }                                                                                      \
+            if (i < nh_w) {                                    /* the wave's last step */          \
+                FA_RAGGED(i, false)                                                                \
+                FA_ROTATE()                                                                        \
+                ++i;                                                                               \
+            }                                                                                      \
+        }                                                                                          \
+        for (; i <= nh_wg; ++i) {                              /* drain, idle (and the safe pass) */ \
+            FA_GENERIC(i, sa, sb, pb, pa, SAFE_)                                                   \
+            FA_ROTATE()                                                                            \
         }                                                                                          \
     }
 
-    f32x16 sa, sb;
-    vec8 pa[2], pb[2];
+    f32x16 sa[QB], sb[QB];
+    vec8 pa[QB][2], pb[QB][2];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
+    for (int b = 0; b < QB; ++b) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { pa[0][j] = (T)0.f; pa[1][j] = (T)0.f; pb[0][j] = (T)0.f; pb[1][j] = (T)0.f; }
+        for (int e = 0; e < 16; ++e) { sa[b][e] = 0.f; sb[b][e] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q landed (see fa_fwd_tile_kernel)
+        for (int j = 0; j < 8; ++j) { pa[b][0][j] = (T)0.f; pa[b][1][j] = (T)0.f; pb[b][0][j] = (T)0.f; pb[b][1][j] = (T)0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[b][ks]));   // Q landed (see fa_fwd_tile_kernel)
+    }
 
     bool bad = false;
     FA_RUN(false)
@@ -381,21 +460,27 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     for (int w = 0; w < NWAVES; ++w) any_bad |= flags[w];
     if (any_bad) {
         __syncthreads();   // (flags are rewritten only by a later launch; this orders the LDS ring reuse)
-        m = -INFINITY;
-        l = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int b = 0; b < QB; ++b) {
+            m[b] = -INFINITY;
+            l[b] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[b][dt][e] = 0.f;
+        }
         FA_RUN(true)
     }
 #undef FA_ISSUE
 #undef FA_PUBLISH
 #undef FA_STEADY
+#undef FA_FAST
+#undef FA_RAGGED
+#undef FA_ROTATE
 #undef FA_OPND_LOAD
-#undef FA_PAIR_FMA
-#undef FA_PAIR_EXP
-#undef FA_PAIR_SUM
+#undef FA_ITEM_FMA
+#undef FA_ITEM_EXP
+#undef FA_ITEM_SUM
 #undef FA_GENERIC
 #undef FA_RUN
 #undef FA_DMA_K
@@ -409,55 +494,68 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 
     // ---- epilogue: O /= l through LDS, whole-row stores (as fa_fwd_dma_kernel; the K ring is free now)
     if (!wave_active) return;
-    const float lt = half_swap_sum(l);
-    const float inv = __builtin_amdgcn_rcpf(lt);
     unsigned char* slab = smem + wave * (32 * ROWB);
     constexpr int CPR = D / 8;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            vec4 w;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = (T)(o[dt][4 * rg + j] * inv);
-            const int ch = 4 * dt + rg;
-            *(vec4*)(slab + r * ROWB + ((ch ^ (r & (CPR - 1))) << 4) + 8 * h) = w;
-        }
-    }
-    if (p.lse != nullptr && h == 0 && qrow < L) p.lse[(int64_t)g * L + qrow] = m * p.scale + __logf(lt);
-    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
     constexpr int RPI = 64 / CPR;
+    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
 #pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
-        const int rr = i * RPI + lane / CPR, ch = lane % CPR;
-        const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
-        if (q_row0 + rr < L) *(u32x4*)(og + (int64_t)(q_row0 + rr) * p.o_sl + ch * 8) = val;
+    for (int b = 0; b < QB; ++b) {
+        const float lt = half_swap_sum(l[b]);
+        const float inv = __builtin_amdgcn_rcpf(lt);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                vec4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (T)(o[b][dt][4 * rg + j] * inv);
+                const int ch = 4 * dt + rg;
+                *(vec4*)(slab + r * ROWB + ((ch ^ (r & (CPR - 1))) << 4) + 8 * h) = w;
+            }
+        }
+        const int row_b = qrow + 32 * b;
+        if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * p.scale + __logf(lt);
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int rr = i * RPI + lane / CPR, ch = lane % CPR;
+            const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
+            const int orow = q_row0 + 32 * b + rr;
+            if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
+        }
     }
 }
 
-#ifndef FA_PIPE_MIN_WAVES
-#define FA_PIPE_MIN_WAVES 1
-#endif
-template <typename T, int D, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64, (D == 64 && NWAVES == 4) ? FA_PIPE_MIN_WAVES : 1) void fa_fwd_pipe_kernel(const FwdParams p) {
-    fa_fwd_pipe_body<T, D, NWAVES>(p);
+// (two query blocks per wave: hold the register allocator to 2 waves per SIMD = 256 registers)
+template <typename T, int D, int NWAVES, int QB>
+__global__ __launch_bounds__(NWAVES * 64, QB == 2 ? 2 : 1) void fa_fwd_pipe_kernel(const FwdParams p) {
+    fa_fwd_pipe_body<T, D, NWAVES, QB>(p);
 }
 
 template <typename T, int D>
-static hipError_t launch_pipe_w(const FwdParams& p, int waves, hipStream_t stream) {
+static hipError_t launch_pipe_w(const FwdParams& p, int waves, int qb, hipStream_t stream) {
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
+    if (qb == 2) {
+        if constexpr (D == 64) {
+            if (waves == 2) hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 2, 2>), dim3((unsigned)grid), dim3(128), 0, stream, p);
+            else hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 4, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     switch (waves) {
-        case 4: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 2>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
-        default: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 4, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 2, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
+        default: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 1, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
     }
     return hipGetLastError();
 }
 
-// callers guarantee: D in {64, 128}, waves in {1, 2, 4}, skip-max arithmetic wanted (bf16, or f16 with p.skipmax)
-hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
-    if (dtype == 1) return p.D == 64 ? launch_pipe_w<__bf16, 64>(p, waves, stream) : launch_pipe_w<__bf16, 128>(p, waves, stream);
-    return p.D == 64 ? launch_pipe_w<_Float16, 64>(p, waves, stream) : launch_pipe_w<_Float16, 128>(p, waves, stream);
+// callers guarantee: D in {64, 128}, waves in {1, 2, 4}, skip-max arithmetic wanted (bf16, or f16 with p.skipmax);
+// qb = 32-row query blocks per wave (2 only for D = 64 with 4 waves; the host sized p.nq_tiles for it)
+hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream) {
+    if (dtype == 1) return p.D == 64 ? launch_pipe_w<__bf16, 64>(p, waves, qb, stream) : launch_pipe_w<__bf16, 128>(p, waves, qb, stream);
+    return p.D == 64 ? launch_pipe_w<_Float16, 64>(p, waves, qb, stream) : launch_pipe_w<_Float16, 128>(p, waves, qb, stream);
 }
 
 }  // namespace fa

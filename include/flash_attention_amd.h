@@ -69,9 +69,10 @@ enum {
 
 /* hardware tile the request was mapped to (fa_plan) */
 typedef struct fa_plan_t {
-    int32_t kernel;      /* 0 = MFMA tile kernel (bf16/f16, D in {64,128}), 1 = generic kernel */
+    int32_t kernel;      /* 0 = MFMA kernel, 64-key tiles (bf16/f16, D in {64,128}), 1 = generic kernel,
+                            2 = MFMA kernel, software-pipelined 32-key steps */
     int32_t block_q;     /* q rows per workgroup */
-    int32_t block_kv;    /* keys per LDS tile */
+    int32_t block_kv;    /* keys per LDS tile / step */
     int32_t waves;       /* wavefronts per workgroup */
     int32_t chunk_q;     /* L / num_chunks_q  : the reference's chunkedQueryLen */
     int32_t chunk_kv;    /* L / num_chunks_kv : the reference's chunkedKVLen */

@@ -4,6 +4,10 @@
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/mix scripts/microbench/mix_mfma_valu.hip && /tmp/mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#ifndef RANDOM_DATA
+#define RANDOM_DATA 0
+#endif
+__device__ inline float rnd(unsigned& s) { s = s * 1664525u + 1013904223u; return ((float)(s >> 8) * (1.0f / 16777216.0f) - 0.5f) * 3.4f; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -12,12 +16,14 @@ typedef short i16x8 __attribute__((ext_vector_type(8)));
 template <int MODE>   // 0: MFMA + VALU, 1: MFMA only, 2: VALU only, 3: MFMA + VALU without exp, 4: as 0 with the A operands read from LDS like the kernel (8 ds_read_b128 + 16 ds_read_b64_tr_b16 per tile)
 __global__ __launch_bounds__(256) void mix(float* out, int iters, float c, float mc) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[16384 + 16640];
-    if (MODE == 4) { for (int i = threadIdx.x; i < (16384 + 16640) / 4; i += 256) ((float*)lds)[i] = 0.001f * i; __syncthreads(); }
+    unsigned seed = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 99u;
+    if (MODE == 4) { for (int i = threadIdx.x; i < (16384 + 16640) / 2; i += 256) ((__bf16*)lds)[i] = RANDOM_DATA ? (__bf16)rnd(seed) : (__bf16)(0.001f * i); __syncthreads(); }
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int sw = (r >> 1) & 7;
     const int v_rd = (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
     bf16x8 a, b;
     for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.01f * (threadIdx.x + j)); b[j] = (__bf16)(0.02f * (j + 1)); }
+    if (RANDOM_DATA) for (int j = 0; j < 8; ++j) { a[j] = (__bf16)rnd(seed); b[j] = (__bf16)rnd(seed); }
     f32x16 s0, s1, o0, o1;
     for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; o0[e] = 0.f; o1[e] = 0.f; }
     float l = 0.f, m = 0.f;
@@ -88,13 +94,15 @@ __global__ __launch_bounds__(256) void mix(float* out, int iters, float c, float
 // and fed to both blocks' MFMAs): 32 MFMA + 2x the softmax VALU per iteration = two wave-tiles.
 __global__ __launch_bounds__(256, 2) void mix2(float* out, int iters, float c, float mc) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[16384 + 16640];
-    for (int i = threadIdx.x; i < (16384 + 16640) / 4; i += 256) ((float*)lds)[i] = 0.001f * i;
+    unsigned seed = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 99u;
+    for (int i = threadIdx.x; i < (16384 + 16640) / 2; i += 256) ((__bf16*)lds)[i] = RANDOM_DATA ? (__bf16)rnd(seed) : (__bf16)(0.001f * i);
     __syncthreads();
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int sw = (r >> 1) & 7;
     const int v_rd = (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
     bf16x8 qa, qb;
     for (int j = 0; j < 8; ++j) { qa[j] = (__bf16)(0.01f * (threadIdx.x + j)); qb[j] = (__bf16)(0.02f * (j + 1)); }
+    if (RANDOM_DATA) for (int j = 0; j < 8; ++j) { qa[j] = (__bf16)rnd(seed); qb[j] = (__bf16)rnd(seed); }
     f32x16 sa0, sa1, sb0, sb1, oa0, oa1, ob0, ob1;
     for (int e = 0; e < 16; ++e) { sa0[e] = sa1[e] = sb0[e] = sb1[e] = oa0[e] = oa1[e] = ob0[e] = ob1[e] = 0.f; }
     float la = 0.f, lb = 0.f;
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void mix2(float* out, int iters, float c, f
 }
 
 static void run2(int wgs_per_cu, float* d) {
-    const int iters = 1000, grid = 256 * wgs_per_cu;
+    const int iters = RANDOM_DATA ? 10000 : 1000, grid = 256 * wgs_per_cu;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(mix2, dim3(grid), dim3(256), 0, 0, d, 50, 1.4427f, 3.0f);
     hipDeviceSynchronize();
@@ -160,7 +168,7 @@ static void run2(int wgs_per_cu, float* d) {
 
 template <int MODE>
 static void run(const char* name, int wgs_per_cu, float* d) {
-    const int iters = 2000, grid = 256 * wgs_per_cu;
+    const int iters = RANDOM_DATA ? 20000 : 2000, grid = 256 * wgs_per_cu;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(mix<MODE>, dim3(grid), dim3(256), 0, 0, d, 50, 1.4427f, 3.0f);
     hipDeviceSynchronize();

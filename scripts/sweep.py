@@ -2,7 +2,7 @@
 
 usage: python scripts/sweep.py [cfg] SPEC [SPEC ...]
   SPEC = "[lib:]K=pipe,W=4,S=4"   lib = name of build/variants/libfa_<lib>.so (default: the shipped library)
-         K kernel (tile|pipe), W waves per workgroup, S groups per L2 bunch
+         K kernel (tile|dma|pipe), W waves per workgroup, S groups per L2 bunch, Q 32-row query blocks per wave (1|2)
 Each timing = N back-to-back launches between two events; rounds are interleaved across specs.
 """
 import ctypes, os, sys, pathlib, statistics
@@ -43,12 +43,12 @@ def parse(spec):
     return name, rest
 
 def setenv(rest):
-    for k in ("FA_AMD_KERNEL", "FA_AMD_WAVES", "FA_AMD_SCHED"):
+    for k in ("FA_AMD_KERNEL", "FA_AMD_WAVES", "FA_AMD_SCHED", "FA_AMD_QB"):
         os.environ.pop(k, None)
     for kv in rest.split(","):
         if kv:
             k, val = kv.split("=")
-            os.environ[{"K": "FA_AMD_KERNEL", "W": "FA_AMD_WAVES", "S": "FA_AMD_SCHED"}[k]] = val
+            os.environ[{"K": "FA_AMD_KERNEL", "W": "FA_AMD_WAVES", "S": "FA_AMD_SCHED", "Q": "FA_AMD_QB"}[k]] = val
 
 def timeit(spec, n):
     name, rest = parse(spec)

@@ -94,6 +94,27 @@ def test_every_tile_variant(monkeypatch, waves, D):
     assert torch.equal(out, out_b), "block->tile schedule changed the result"
 
 
+MFMA_KERNELS = [("dma", 1), ("dma", 2), ("pipe", 1), ("pipe", 2), ("tile", 1)]
+
+
+@pytest.mark.parametrize("kernel,qb", MFMA_KERNELS)
+@pytest.mark.parametrize("G,L,D", [(2, 32, 64), (9, 257, 64), (3, 600, 64), (2, 2304, 64), (1, 4608, 64), (2, 1000, 128)])
+def test_every_mfma_kernel(monkeypatch, kernel, qb, G, L, D):
+    """The three MFMA kernels (64-key tiles with LDS-DMA, software-pipelined 32-key steps, register-staged
+    baseline), with one and two 32-row query blocks per wave, against the oracle - whatever the default
+    selection for a shape is.  (Two blocks exist for head_dim 64 only; the request falls back to one otherwise.)"""
+    _, _, with_lse = _mods()
+    from oracle import frozen_randn
+
+    monkeypatch.setenv("FA_AMD_KERNEL", kernel)
+    monkeypatch.setenv("FA_AMD_QB", str(qb))
+    qkv = frozen_randn(SEED + 7 * L + D, (3, G, L, D)).to(torch.bfloat16)
+    ref, ref_lse = _oracle(qkv)
+    out, lse = with_lse(qkv.cuda(), 1, 1)
+    _check(out, ref, torch.bfloat16, f"{kernel} qb={qb} {G}x{L}x{D}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+
+
 @pytest.mark.parametrize("nq,nk", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 3), (3, 2), (3, 3)])
 def test_tiny_fp32_all_chunk_pairs(golden_dir, nq, nk):
     """t_cpp:245-251: fp32 G=4 L=6 D=2, every chunk pair; golden G3 from the reference CPU path."""
@@ -215,9 +236,9 @@ def test_forced_rescale_spike():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_full_size_properties_config2(dtype):
+def test_full_size_properties_config2(monkeypatch, dtype):
     """BASELINE config 2 (G=128, L=4096, D=64): size-independent properties + oracle on sampled groups."""
-    fa, _, _ = _mods()
+    fa, native, _ = _mods()
     G, L, D = 128, 4096, 64
     gen = torch.Generator(device="cuda").manual_seed(0)
     qkv = torch.randn(3, G, L, D, device="cuda", generator=gen).to(dtype)
@@ -241,9 +262,19 @@ def test_full_size_properties_config2(dtype):
     # (4) groups are independent: a permutation of the groups permutes the output bit-exactly
     perm = torch.randperm(G, device="cuda", generator=gen)
     assert torch.equal(fa.flash_attention_qkv_packed(qkv[:, perm].contiguous(), 8, 8), out[perm])
-    # (5) causality: truncating the sequence does not change the surviving rows (same 64-key tiles)
+    # (5) causality: truncating the sequence does not change the surviving rows - bit-exactly when the same
+    # kernel serves both lengths (the default selection depends on L), within rounding otherwise
     Lt = 1536
+    trunc = fa.flash_attention_qkv_packed(qkv[:, :, :Lt].contiguous(), 8, 8)
+    # (two 16-bit results within an ulp of the exact value can sit two ulps apart: 2^-6 relative for bf16)
+    d_, r_ = (trunc.float() - out[:, :Lt].float()).abs(), out[:, :Lt].float().abs()
+    assert bool((d_ <= 1e-2 + 2.0 ** -6 * r_).all()), f"truncated, default kernel: max|delta|={d_.max().item():.3e}"
+    plan = native.plan(G, L, D, dtype, 8, 8)
+    monkeypatch.setenv("FA_AMD_KERNEL", "pipe" if plan.kernel == 2 else "dma")
+    monkeypatch.setenv("FA_AMD_QB", str(plan.block_q // (32 * plan.waves)))
     assert torch.equal(fa.flash_attention_qkv_packed(qkv[:, :, :Lt].contiguous(), 8, 8), out[:, :Lt])
+    monkeypatch.delenv("FA_AMD_KERNEL")
+    monkeypatch.delenv("FA_AMD_QB")
     # (6) the chunk counts never change the result beyond rounding; same hardware tile => identical
     assert torch.equal(fa.flash_attention_qkv_packed(qkv, 16, 4), out)
     # (7) oracle on sampled groups
@@ -349,16 +380,22 @@ def test_cpp_caller_of_the_c_abi(tmp_path):
     assert res.returncode == 0 and "PASSED" in res.stdout, res.stdout + res.stderr
 
 
+@pytest.mark.parametrize("kernel,qb", [("", 0), ("dma", 2), ("pipe", 1), ("pipe", 2)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
-def test_growing_logits_force_the_redo_branch(dtype, step):
+def test_growing_logits_force_the_redo_branch(monkeypatch, dtype, step, kernel, qb):
     """The bf16 kernel keeps its reference max from the first tile and only redoes a tile (exact max +
     rescale) when a row sum shows that some P left the safe range (cdna guide rule 26: a rare,
     data-dependent branch needs inputs that FORCE it and a full-tensor independent reference).
     Logits grow by `step` per 64-key tile: 3 never triggers, 25 triggers once the lag passes 2^60
-    (every other tile), 100 overflows exp2 to +inf inside a single tile."""
+    (every other tile), 100 overflows exp2 to +inf inside a single tile.  The pipelined kernel handles the
+    same event by flagging it and re-running the workgroup through its safe pass."""
     fa, _, _ = _mods()
     from oracle import frozen_randn
+
+    if kernel:
+        monkeypatch.setenv("FA_AMD_KERNEL", kernel)
+        monkeypatch.setenv("FA_AMD_QB", str(qb))
 
     G, L, D = 2, 1024, 64
     x = frozen_randn(SEED + 55, (3, G, L, D)) * 0.05

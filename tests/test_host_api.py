@@ -72,9 +72,16 @@ def test_c_abi_argument_validation(native):
 
 def test_plan_maps_chunks_to_hardware_tiles(native):
     # chunk length is an upper bound on the tile; >= 128 rows -> the 4-wave 128-row tile
-    p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)       # config 2: heuristic (8,8) -> 512x512 chunks
-    assert (p.kernel, p.block_q, p.block_kv, p.waves, p.chunk_q, p.chunk_kv) == (0, 128, 64, 4, 512, 512)
-    assert p.grid == 128 * 32 and p.lds_bytes == 2 * 8192 + 4 * (4096 + 64)
+    p = native.plan(128, 2048, 64, torch.bfloat16, 8, 8)       # L < 4096: 64-key-tile kernel, 128-row workgroups
+    assert (p.kernel, p.block_q, p.block_kv, p.waves, p.chunk_q, p.chunk_kv) == (0, 128, 64, 4, 256, 256)
+    assert p.grid == 128 * 16 and p.lds_bytes == 2 * 8192 + 4 * (4096 + 64)
+    # config 2: heuristic (8,8) -> 512x512 chunks; bf16, D=64, L >= 4096 -> pipelined 32-key steps, 2 query blocks
+    # per wave = 256-row workgroups, K/V rings of four 32-key slots
+    p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)
+    assert (p.kernel, p.block_q, p.block_kv, p.waves, p.chunk_q, p.chunk_kv) == (2, 256, 32, 4, 512, 512)
+    assert p.grid == 128 * 16 and p.lds_bytes == 4 * 4096 + 8 * (2048 + 64) + 16
+    p = native.plan(128, 4096, 64, torch.float16, 8, 8)        # f16 packed op (scale 1) keeps the per-tile row max
+    assert (p.kernel, p.block_q, p.block_kv) == (0, 128, 64)
     p = native.plan(16, 32768, 128, torch.bfloat16, 16, 16)    # config 3
     assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 128, 4, 2 * 16384 + 8 * (4096 + 64))
     assert native.plan(4, 4096, 64, torch.float16, 64, 64).block_q == 64     # 64-row chunks honoured
