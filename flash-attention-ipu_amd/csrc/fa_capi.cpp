@@ -63,11 +63,12 @@ bool tile_kernel_ok(int64_t D, int dtype, const void* const ptrs[4], const int64
 //   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic only
 //   't' fa_fwd_tile_kernel  register-staged A/B baseline (FA_AMD_KERNEL=tile)
 // and qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
-// Default: head_dim 64 with 4 waves, skip-max arithmetic and L >= 4096 -> 'p' with qb 2 (256-row workgroups:
-// +1..8 % measured at L 4096 .. 32768; slower below); everything else -> 'd' with qb 1.
+// Default: head_dim 64 with 4 waves, skip-max arithmetic, L >= 4096 and a grid of >= 1024 workgroups -> 'p' with
+// qb 2 (256-row workgroups: +1..6 % measured at L 4096 .. 32768 under sustained load; slower on short sequences
+// and under-filled grids); everything else -> 'd' with qb 1.
 // FA_AMD_KERNEL=dma|pipe|tile and FA_AMD_QB=1|2 override (developer knobs).
 struct KernelChoice { char which; int qb; };
-KernelChoice pick_kernel(int64_t L, int64_t D, int waves, bool skip_ok) {
+KernelChoice pick_kernel(int64_t G, int64_t L, int64_t D, int waves, bool skip_ok) {
     const char* kv = getenv("FA_AMD_KERNEL");
     const char forced = (kv && (kv[0] == 't' || kv[0] == 'd' || kv[0] == 'p')) ? kv[0] : 0;
     const char* qe = getenv("FA_AMD_QB");
@@ -76,8 +77,10 @@ KernelChoice pick_kernel(int64_t L, int64_t D, int waves, bool skip_ok) {
     const bool pipe_ok = skip_ok && waves <= 4;
     if (forced == 't') return KernelChoice{'t', 1};
     if (forced == 'p' && pipe_ok) kc.which = 'p';
-    if (forced == 0 && pipe_ok && D == 64 && waves == 4 && L >= 4096) kc = KernelChoice{'p', 2};
-    const bool qb2_ok = D == 64 && L >= 256 && (waves == 4 || (waves == 2 && kc.which == 'p'));
+    // (256-row workgroups at 2 per CU: below ~2 workgroups per slot of a 256-CU device the coarser grid loses)
+    const int64_t wgs_qb2 = (G + 7) / 8 * 8 * ((L + 255) / 256);
+    if (forced == 0 && pipe_ok && D == 64 && waves == 4 && L >= 4096 && wgs_qb2 >= 1024) kc = KernelChoice{'p', 2};
+    const bool qb2_ok = D == 64 && L >= 256 && waves == 4;
     if (qb_env == 1) kc.qb = 1;
     if (qb_env == 2 && qb2_ok) kc.qb = 2;
     if (forced == 'p' && kc.which == 'p' && qb_env == 0) kc.qb = (qb2_ok && waves == 4) ? 2 : 1;
@@ -96,7 +99,7 @@ int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_
     plan->chunk_kv = (int32_t)(L / nk);
     if (tile_ok) {
         plan->waves = pick_waves(L, plan->chunk_q);
-        const KernelChoice kc = pick_kernel(L, D, plan->waves, skip_ok);
+        const KernelChoice kc = pick_kernel(G, L, D, plan->waves, skip_ok);
         if (choice) *choice = kc;
         plan->kernel = kc.which == 'p' ? 2 : 0;
         plan->block_q = 32 * plan->waves * kc.qb;

@@ -30,6 +30,10 @@
 
 #include "fa_device.h"
 
+// ring slots per K / V ring (power of two)
+#ifndef FA_PIPE_SLOTS
+#define FA_PIPE_SLOTS(D_, QB_) 4
+#endif
 // steady step: LDS operands (K rows / V^T fragments) are requested this many MFMAs ahead of their use
 #ifndef FA_PIPE_PF
 #define FA_PIPE_PF 6
@@ -64,8 +68,12 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     constexpr int DT = D / 32;
     static_assert(PIECES % NWAVES == 0 && PPW >= 1, "pieces must split evenly over the waves");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * KH_B + 4 * VH_B];   // K0..K3 V0..V3
-    unsigned char* const smem_v = smem + 4 * KH_B;
+    // ring depth: 4 slots = the DMA of a step has two steps to land (8 slots = six steps were measured 1-2 %
+    // slower: the groups of NS steps leave more ragged steps over)
+    constexpr int NS = FA_PIPE_SLOTS(D, QB);
+    constexpr int NSM = NS - 1;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * KH_B + NS * VH_B];   // K0..K(NS-1) V0..V(NS-1)
+    unsigned char* const smem_v = smem + NS * KH_B;
     __shared__ int flags[NWAVES];
 
     const int b = blockIdx.x;
@@ -140,7 +148,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         const unsigned vo_ = (unsigned)(J_) * HK * v_slb;                                          \
         const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
-            lds_dma_b128(vr_, smem_lds + 4 * KH_B + (SLOT_) * VH_B + v_dst[j], v_vo[j]);           \
+            lds_dma_b128(vr_, smem_lds + NS * KH_B + (SLOT_) * VH_B + v_dst[j], v_vo[j]);          \
     }
 
     int k_rd[KS];
@@ -241,11 +249,11 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // every step: issue the DMA for K(i+3), V(i+2); compute; publish (everything issued before this step has
     // landed - this step's own DMA may fly on across the barrier)
 #define FA_ISSUE(I_, KSLOT_, VSLOT_)                                                               \
-        const bool dk_ = (I_) + 3 < nh_wg, dv_ = (I_) + 2 < nh_wg;                                 \
-        if (dk_ && FA_PIPE_ABL != 2) FA_DMA_K((I_) + 3, KSLOT_)                                    \
-        if (dv_ && FA_PIPE_ABL != 2) FA_DMA_V((I_) + 2, VSLOT_)
+        const bool dk_ = (I_) + NS - 1 < nh_wg, dv_ = (I_) + NS - 2 < nh_wg;                       \
+        if (dk_ && FA_PIPE_ABL != 2) FA_DMA_K((I_) + NS - 1, KSLOT_)                               \
+        if (dv_ && FA_PIPE_ABL != 2) FA_DMA_V((I_) + NS - 2, VSLOT_)
 #define FA_PUBLISH()                                                                               \
-        if (dk_ && dv_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");             \
+        if (dk_ && dv_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NS - 3)) : "memory");  \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
         FA_PIPE_BARRIER();
     // steady-state step I_ (ring index R_ = I_ & 3 at compile time): S(I_) is in SC_, SN_ receives S(I_+1),
@@ -349,7 +357,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         FA_PUBLISH()                                                                               \
     }
 #define FA_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                      \
-    FA_FAST(I_, ((R_) + 1) & 3, ((R_) + 3) & 3, ((R_) + 3) & 3, ((R_) + 2) & 3, SC_, SN_, PP_, PC_, false, true)
+    FA_FAST(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, false, true)
     // The ragged steps and the generic steps after the groups of four use FIXED register roles (S(i) in sa,
     // S(i+1) -> sb, P(i-1) in pb, P(i) -> pa) and rotate by copying afterwards: one instantiation each instead of
     // one per parity (parity branches make hipcc shuffle the whole accumulator state through phi copies)
@@ -360,16 +368,16 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         pb[b][1] = pa[b][1];                                                                       \
     }
 #define FA_RAGGED(I_, QK_)                                                                         \
-    FA_FAST(I_, ((I_) + 1) & 3, ((I_) + 3) & 3, ((I_) + 3) & 3, ((I_) + 2) & 3, sa, sb, pb, pa, true, QK_)
+    FA_FAST(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, true, QK_)
     // generic step (runtime ring slots, compiler's own schedule): the first step, the up to three steps left
     // over by the groups of four, the diagonal step, the drain step and the idle steps of a finished wave.
     // SAFE_ = the fallback pass: a step whose P outgrew the safe range is redone with an exact max.
 #define FA_GENERIC(I_, SC_, SN_, PP_, PC_, SAFE_)                                                  \
     {                                                                                              \
         const int i_ = (I_);                                                                       \
-        FA_ISSUE(i_, (i_ + 3) & 3, (i_ + 2) & 3)                                                   \
-        if (i_ + 1 < nh_w) FA_QK_H(SN_, (i_ + 1) & 3)                                              \
-        if (i_ >= 1 && i_ <= nh_w) FA_PV_H(PP_, (i_ + 3) & 3)                                      \
+        FA_ISSUE(i_, (i_ + NS - 1) & NSM, (i_ + NS - 2) & NSM)                                     \
+        if (i_ + 1 < nh_w) FA_QK_H(SN_, (i_ + 1) & NSM)                                            \
+        if (i_ >= 1 && i_ <= nh_w) FA_PV_H(PP_, (i_ + NS - 1) & NSM)                               \
         if (i_ < nh_w) {                                                                           \
             float ls[QB];                                                                          \
             const bool diag_ = i_ >= nh_w - QB;                                                    \
@@ -380,7 +388,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             _Pragma("unroll") for (int b = 0; b < QB; ++b) over_ |= !(ls[b] <= P_LIMIT);           \
             if (SAFE_) {                                                                           \
                 if (__builtin_amdgcn_ballot_w64(over_) != 0) {                                     \
-                    FA_QK_H(SC_, i_ & 3)                                                           \
+                    FA_QK_H(SC_, i_ & NSM)                                                         \
                     if (diag_) FA_MASK_H(SC_, i_)                                                  \
                     FA_MAXR_H(SC_)                                                                 \
                     FA_SM_H(SC_)                                                                   \
@@ -398,24 +406,22 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // a successor.
 #define FA_RUN(SAFE_)                                                                              \
     {                                                                                              \
-        FA_DMA_K(0, 0)                                                                             \
-        FA_DMA_V(0, 0)                                                                             \
-        if (1 < nh_wg) {                                                                           \
-            FA_DMA_K(1, 1)                                                                         \
-            FA_DMA_V(1, 1)                                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < NS - 1; ++j_) {       /* K(0..NS-2), V(0..NS-3) */    \
+            if (j_ < nh_wg) FA_DMA_K(j_, j_)                                                       \
+            if (j_ < NS - 2 && j_ < nh_wg) FA_DMA_V(j_, j_)                                        \
         }                                                                                          \
-        if (2 < nh_wg) FA_DMA_K(2, 2)                                                              \
         lds_dma_wait_all();                                                                        \
         __syncthreads();                                                                           \
         if (nh_w >= 1) FA_QK_H(sa, 0)                                                              \
         FA_GENERIC(0, sa, sb, pb, pa, SAFE_)                                                       \
         int i = 1;                                                                                 \
         if (!(SAFE_)) {                                                                            \
-            for (; i + 3 + QB < nh_w; i += 4) {       /* steps i .. i+3 carry no mask */           \
-                FA_STEADY(i, 1, sb, sa, pa, pb)                                                    \
-                FA_STEADY(i + 1, 2, sa, sb, pb, pa)                                                \
-                FA_STEADY(i + 2, 3, sb, sa, pa, pb)                                                \
-                FA_STEADY(i + 3, 0, sa, sb, pb, pa)                                                \
+            for (; i + NS - 1 + QB < nh_w; i += NS) {  /* steps i .. i+NS-1 carry no mask */        \
+                fa_static_for<0, NS>([&](auto ki_) {                                               \
+                    constexpr int k_ = decltype(ki_)::value, R_ = (1 + k_) % NS;                   \
+                    if constexpr (k_ % 2 == 0) FA_STEADY(i + k_, R_, sb, sa, pa, pb)               \
+                    else FA_STEADY(i + k_, R_, sa, sb, pb, pa)                                     \
+                });                                                                                \
             }                                                                                      \
         }                                                                                          \
         FA_ROTATE()                                            /* i is odd: S(i) sb -> sa, P(i-1) pa -> pb */ \
@@ -536,8 +542,7 @@ static hipError_t launch_pipe_w(const FwdParams& p, int waves, int qb, hipStream
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
     if (qb == 2) {
         if constexpr (D == 64) {
-            if (waves == 2) hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 2, 2>), dim3((unsigned)grid), dim3(128), 0, stream, p);
-            else hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 4, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 4, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;

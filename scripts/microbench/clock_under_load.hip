@@ -25,7 +25,7 @@ __global__ void sampler(unsigned long long* out, int spins) {
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
 
 int main(int argc, char** argv) {
-    const int mode = argc > 1 ? atoi(argv[1]) : 1;   // 0: idle, 1: attention with random data, 2: attention with constant data
+    const int mode = argc > 1 ? atoi(argv[1]) : 1;   // 0: idle, 1: attention with random data, 2: attention with constant data, 3: backward (random data)
     const long G = 128, L = 4096, D = 64;
     const size_t n = 3ul * G * L * D;
     std::vector<unsigned short> h(n);
@@ -36,8 +36,21 @@ int main(int argc, char** argv) {
     (void)hipMalloc(&qkv, n * 2); (void)hipMalloc(&out, n * 2 / 3); (void)hipMalloc(&d, 16);
     (void)hipMemcpy(qkv, h.data(), n * 2, hipMemcpyHostToDevice);
     hipStream_t s1, s2; (void)hipStreamCreate(&s1); (void)hipStreamCreate(&s2);
+    void *dq = nullptr, *dout = nullptr; float *lse = nullptr, *dsum = nullptr;
+    const int64_t st[3] = {L * D, 0, D};
+    int64_t st8[8][3];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 3; ++j) st8[i][j] = st[j];
+    if (mode == 3) {
+        (void)hipMalloc(&dq, n * 2); (void)hipMalloc(&dout, n * 2 / 3); (void)hipMalloc((void**)&lse, G * L * 4); (void)hipMalloc((void**)&dsum, G * L * 4);
+        (void)hipMemcpy(dout, qkv, n * 2 / 3, hipMemcpyDeviceToDevice);
+        fa_fwd_qkv_packed(qkv, out, lse, G, L, D, 8, 8, FA_DTYPE_BF16, s1);
+    }
     for (int rep = 0; rep < 3; ++rep) {
-        if (mode) for (int i = 0; i < 300; ++i) fa_fwd_qkv_packed(qkv, out, nullptr, G, L, D, 8, 8, FA_DTYPE_BF16, s1);   // ~90 ms of load
+        if (mode == 3) {
+            const char* b = (const char*)qkv; char* g = (char*)dq; const size_t sz = (size_t)G * L * D * 2;
+            for (int i = 0; i < 90; ++i)
+                fa_bwd(b, b + sz, b + 2 * sz, out, dout, lse, g, g + sz, g + 2 * sz, dsum, G, L, D, 1, st8, FA_DTYPE_BF16, 1.0f, 1, s1);
+        } else if (mode) for (int i = 0; i < 300; ++i) fa_fwd_qkv_packed(qkv, out, nullptr, G, L, D, 8, 8, FA_DTYPE_BF16, s1);   // ~90 ms of load
         if (mode) for (volatile int w = 0; w < 20000000; ++w) {}   // let the load start (host spin ~20 ms)
         hipLaunchKernelGGL(sampler, dim3(1), dim3(64), 0, s2, d, 20000);
         (void)hipStreamSynchronize(s2);
