@@ -192,6 +192,31 @@ def test_sdpa_override_vs_oracle(dtype, batch_shape, L):
     _check(out.reshape(G, L, D), ref, dtype, f"sdpa {dtype} {batch_shape} L={L}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kernel", ["", "dma", "pipe"])
+def test_sdpa_long_sequence_scaled_logits(monkeypatch, dtype, kernel):
+    """The SDPA override at L = 4096 with a [B, T, 3C]-style head-inner projection (strided q/k/v views): the
+    1/sqrt(D) scale selects the skip-max arithmetic for f16 too, so the default here is the pipelined kernel for
+    both dtypes (G = 64 groups x 16 row tiles = 1024 workgroups); forced kernels for comparison."""
+    import torch.nn.functional as F
+
+    import flash_attention_amd.auto  # noqa: F401
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    if kernel:
+        monkeypatch.setenv("FA_AMD_KERNEL", kernel)
+    B, H, L, D = 4, 16, 4096, 64
+    assert native.plan(B * H, L, D, torch.bfloat16, 8, 8).kernel == (0 if kernel == "dma" else 2)
+    x = frozen_randn(SEED + 4096, (B, L, 3 * H * D)).to(dtype).cuda()
+    q, k, v = (t.view(B, L, H, D).transpose(1, 2) for t in x.split(H * D, dim=2))
+    out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+    assert out.shape == (B, H, L, D) and out.dtype == dtype
+    for b, hh in ((0, 0), (3, 15), (1, 7)):
+        ref, _ = _oracle(torch.stack([q[b, hh], k[b, hh], v[b, hh]]).unsqueeze(1).cpu(), scale=D ** -0.5)
+        _check(out[b, hh].unsqueeze(0), ref, dtype, f"sdpa L=4096 {dtype} kernel={kernel or 'default'} ({b},{hh})")
+
+
 def test_sdpa_golden_g4_and_strided_views(golden_dir):
     import torch.nn.functional as F
 
