@@ -57,6 +57,26 @@ def test_packed_backward_vs_oracle(dtype, G, L, D):
         _close(x.grad[i], ref_grad[i], f"d{name} {dtype} {G}x{L}x{D}")
 
 
+@pytest.mark.parametrize("kernel", ["pipe", "tile"])
+def test_backward_after_every_forward_kernel(monkeypatch, kernel):
+    """The backward consumes the forward's `out` and log-sum-exp: the same gradients whichever forward kernel
+    produced them (the default at these sizes is the 64-key-tile kernel, covered above)."""
+    import flash_attention_amd as fa
+    from oracle import frozen_randn
+
+    monkeypatch.setenv("FA_AMD_KERNEL", kernel)
+    G, L, D, dtype = 2, 1024, 64, torch.bfloat16
+    qkv = (frozen_randn(SEED + L + D, (3, G, L, D)) * 0.5).to(dtype)
+    dout = frozen_randn(SEED + 1, (G, L, D)).to(dtype)
+    ref_out, ref_grad = _oracle_grads(qkv, dout, 1.0)
+    x = qkv.cuda().requires_grad_(True)
+    out = fa.flash_attention_qkv_packed(x, 1, 1)
+    out.backward(dout.cuda())
+    _close(out, ref_out, f"out ({kernel})")
+    for i, name in enumerate("qkv"):
+        _close(x.grad[i], ref_grad[i], f"d{name} after the {kernel} forward")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_sdpa_backward_vs_stock(dtype):
     """t_sdpa.py:96-113: dq, dk, dv of the patched SDPA vs stock SDPA math (fp64 here), batch shape (2,3)."""
