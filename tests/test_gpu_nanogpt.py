@@ -155,3 +155,29 @@ def test_torch_compile_traces_through_the_custom_ops():
 
     qkv = (torch.randn(3, 4, 256, 64, device="cuda") * 0.5).to(torch.bfloat16)
     torch.testing.assert_close(torch.compile(packed, fullgraph=True, backend="aot_eager")(qkv), packed(qkv))
+
+
+def test_tiny_gpt_trains_through_the_override():
+    """demo/train_tiny_gpt.py: 60 AdamW steps on a synthetic task that needs attention; the loss must fall
+    well below log(vocab) - i.e. gradients through the HIP forward + backward are usable for training - and track
+    the run with the override undone (stock SDPA) step for step within bf16 noise at the start."""
+    import pathlib
+    import sys
+
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "demo"))
+    from train_tiny_gpt import train
+
+    import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl import utils  # noqa: F401
+
+    ours = train(steps=60, override=True)
+    assert ours[0] > 3.5 and ours[-1] < 0.6 * ours[0], (ours[0], ours[-1])
+    assert all(l == l for l in ours), "NaN loss"
+    wrapped = F.scaled_dot_product_attention
+    try:   # undo the override for the comparison run
+        F.scaled_dot_product_attention = wrapped.__wrapped__
+        stock = train(steps=60, override=False)
+    finally:
+        F.scaled_dot_product_attention = wrapped
+    assert abs(ours[0] - stock[0]) < 5e-2, (ours[0], stock[0])       # same init, same data, same first loss
+    assert stock[-1] < 0.6 * stock[0] and abs(ours[-1] - stock[-1]) < 0.35 * stock[0], (ours[-1], stock[-1])
