@@ -277,34 +277,47 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             opnd[(X_)] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); \
         }
     // vector work item V_ (0 .. 8 QB - 1) = score pair V_ % 8 of block V_ / 8
+    // MASK_ modes: 0 no mask; 1 causal mask on every block; 2 mask on block 0 only (two blocks: the step of block
+    // 0's diagonal); 3 block 0 is dead - all its keys lie after its rows: no softmax, P = 0 - and block 1 is masked
+    // (two blocks: the wave's last step)
+#define FA_ITEM_MASKED(MASK_, B_) ((MASK_) == 1 || ((MASK_) == 2 && (B_) == 0) || ((MASK_) == 3 && (B_) == 1))
+#define FA_ITEM_DEAD(MASK_, B_) ((MASK_) == 3 && (B_) == 0)
 #define FA_ITEM_FMA(SC_, V_, MASK_)                                                                \
         {                                                                                          \
             constexpr int b_ = (V_) / 8, e_ = 2 * ((V_) % 8);                                      \
-            if constexpr (MASK_) {   /* key of element e: (e & 3) + 8 (e >> 2) + 4 h within the step */ \
+            if constexpr (FA_ITEM_MASKED(MASK_, b_)) {   /* key of element e: (e & 3) + 8 (e >> 2) + 4 h in the step */ \
                 const int key_ = key0_ + (e_ & 3) + 8 * (e_ >> 2);                                 \
                 if (key_ > qrow + 32 * b_) SC_[b_][e_] = -INFINITY;                                \
                 if (key_ + 1 > qrow + 32 * b_) SC_[b_][e_ + 1] = -INFINITY;                        \
             }                                                                                      \
-            SC_[b_][e_] = __builtin_fmaf(SC_[b_][e_], c, -mc[b_]);                                 \
-            SC_[b_][e_ + 1] = __builtin_fmaf(SC_[b_][e_ + 1], c, -mc[b_]);                         \
+            if constexpr (!FA_ITEM_DEAD(MASK_, b_)) {                                              \
+                SC_[b_][e_] = __builtin_fmaf(SC_[b_][e_], c, -mc[b_]);                             \
+                SC_[b_][e_ + 1] = __builtin_fmaf(SC_[b_][e_ + 1], c, -mc[b_]);                     \
+            }                                                                                      \
         }
-#define FA_ITEM_EXP(SC_, V_)                                                                       \
+#define FA_ITEM_EXP(SC_, V_, MASK_)                                                                \
         {                                                                                          \
             constexpr int b_ = (V_) / 8, e_ = 2 * ((V_) % 8);                                      \
-            SC_[b_][e_] = fast_exp2(SC_[b_][e_]);                                                  \
-            SC_[b_][e_ + 1] = fast_exp2(SC_[b_][e_ + 1]);                                          \
+            if constexpr (!FA_ITEM_DEAD(MASK_, b_)) {                                              \
+                SC_[b_][e_] = fast_exp2(SC_[b_][e_]);                                              \
+                SC_[b_][e_ + 1] = fast_exp2(SC_[b_][e_ + 1]);                                      \
+            }                                                                                      \
         }
-#define FA_ITEM_SUM(SC_, PC_, V_)                                                                  \
+#define FA_ITEM_SUM(SC_, PC_, V_, MASK_)                                                           \
         {                                                                                          \
             constexpr int b_ = (V_) / 8, p_ = (V_) % 8, e_ = 2 * p_;                               \
-            ls[b_] += SC_[b_][e_];                                                                 \
-            ls[b_] += SC_[b_][e_ + 1];                                                             \
-            PC_[b_][p_ >> 2][2 * (p_ & 3)] = (T)SC_[b_][e_];                                       \
-            PC_[b_][p_ >> 2][2 * (p_ & 3) + 1] = (T)SC_[b_][e_ + 1];                               \
+            if constexpr (!FA_ITEM_DEAD(MASK_, b_)) {                                              \
+                ls[b_] += SC_[b_][e_];                                                             \
+                ls[b_] += SC_[b_][e_ + 1];                                                         \
+                PC_[b_][p_ >> 2][2 * (p_ & 3)] = (T)SC_[b_][e_];                                   \
+                PC_[b_][p_ >> 2][2 * (p_ & 3) + 1] = (T)SC_[b_][e_ + 1];                           \
+            } else {                                                                               \
+                PC_[b_][p_ >> 2][2 * (p_ & 3)] = (T)0.f;                                           \
+                PC_[b_][p_ >> 2][2 * (p_ & 3) + 1] = (T)0.f;                                       \
+            }                                                                                      \
         }
     // KN_ / VP_ / KI_ / VI_: ring slots of K(I_+1), V(I_-1) and of the DMA targets K(I_+3), V(I_+2) - compile-time
-    // constants in the 4-step groups, i-dependent values in the ragged steps; MASK_: causal mask on S(I_)
-    // (the wave's last QB steps; also used, harmlessly, for the <= 3 steps the groups of four leave over);
+    // constants in the 4-step groups, i-dependent values in the ragged steps; MASK_: mask mode (above);
     // QK_: a next step exists
 #define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_)                             \
     {                                                                                              \
@@ -320,7 +333,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         float mc[QB], ls[QB];                                                                      \
         _Pragma("unroll") for (int b = 0; b < QB; ++b) { mc[b] = m[b] * c; ls[b] = 0.f; }          \
         FA_ITEM_FMA(SC_, 0, MASK_)                                                                 \
-        FA_ITEM_EXP(SC_, 0)                                                                        \
+        FA_ITEM_EXP(SC_, 0, MASK_)                                                                 \
         FA_ITEM_FMA(SC_, 1, MASK_)                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         fa_static_for<0, NMF>([&](auto gi_) {                                                      \
@@ -341,8 +354,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             /* this MFMA's share of the vector work items */                                      \
             fa_static_for<(n_ * NV) / NMF, ((n_ + 1) * NV) / NMF>([&](auto vi_) {                  \
                 constexpr int v_ = decltype(vi_)::value;                                           \
-                if constexpr (v_ + 1 < NV) { FA_ITEM_EXP(SC_, v_ + 1) }                            \
-                FA_ITEM_SUM(SC_, PC_, v_)                                                          \
+                if constexpr (v_ + 1 < NV) { FA_ITEM_EXP(SC_, v_ + 1, MASK_) }                     \
+                FA_ITEM_SUM(SC_, PC_, v_, MASK_)                                                   \
                 if constexpr (v_ + 2 < NV) { FA_ITEM_FMA(SC_, v_ + 2, MASK_) }                     \
             });                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                     \
@@ -357,7 +370,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         FA_PUBLISH()                                                                               \
     }
 #define FA_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                      \
-    FA_FAST(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, false, true)
+    FA_FAST(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, 0, true)
     // The ragged steps and the generic steps after the groups of four use FIXED register roles (S(i) in sa,
     // S(i+1) -> sb, P(i-1) in pb, P(i) -> pa) and rotate by copying afterwards: one instantiation each instead of
     // one per parity (parity branches make hipcc shuffle the whole accumulator state through phi copies)
@@ -367,8 +380,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         pb[b][0] = pa[b][0];                                                                       \
         pb[b][1] = pa[b][1];                                                                       \
     }
-#define FA_RAGGED(I_, QK_)                                                                         \
-    FA_FAST(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, true, QK_)
+#define FA_RAGGED(I_, MASK_, QK_)                                                                  \
+    FA_FAST(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, MASK_, QK_)
     // generic step (runtime ring slots, compiler's own schedule): the first step, the up to three steps left
     // over by the groups of four, the diagonal step, the drain step and the idle steps of a finished wave.
     // SAFE_ = the fallback pass: a step whose P outgrew the safe range is redone with an exact max.
@@ -426,12 +439,17 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         }                                                                                          \
         FA_ROTATE()                                            /* i is odd: S(i) sb -> sa, P(i-1) pa -> pb */ \
         if (!(SAFE_)) {                                                                            \
-            for (; i + 1 < nh_w; ++i) {                        /* left-over and masked steps */    \
-                FA_RAGGED(i, true)                                                                 \
+            for (; i + QB < nh_w; ++i) {                       /* steps the groups left over */    \
+                FA_RAGGED(i, 0, true)                                                              \
                 FA_ROTATE()                                                                        \
             }                                                                                      \
+            if (QB == 2 && i + 1 < nh_w) {                     /* block 0's diagonal step */       \
+                FA_RAGGED(i, 2, true)                                                              \
+                FA_ROTATE()                                                                        \
+                ++i;                                                                               \
+            }                                                                                      \
             if (i < nh_w) {                                    /* the wave's last step */          \
-                FA_RAGGED(i, false)                                                                \
+                FA_RAGGED(i, (QB == 2 ? 3 : 1), false)                                             \
                 FA_ROTATE()                                                                        \
                 ++i;                                                                               \
             }                                                                                      \
@@ -485,6 +503,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #undef FA_ROTATE
 #undef FA_OPND_LOAD
 #undef FA_ITEM_FMA
+#undef FA_ITEM_MASKED
+#undef FA_ITEM_DEAD
 #undef FA_ITEM_EXP
 #undef FA_ITEM_SUM
 #undef FA_GENERIC
