@@ -5,34 +5,38 @@
 // fa_fwd_dma_kernel runs  QK^T (8 MFMA) -> softmax (~110 VALU) -> PV (8 MFMA)  strictly one after the other
 // per 64-key tile, so a wave's matrix work never overlaps its own vector work and the SIMD relies on the other
 // three waves to fill the gaps (measured: VALU issue port 71 % busy).  Here the kv loop advances in steps of
-// 32 keys and iteration i of a wave issues, interleaved by sched_group_barrier,
+// 32 keys and iteration i of a wave issues, in a hand-written order frozen with sched_barrier(0),
 //
 //        MFMA:  S(i+1) = K(i+1) Q^T          and      O^T += V(i-1)^T P(i-1)^T
 //        VALU:  P(i)   = 2^(c S(i) - c m),  row sums, bf16/f16 packing
 //
 // i.e. the matrix pipe works on the next and the previous step while the vector pipe exponentiates the current
-// one; the accumulators of S(i) and S(i+1) are the two halves of what used to be one 64-key tile, so the
-// register budget (and 4 waves per SIMD at head_dim 64) is unchanged.  scripts/microbench/pipe_half.hip has the
-// instruction-mix measurement that motivated it (0.444 -> 0.396 us per wave-tile per SIMD).
+// one; the accumulators of S(i) and S(i+1) are the two halves of what used to be one 64-key tile.
+// scripts/microbench/pipe_half.hip and pipe_half2.hip have the instruction-mix measurements that motivated it.
 //
-// Only the skip-max arithmetic is implemented (reference max fixed on the first step, overflow-triggered
-// redo; see fa_fwd_dma.hip): bf16 always, f16 when the host selects it.  K and V live in rings of four 32-key
-// slots; step i reads K(i+1), V(i-1) (and K(i) if it has to redo), while the DMA fills K(i+3) and V(i+2).
+// Only the skip-max arithmetic is implemented (reference max fixed on the first step; see fa_fwd_dma.hip):
+// bf16 always, f16 when the host selects it.  A step whose P left the safe range only raises a flag (optimistic
+// pass); if any wave of the workgroup raised it, the workgroup runs again through a slow pass that redoes such
+// steps with an exact max.  K and V live in rings of four 32-key slots; step i reads K(i+1), V(i-1) (and K(i)
+// if the slow pass has to redo), while the DMA fills K(i+3) and V(i+2).
 // One workgroup barrier per step; the DMA issued in a step may stay in flight across that step's barrier
 // (s_waitcnt vmcnt(2*PPW)), so a slot has two full steps to land.
 //
 // QB = 32-row query blocks per wave.  With QB = 2 (head_dim 64) a wave owns 64 query rows and every K row /
 // V^T fragment it reads from LDS feeds two MFMAs, and a workgroup of 4 waves covers 256 rows per streamed K/V
 // step: half the LDS operand traffic and half the L2->LDS DMA traffic per FLOP.  That matters because this
-// kernel is POWER-bound, not issue-bound: scripts/microbench/clock_under_load.hip shows the device holding
-// only ~1.7 GHz (of 2.4) while it runs; energy per FLOP, not instruction slots, sets the speed.  Two blocks
-// double the accumulators, so 2 waves per SIMD - which the in-wave pipelining makes sufficient.
+// forward is POWER-bound: scripts/microbench/clock_under_load.hip shows the device holding only ~1.7 GHz (of
+// 2.4) under fa_fwd_dma_kernel, ~1.95 under this kernel; energy per FLOP counts as much as instruction slots.
+// Two blocks double the accumulators, so 2 waves per SIMD - which the in-wave pipelining makes sufficient.
+// Structure of a wave's pass (FA_RUN): generic first step (exact row max) -> groups of four steady steps with
+// compile-time ring slots -> left-over steps, block 0's diagonal step and the last step through the same
+// hand-ordered body with run-time slots and mask modes -> generic drain / idle steps.
 
 #include "fa_device.h"
 
 // ring slots per K / V ring (power of two)
 #ifndef FA_PIPE_SLOTS
-#define FA_PIPE_SLOTS(D_, QB_) 4
+#define FA_PIPE_SLOTS(D_, QB_, W_) 4
 #endif
 // steady step: LDS operands (K rows / V^T fragments) are requested this many MFMAs ahead of their use
 #ifndef FA_PIPE_PF
@@ -70,7 +74,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 
     // ring depth: 4 slots = the DMA of a step has two steps to land (8 slots = six steps were measured 1-2 %
     // slower: the groups of NS steps leave more ragged steps over)
-    constexpr int NS = FA_PIPE_SLOTS(D, QB);
+    constexpr int NS = FA_PIPE_SLOTS(D, QB, NWAVES);
     constexpr int NSM = NS - 1;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * KH_B + NS * VH_B];   // K0..K(NS-1) V0..V(NS-1)
     unsigned char* const smem_v = smem + NS * KH_B;
