@@ -82,8 +82,10 @@ def test_plan_maps_chunks_to_hardware_tiles(native):
     assert p.grid == 128 * 16 and p.lds_bytes == 4 * 4096 + 8 * (2048 + 64) + 16
     p = native.plan(128, 4096, 64, torch.float16, 8, 8)        # f16 packed op (scale 1) keeps the per-tile row max
     assert (p.kernel, p.block_q, p.block_kv) == (0, 128, 64)
-    p = native.plan(16, 32768, 128, torch.bfloat16, 16, 16)    # config 3
-    assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 128, 4, 2 * 16384 + 8 * (4096 + 64))
+    p = native.plan(16, 32768, 128, torch.bfloat16, 16, 16)    # config 3: head_dim 128, long, bf16 -> 8 waves = 256 rows
+    assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 256, 8, 2 * 16384 + 8 * (4096 + 64))
+    p = native.plan(16, 2048, 128, torch.bfloat16, 8, 8)
+    assert (p.kernel, p.block_q, p.waves) == (0, 128, 4)
     assert native.plan(4, 4096, 64, torch.float16, 64, 64).block_q == 64     # 64-row chunks honoured
     assert native.plan(4, 4096, 64, torch.float16, 128, 64).block_q == 32    # 32-row chunks honoured
     assert native.plan(5, 200, 64, torch.bfloat16, 1, 1).grid == 8 * 2       # G padded to the 8 XCDs
