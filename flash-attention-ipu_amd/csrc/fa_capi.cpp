@@ -68,7 +68,7 @@ bool tile_kernel_ok(int64_t D, int dtype, const void* const ptrs[4], const int64
 // and under-filled grids); everything else -> 'd' with qb 1.
 // FA_AMD_KERNEL=dma|pipe|tile and FA_AMD_QB=1|2 override (developer knobs).
 struct KernelChoice { char which; int qb; };
-KernelChoice pick_kernel(int64_t G, int64_t L, int64_t D, int waves, bool skip_ok) {
+KernelChoice pick_kernel(int64_t G, int64_t L, int64_t D, int waves, int64_t chunk_q, bool skip_ok) {
     const char* kv = getenv("FA_AMD_KERNEL");
     const char forced = (kv && (kv[0] == 't' || kv[0] == 'd' || kv[0] == 'p')) ? kv[0] : 0;
     const char* qe = getenv("FA_AMD_QB");
@@ -79,8 +79,8 @@ KernelChoice pick_kernel(int64_t G, int64_t L, int64_t D, int waves, bool skip_o
     if (forced == 'p' && pipe_ok) kc.which = 'p';
     // (256-row workgroups at 2 per CU: below ~2 workgroups per slot of a 256-CU device the coarser grid loses)
     const int64_t wgs_qb2 = (G + 7) / 8 * 8 * ((L + 255) / 256);
-    if (forced == 0 && pipe_ok && D == 64 && waves == 4 && L >= 4096 && wgs_qb2 >= 1024) kc = KernelChoice{'p', 2};
-    const bool qb2_ok = D == 64 && L >= 256 && waves == 4;
+    if (forced == 0 && pipe_ok && D == 64 && waves == 4 && chunk_q >= 256 && L >= 4096 && wgs_qb2 >= 1024) kc = KernelChoice{'p', 2};
+    const bool qb2_ok = D == 64 && L >= 256 && waves == 4 && chunk_q >= 256;   // (the chunk bounds the q tile)
     if (qb_env == 1) kc.qb = 1;
     if (qb_env == 2 && qb2_ok) kc.qb = 2;
     if (forced == 'p' && kc.which == 'p' && qb_env == 0) kc.qb = (qb2_ok && waves == 4) ? 2 : 1;
@@ -108,7 +108,7 @@ int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_
             if (!(we && *we) && plan->waves == 4 && D == 128 && skip_ok && plan->chunk_q >= 256 && L >= 4096 && wgs256 >= 512)
                 plan->waves = 8;
         }
-        const KernelChoice kc = pick_kernel(G, L, D, plan->waves, skip_ok);
+        const KernelChoice kc = pick_kernel(G, L, D, plan->waves, plan->chunk_q < L ? plan->chunk_q : L, skip_ok);
         if (choice) *choice = kc;
         plan->kernel = kc.which == 'p' ? 2 : 0;
         plan->block_q = 32 * plan->waves * kc.qb;

@@ -26,7 +26,7 @@ static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (uns
 
 int main(int argc, char** argv) {
     const int mode = argc > 1 ? atoi(argv[1]) : 1;   // 0: idle, 1: attention with random data, 2: attention with constant data, 3: backward (random data)
-    const long G = 128, L = 4096, D = 64;
+    const long D = argc > 2 ? atol(argv[2]) : 64, L = argc > 3 ? atol(argv[3]) : 4096, G = argc > 4 ? atol(argv[4]) : 128;   // [mode] [D] [L] [G]
     const size_t n = 3ul * G * L * D;
     std::vector<unsigned short> h(n);
     unsigned s = 12345;

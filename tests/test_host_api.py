@@ -80,6 +80,8 @@ def test_plan_maps_chunks_to_hardware_tiles(native):
     p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)
     assert (p.kernel, p.block_q, p.block_kv, p.waves, p.chunk_q, p.chunk_kv) == (2, 256, 32, 4, 512, 512)
     assert p.grid == 128 * 16 and p.lds_bytes == 4 * 4096 + 8 * (2048 + 64) + 16
+    p = native.plan(128, 4096, 64, torch.bfloat16, 32, 32)     # 128-row chunks bound the q tile: no 256-row workgroups
+    assert (p.kernel, p.block_q, p.block_kv) == (0, 128, 64)
     p = native.plan(128, 4096, 64, torch.float16, 8, 8)        # f16 packed op (scale 1) keeps the per-tile row max
     assert (p.kernel, p.block_q, p.block_kv) == (0, 128, 64)
     p = native.plan(16, 32768, 128, torch.bfloat16, 16, 16)    # config 3: head_dim 128, long, bf16 -> 8 waves = 256 rows
