@@ -123,7 +123,11 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         }                                                                                          \
     }
     // publish a DMA'd tile: drain this wave's DMA, then the workgroup barrier
+#if defined(FA_DMA_ABL_NOBAR)   /* timing-only ablation: wrong results */
+#define FA_TILE_BARRIER() { lds_dma_wait_all(); }
+#else
 #define FA_TILE_BARRIER() { lds_dma_wait_all(); __syncthreads(); }
+#endif
     const unsigned smem_lds = lds_offset(smem);
 
     int k_rd[KS];
