@@ -1,6 +1,7 @@
-"""Developer aid: run a grid of small cases on the GPU and print max|delta| vs the oracle per case."""
+"""Developer aid (test infrastructure: it uses the oracle, so it lives under tests/): run a grid of small cases on
+the GPU and print max|delta| vs the oracle per case."""
 import sys, pathlib, os
-ROOT = pathlib.Path(__file__).resolve().parent.parent
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd")]
 import torch
 import flash_attention_amd as fa
