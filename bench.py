@@ -185,6 +185,20 @@ def main():
             mpr = lib_.fa_probe_mfma_peak(_native.FA_DTYPE[dtype], 40000, 1)   # ~30 ms per repetition: clock settles
         measured_peak = round(mp, 1) if mp > 0 else None
         measured_peak_random = round(mpr, 1) if mpr > 0 else None
+    # which core clock does the device hold under this load?  (untimed repeat of the steps with a one-wave clock
+    # sampler on a side stream: the kernels are power-bound; nominal peak assumes 2400 MHz)
+    clock_mhz = None
+    if rank == 0:
+        side = torch.cuda.Stream(device=dev)
+        buf = torch.zeros(2, dtype=torch.int64, device=dev)
+        n_rep = max(args.steps, int(60.0 / max(kernel_ms, 1e-3)))          # >= 60 ms of load
+        for i in range(n_rep):
+            fa.flash_attention_qkv_packed(qkv, nq, nk)                      # (kernel only: no collective on one rank)
+            if i == 8:                                                      # the load is running: start sampling
+                _native.load_native_library().fa_probe_clock(buf.data_ptr(), 15000, side.cuda_stream)   # ~30-40 ms
+        torch.cuda.synchronize()
+        cyc, ticks = (int(x) for x in buf.tolist())
+        clock_mhz = round(cyc / ticks * 100.0) if ticks > 0 else None
     if rank == 0:
         total_tflops = world * flops_step * args.steps / elapsed / 1e12
         achieved = flops_step / (kernel_ms * 1e-3) / 1e12
@@ -213,6 +227,8 @@ def main():
             "pct_mfma_peak": round(100.0 * total_tflops / (world * PEAK_TFLOPS), 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
+                         "shader_clock_mhz_under_load": clock_mhz,
+                         "frac_at_that_clock": round(achieved / (PEAK_TFLOPS * clock_mhz / 2400.0), 4) if clock_mhz else None,
                          "measured_mfma_peak": measured_peak,
                          "frac_of_measured_peak": round(achieved / measured_peak, 4) if measured_peak else None,
                          "measured_mfma_peak_random_operands": measured_peak_random,

@@ -161,6 +161,14 @@ double fa_probe_mfma_peak(int32_t dtype, int32_t iters, int32_t random_data) {
     return fa::probe_mfma_peak(dtype, iters, random_data);
 }
 
+int fa_probe_clock(void* out2, int32_t spins, void* stream) {
+    if (!out2) return fail(FA_ERR_NULL_POINTER, "fa_probe_clock: null output pointer");
+    if (spins < 1) return fail(FA_ERR_BAD_SHAPE, "fa_probe_clock: spins must be >= 1");
+    hipError_t e = fa::launch_clock_sampler(static_cast<unsigned long long*>(out2), spins, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
 int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_shape[3]) {
     if (!qkv_shape || !out_shape) return fail(FA_ERR_NULL_POINTER, "null shape pointer");
     if (rank != 4) return fail(FA_ERR_BAD_SHAPE, "qkv must have 4 dimensions (got %d)", rank);

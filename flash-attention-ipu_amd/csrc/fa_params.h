@@ -52,7 +52,8 @@ hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, hipS
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream);
 
 hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);   // fa_fwd_pipe.hip
-double probe_mfma_peak(int dtype, int iters, int random_data);   // fa_probe.hip
+double probe_mfma_peak(int dtype, int iters, int random_data);
+hipError_t launch_clock_sampler(unsigned long long* out, int spins, hipStream_t stream);   // fa_probe.hip
 
 }  // namespace fa
 #endif

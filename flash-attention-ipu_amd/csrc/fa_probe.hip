@@ -71,4 +71,26 @@ double probe_mfma_peak(int dtype, int iters, int random_data) {
     return best;
 }
 
+// One wave that samples the shader clock counter (clock64 = s_memtime) against the constant 100 MHz counter
+// (wall_clock64 = s_memrealtime) for `spins` sleeps of ~2 us: launched on a side stream while other work runs, it
+// tells which core clock the device actually holds under that load.  out[0] = shader cycles, out[1] = 10 ns ticks.
+__global__ void fa_clock_sampler_kernel(unsigned long long* out, int spins) {
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    unsigned long long c1 = c0, w1 = w0;
+    for (int i = 0; i < spins; ++i) {
+        __builtin_amdgcn_s_sleep(64);
+        c1 = clock64();
+        w1 = wall_clock64();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = w1 - w0;
+    }
+}
+
+hipError_t launch_clock_sampler(unsigned long long* out, int spins, hipStream_t stream) {
+    hipLaunchKernelGGL(fa_clock_sampler_kernel, dim3(1), dim3(64), 0, stream, out, spins);
+    return hipGetLastError();
+}
+
 }  // namespace fa

@@ -83,6 +83,8 @@ def _declare(lib):
                            i32, i32, i32, ctypes.c_float, i32, vp]
     lib.fa_bwd.restype = ctypes.c_int
     lib.fa_bwd.argtypes = [vp] * 10 + [i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32, vp]
+    lib.fa_probe_clock.restype = ctypes.c_int
+    lib.fa_probe_clock.argtypes = [ctypes.c_void_p, i32, ctypes.c_void_p]
     lib.fa_probe_mfma_peak.restype = ctypes.c_double
     lib.fa_probe_mfma_peak.argtypes = [i32, i32, i32]
     lib.fa_fwd_qkv_packed.restype = ctypes.c_int

@@ -94,6 +94,13 @@ const char* fa_error_string(int code);
  * reports the attention kernel against both as well as against the nominal 2.5 PFLOP/s. */
 double fa_probe_mfma_peak(int32_t dtype, int32_t iters, int32_t random_data);
 
+/* Bench utility: enqueue on `stream` (use a side stream) a one-wave kernel that samples the shader clock counter
+ * against the constant 100 MHz counter for `spins` sleeps of ~2 us and writes two uint64 to the device buffer
+ * `out2`: {shader cycles, 10 ns ticks}.  cycles / ticks * 100 = the core clock in MHz the device held meanwhile -
+ * bench.py runs it next to the timed steps (the attention kernels are power-bound: DESIGN.md 3.0).
+ * (No reference counterpart.) */
+int fa_probe_clock(void* out2, int32_t spins, void* stream);
+
 /* [3,G,L,D] -> [G,L,D]; returns FA_OK or FA_ERR_BAD_SHAPE (rank != 4 or dim0 != 3). */
 int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_shape[3]);
 
