@@ -434,3 +434,17 @@ def test_growing_logits_force_the_redo_branch(monkeypatch, dtype, step, kernel, 
     out2, lse = _mods()[2](x.cuda(), 1, 1)
     _check(out2, ref, dtype, f"growing logits step={step}")
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
+
+
+def test_differential_fuzz_of_the_kernel_variants():
+    """tests/tools/fuzz_kernels.py, bounded: random shapes / dtypes / scales / layouts; every MFMA kernel variant
+    against the register-staged baseline kernel and (short sequences) the fp64 oracle."""
+    import pathlib
+    import sys
+
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent / "tools"))
+    from fuzz_kernels import fuzz
+
+    msgs = []
+    bad, _ = fuzz(40, 20260, log=msgs.append)
+    assert bad == 0, "\n".join(m for m in msgs if m.startswith("MISMATCH"))

@@ -1,0 +1,84 @@
+"""Developer aid (test infrastructure): differential fuzz of the forward kernels.  Random shapes, dtypes, scales and
+layouts; every MFMA kernel variant (dma / pipe x 1 / 2 query blocks per wave, 1..8 waves) against the register-staged
+baseline kernel and, for short sequences, against the fp64 oracle.
+
+    python tests/tools/fuzz_kernels.py [cases] [seed]
+"""
+import ctypes, os, pathlib, random, sys
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd")]
+import torch
+from flash_attention_amd._impl import _native
+from oracle import dense_causal_attention_lse
+
+lib = _native.load_native_library()
+KNOBS = ("FA_AMD_KERNEL", "FA_AMD_QB", "FA_AMD_WAVES", "FA_AMD_SCHED")
+
+
+def run(q, k, v, heads, scale, env):
+    for kk in KNOBS:
+        os.environ.pop(kk, None)
+    os.environ.update(env)
+    B, H, L, D = q.shape
+    out = torch.empty(B, H, L, D, device="cuda", dtype=q.dtype)
+    lse = torch.empty(B * H, L, device="cuda", dtype=torch.float32)
+    def st(t):
+        return (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+    rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B * H, L, D, H,
+                    st(q), st(k), st(v), st(out), 1, 1, _native.FA_DTYPE[q.dtype], ctypes.c_float(scale), 1,
+                    torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.fa_last_error().decode()
+    torch.cuda.synchronize()
+    return out, lse
+
+
+def fuzz(cases, seed, log=print):
+  rng = random.Random(seed)
+  bad = 0
+  for case in range(cases):
+      D = rng.choice([64, 64, 128])
+      L = rng.choice([rng.randint(1, 300), rng.randint(1, 1500), rng.randint(1500, 5000)])
+      B, H = rng.randint(1, 3), rng.randint(1, 5)
+      dt = rng.choice([torch.bfloat16, torch.float16])
+      scale = rng.choice([1.0, D ** -0.5])
+      amp = rng.choice([0.3, 1.0])
+      torch.manual_seed(case)
+      if rng.random() < 0.5:      # head-inner projection layout [B, L, 3, H, D] -> strided views
+          x = (torch.randn(B, L, 3, H, D, device="cuda") * amp).to(dt)
+          q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+      else:
+          q, k, v = ((torch.randn(B, H, L, D, device="cuda") * amp).to(dt) for _ in range(3))
+      base, base_lse = run(q, k, v, H, scale, {"FA_AMD_KERNEL": "tile"})
+      variants = [{}]
+      for kern in ("dma", "pipe"):
+          for qb in (1, 2):
+              variants.append({"FA_AMD_KERNEL": kern, "FA_AMD_QB": str(qb), "FA_AMD_WAVES": str(rng.choice([1, 2, 4, 4, 8])),
+                               "FA_AMD_SCHED": str(rng.choice([1, 2, 8]))})
+      ulp = 2.0 ** -6 if dt == torch.bfloat16 else 2.0 ** -9
+      ref = None
+      if L <= 700:
+          qkv = torch.stack([t.reshape(B * H, L, D) for t in (q, k, v)]).cpu()
+          ref, ref_lse = dense_causal_attention_lse(qkv, scale=scale, compute_dtype=torch.float64)
+      for env in variants:
+          out, lse = run(q, k, v, H, scale, env)
+          d = (out.float() - base.float()).abs()
+          tol = 1e-2 * (1 if dt == torch.bfloat16 else 0.1) + ulp * base.float().abs()
+          ok = bool(torch.isfinite(out).all()) and bool((d <= tol).all()) and bool(((lse - base_lse).abs() <= 2e-3 + 1e-4 * base_lse.abs()).all())
+          if ref is not None:
+              e = (out.reshape(B * H, L, D).cpu().double() - ref).abs()
+              ok = ok and bool((e <= 1e-2 + 1e-2 * ref.abs()).all())
+          if not ok:
+              bad += 1
+              log(f"MISMATCH case {case}: B={B} H={H} L={L} D={D} {dt} scale={scale:.3g} env={env} max|d|={d.max().item():.3e}")
+      if case % 20 == 0:
+          log(f"case {case}: B={B} H={H} L={L} D={D} {dt} ok so far, bad={bad}")
+  for kk in KNOBS:
+      os.environ.pop(kk, None)
+  return bad, len(variants)
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    bad, nv = fuzz(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print(f"{n} cases x {nv} variants: {bad} mismatches")
+    sys.exit(1 if bad else 0)
