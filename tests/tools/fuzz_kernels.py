@@ -41,7 +41,7 @@ def fuzz(cases, seed, log=print):
       B, H = rng.randint(1, 3), rng.randint(1, 5)
       dt = rng.choice([torch.bfloat16, torch.float16])
       scale = rng.choice([1.0, D ** -0.5])
-      amp = rng.choice([0.3, 1.0])
+      amp = rng.choice([0.3, 1.0]) * float(os.environ.get("FUZZ_AMP", "1"))   # FUZZ_AMP=5: logits far past the skip-max range
       torch.manual_seed(case)
       if rng.random() < 0.5:      # head-inner projection layout [B, L, 3, H, D] -> strided views
           x = (torch.randn(B, L, 3, H, D, device="cuda") * amp).to(dt)
@@ -62,11 +62,14 @@ def fuzz(cases, seed, log=print):
       for env in variants:
           out, lse = run(q, k, v, H, scale, env)
           d = (out.float() - base.float()).abs()
-          tol = 1e-2 * (1 if dt == torch.bfloat16 else 0.1) + ulp * base.float().abs()
+          # output error scales with |V| (P carries 8 / 11 bits); with FUZZ_AMP > 1 the softmax is nearly one-hot and
+          # 16-bit P underflow shows as a few more ulps in every kernel: twice the slack there
+          vs = max(1.0, amp) * (2.0 if amp > 1.0 else 1.0)
+          tol = vs * 1e-2 * (1 if dt == torch.bfloat16 else 0.1) + ulp * (2.0 if amp > 1.0 else 1.0) * base.float().abs()
           ok = bool(torch.isfinite(out).all()) and bool((d <= tol).all()) and bool(((lse - base_lse).abs() <= 2e-3 + 1e-4 * base_lse.abs()).all())
           if ref is not None:
               e = (out.reshape(B * H, L, D).cpu().double() - ref).abs()
-              ok = ok and bool((e <= 1e-2 + 1e-2 * ref.abs()).all())
+              ok = ok and bool((e <= max(1.0, amp) * 1e-2 + 1e-2 * ref.abs()).all())
           if not ok:
               bad += 1
               log(f"MISMATCH case {case}: B={B} H={H} L={L} D={D} {dt} scale={scale:.3g} env={env} max|d|={d.max().item():.3e}")
