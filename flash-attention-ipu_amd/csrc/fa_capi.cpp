@@ -31,8 +31,9 @@ int elt_size(int dtype) { return dtype == FA_DTYPE_F32 ? 4 : 2; }
 // upper bounds on the scheduling tile: the result is independent of them (semantic
 // contract), so a chunk larger than one workgroup can hold is subdivided into hardware tiles, and a
 // chunk that IS a hardware tile size is honoured exactly.  Tiles: 32 q rows per wave, 1..8 waves.
-// The default tile is 4 waves = 128 rows (4 workgroups per CU at D=64, 2 at D=128): fastest on every
-// shape measured, including grids that under-fill the chip.
+// The base tile is 4 waves = 128 rows (4 workgroups per CU at D=64, 2 at D=128): fastest on short sequences and
+// grids that under-fill the chip; long sequences on full grids get 256-row workgroups (make_plan / pick_kernel:
+// two query blocks per wave at head_dim 64, 8 waves at head_dim 128).
 int pick_waves(int64_t L, int64_t chunk_q) {
     int64_t want = chunk_q < L ? chunk_q : L;
     const char* env = getenv("FA_AMD_WAVES");

@@ -39,7 +39,7 @@ struct BwdParams {
     int64_t q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl, do_sb, do_sh, do_sl;
     int64_t dq_sb, dq_sh, dq_sl, dk_sb, dk_sh, dk_sl, dv_sb, dv_sh, dv_sl;
     int32_t G, G8, H, L, D;
-    int32_t nq_tiles;      // 128-row query blocks per group
+    int32_t nq_tiles;      // workgroup row tiles per group (32 rows x waves x query blocks per wave each)
     int32_t nk_tiles;      // 128-key blocks per group
     int32_t sched;         // groups per XCD bunch
     float scale, scale_log2;
