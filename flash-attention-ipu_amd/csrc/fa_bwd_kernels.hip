@@ -7,9 +7,10 @@
 // The reference runs one kv-outer / q-inner double loop that updates dQ in place; here the work is
 // split so that no gradient is ever summed across workgroups (deterministic, no atomics):
 //
-//   fa_bwd_dsum_kernel   Dsum[g,r] = sum_d dO[g,r,d] * O[g,r,d]           (FA.cpp:375-378)
 //   fa_bwd_dq_kernel     one workgroup per (group, 128 query rows): sweeps kv tiles <= diagonal,
-//                        dQ^T += K^T dS^T with the query row on the lane (same shape as the forward)
+//                        dQ^T += K^T dS^T with the query row on the lane (same shape as the forward);
+//                        its prologue also forms Dsum[g,r] = sum_d dO[g,r,d] * O[g,r,d] (FA.cpp:375-378)
+//                        for its own rows and publishes it to the workspace for the next kernel
 //   fa_bwd_dkdv_kernel   one workgroup per (group, 128 keys): sweeps 64-row query tiles >= diagonal,
 //                        dV^T += dO^T P and dK^T += Q^T dS with the KEY on the lane, so the score and
 //                        dP accumulators are already the B operands of those two products.
@@ -25,32 +26,6 @@
 #include "fa_device.h"
 
 namespace fa {
-
-// ---------------------------------------------------------------------------------------------
-// Dsum = rowsum(dO o O), one 16-byte chunk per thread, D/8 threads per row
-// ---------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(256) void fa_bwd_dsum_kernel(const BwdParams p) {
-    constexpr int TPR = D / 8;              // threads per row
-    constexpr int RPB = 256 / TPR;          // rows per block
-    typedef T vec8 __attribute__((ext_vector_type(8)));
-    const int64_t row_lin = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;   // over G*L
-    const int ch = threadIdx.x % TPR;
-    float acc = 0.f;
-    const bool ok = row_lin < (int64_t)p.G * p.L;
-    if (ok) {
-        const int g = (int)(row_lin / p.L), r = (int)(row_lin - (int64_t)g * p.L);
-        const int bb = g / p.H, hh = g - bb * p.H;
-        const T* op = (const T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)r * p.o_sl + ch * 8;
-        const T* gp = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh + (int64_t)r * p.do_sl + ch * 8;
-        const vec8 a = *(const vec8*)op, b = *(const vec8*)gp;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
-    }
-#pragma unroll
-    for (int off = TPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (ok && ch == 0) p.dsum[row_lin] = acc;
-}
 
 // ---------------------------------------------------------------------------------------------
 // shared pieces of the two gradient kernels
@@ -131,7 +106,22 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
         }
     }
     const float lse2 = p.lse[(int64_t)g * L + qr] * LOG2E;
-    const float dsum = p.dsum[(int64_t)g * L + qr];
+    // Dsum = rowsum(dO o O) of this lane's row (FA.cpp:375-378), from the dO fragments already in registers and the
+    // matching O fragments; the two half-waves hold the two halves of the row.  Published for fa_bwd_dkdv_kernel,
+    // which runs after this kernel on the same stream (this replaces a separate pass over dO and O).
+    float dsum;
+    {
+        const T* op = (const T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)qr * p.o_sl + 8 * h;
+        float acc = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const vec8 of = *(const vec8*)(op + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)of[j] * (float)dof[ks][j];
+        }
+        dsum = half_swap_sum(acc);
+        if (h == 0 && qrow < L) p.dsum[(int64_t)g * L + qrow] = dsum;
+    }
     const float c = p.scale_log2;
 
     // LDS-DMA geometry (pieces pc = wave + j*NWAVES of each image)
@@ -494,13 +484,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dkdv_kernel(const BwdParam
 }
 
 // ---------------------------------------------------------------------------------------------
-// host-side launcher: Dsum, then dQ, then dK/dV on the same stream (4-wave workgroups)
+// host-side launcher: dQ (which also publishes Dsum), then dK/dV on the same stream (4-wave workgroups)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
 static hipError_t launch_bwd_t(const BwdParams& p, hipStream_t stream) {
-    constexpr int RPB = 256 / (D / 8);
-    const int64_t rows = (int64_t)p.G * p.L;
-    hipLaunchKernelGGL((fa_bwd_dsum_kernel<T, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nk_tiles)), dim3(256), 0, stream, p);
     return hipGetLastError();
