@@ -294,6 +294,7 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
     p.nk_tiles = (int32_t)((L + 127) / 128);
     {
         int64_t bunch = (8ll << 20) / (2 * L * D * 2);
+        if (const char* sched = getenv("FA_AMD_SCHED")) { if (*sched) bunch = atoi(sched); }
         const int64_t ng = p.G8 / 8;
         if (bunch < 1) bunch = 1;
         if (bunch > ng) bunch = ng;
