@@ -59,6 +59,20 @@ bool tile_kernel_ok(int64_t D, int dtype, const void* const ptrs[4], const int64
     return true;
 }
 
+// fp32 inputs: the v_mfma_f32_32x32x2_f32 kernel (fa_fwd_f32.hip) needs head_dim 64 / 128 and 16-byte rows
+bool f32_kernel_ok(int64_t D, int dtype, const void* const ptrs[4], const int64_t* const strides[4]) {
+    if (dtype != FA_DTYPE_F32 || !(D == 64 || D == 128)) return false;
+    if (const char* e = getenv("FA_AMD_F32")) { if (e[0] == 'g') return false; }   // FA_AMD_F32=generic: A/B knob
+    for (int i = 0; i < 4; ++i) {
+        if (ptrs[i] && (reinterpret_cast<uintptr_t>(ptrs[i]) & 15)) return false;
+        if (strides[i]) {
+            for (int j = 0; j < 3; ++j)
+                if (strides[i][j] % 4) return false;
+        }
+    }
+    return true;
+}
+
 // Which MFMA kernel serves a request:
 //   'd' fa_fwd_dma_kernel   64-key tiles, LDS-DMA staged (fa_fwd_dma.hip)
 //   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic only
@@ -88,8 +102,8 @@ KernelChoice pick_kernel(int64_t G, int64_t L, int64_t D, int waves, int64_t chu
     return kc;
 }
 
-int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, bool tile_ok, bool skip_ok, fa_plan_t* plan,
-              KernelChoice* choice) {
+int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, bool tile_ok, bool f32_ok, bool skip_ok,
+              fa_plan_t* plan, KernelChoice* choice) {
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1 (got %lld, %lld, %lld)", (long long)G, (long long)L, (long long)D);
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     if (nq < 1 || L % nq != 0) return fail(FA_ERR_CHUNKS_Q, "sequence length %lld is not divisible by num_chunks_q=%d", (long long)L, nq);
@@ -119,6 +133,13 @@ int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_
         plan->grid = g8 * nqt;
         plan->lds_bytes = kc.which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * plan->waves
                                           : 2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64);
+    } else if (f32_ok) {
+        plan->kernel = 3;
+        plan->waves = 4;
+        plan->block_q = 128;
+        plan->block_kv = 32;
+        plan->grid = (G + 7) / 8 * 8 * ((L + 127) / 128);
+        plan->lds_bytes = 2 * 32 * (D + 1) * 4 + 2 * 32 * D * 4;
     } else {
         if (D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic kernel supports D <= 1024 (got %lld)", (long long)D);
         plan->kernel = 1;
@@ -185,7 +206,8 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
     const void* const ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
     const int64_t* const strides[4] = {nullptr, nullptr, nullptr, nullptr};
     // (the packed op has softmax scale 1: f16 keeps the per-tile row max, bf16 runs the skip-max arithmetic)
-    return make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_kernel_ok(D, dtype, ptrs, strides), dtype == FA_DTYPE_BF16, plan, nullptr);
+    return make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_kernel_ok(D, dtype, ptrs, strides),
+                     f32_kernel_ok(D, dtype, ptrs, strides), dtype == FA_DTYPE_BF16, plan, nullptr);
 }
 
 int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
@@ -215,7 +237,9 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     int skipmax = softmax_scale <= 0.25f ? 1 : 0;
     if (const char* sm = getenv("FA_AMD_SKIPMAX")) skipmax = atoi(sm);
     KernelChoice kc{'d', 1};
-    int rc = make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_ok, dtype == FA_DTYPE_BF16 || skipmax != 0, &plan, &kc);
+    bool f32_ok = f32_kernel_ok(D, dtype, ptrs, strides);
+    if (f32_ok && (L * k_strides[2] >= (1ll << 31) || L * v_strides[2] >= (1ll << 31))) f32_ok = false;
+    int rc = make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_ok, f32_ok, dtype == FA_DTYPE_BF16 || skipmax != 0, &plan, &kc);
     if (rc != FA_OK) return rc;
 
     fa::FwdParams p;
@@ -246,6 +270,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.skipmax = skipmax;
     hipError_t e = plan.kernel == 1    ? fa::launch_fwd_generic(p, dtype, (hipStream_t)stream)
+                   : plan.kernel == 3 ? fa::launch_fwd_f32(p, (hipStream_t)stream)
                    : kc.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, kc.qb, (hipStream_t)stream)
                    : kc.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves, kc.qb, (hipStream_t)stream)
                                      : fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream);

@@ -50,6 +50,7 @@ hipError_t launch_bwd_generic(const BwdParams& p, int dtype, hipStream_t stream)
 hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream);
+hipError_t launch_fwd_f32(const FwdParams& p, hipStream_t stream);   // fa_fwd_f32.hip
 
 hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);   // fa_fwd_pipe.hip
 double probe_mfma_peak(int dtype, int iters, int random_data);

@@ -70,7 +70,8 @@ enum {
 /* hardware tile the request was mapped to (fa_plan) */
 typedef struct fa_plan_t {
     int32_t kernel;      /* 0 = MFMA kernel, 64-key tiles (bf16/f16, D in {64,128}), 1 = generic kernel,
-                            2 = MFMA kernel, software-pipelined 32-key steps */
+                            2 = MFMA kernel, software-pipelined 32-key steps,
+                            3 = fp32 MFMA kernel (fp32 inputs, D in {64,128}, 16-byte rows) */
     int32_t block_q;     /* q rows per workgroup */
     int32_t block_kv;    /* keys per LDS tile / step */
     int32_t waves;       /* wavefronts per workgroup */

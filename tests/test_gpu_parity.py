@@ -128,18 +128,37 @@ def test_tiny_fp32_all_chunk_pairs(golden_dir, nq, nk):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("G,L,D", [(2, 6, 2), (2, 33, 7), (3, 70, 24), (2, 300, 80), (8, 256, 128), (1, 1500, 32), (2, 1, 64), (1, 1, 1)])
-def test_generic_kernel(dtype, G, L, D):
-    """Shapes only the generic kernel serves (fp32, odd D, L=1) - incl. t_cpp:256-259's fp32 8x256x128."""
+def test_generic_kernel(monkeypatch, dtype, G, L, D):
+    """Shapes the generic kernel serves (odd D, L=1, and fp32 at any head dim when the fp32 MFMA kernel is switched
+    off) - incl. t_cpp:256-259's fp32 8x256x128."""
     fa, native, _ = _mods()
     from oracle import frozen_randn
 
     if dtype != torch.float32 and D in (64, 128):
         pytest.skip("served by the MFMA kernel")
+    if dtype == torch.float32 and D in (64, 128):
+        monkeypatch.setenv("FA_AMD_F32", "generic")      # (the fp32 MFMA kernel has its own test below)
     qkv = (frozen_randn(SEED + D, (3, G, L, D)) * (1.0 if D > 16 else 2.0)).to(dtype)
     assert native.plan(G, L, D, dtype, 1, 1).kernel == 1
     ref, ref_lse = _oracle(qkv)
     out = fa.flash_attention_qkv_packed(qkv.cuda(), 1, 1)
     _check(out, ref, dtype, f"generic {dtype} {G}x{L}x{D}")
+
+
+@pytest.mark.parametrize("G,L,D", [(8, 256, 128), (2, 1, 64), (3, 600, 64), (2, 1000, 128), (9, 257, 64), (1, 4096, 64), (2, 33, 128)])
+def test_fp32_mfma_kernel(G, L, D):
+    """fp32 inputs at head_dim 64 / 128 run v_mfma_f32_32x32x2_f32 (fp32 products, fp32 accumulation): the reference's
+    FLOAT path with its own bound, max|delta| <= 1e-4 (t_cpp:249-262; 8x256x128 is its shape), plus the log-sum-exp."""
+    _, native, with_lse = _mods()
+    from oracle import frozen_randn
+
+    qkv = frozen_randn(SEED + 3 * L + D, (3, G, L, D))
+    assert native.plan(G, L, D, torch.float32, 1, 1).kernel == 3
+    ref, ref_lse = _oracle(qkv)
+    out, lse = with_lse(qkv.cuda(), 1, 1)
+    assert out.dtype == torch.float32
+    _check(out, ref, torch.float32, f"fp32 mfma {G}x{L}x{D}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=1e-4, rtol=1e-5)
 
 
 def test_golden_config1_and_g5(golden_dir):

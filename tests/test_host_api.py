@@ -92,7 +92,8 @@ def test_plan_maps_chunks_to_hardware_tiles(native):
     assert native.plan(4, 4096, 64, torch.float16, 128, 64).block_q == 32    # 32-row chunks honoured
     assert native.plan(5, 200, 64, torch.bfloat16, 1, 1).grid == 8 * 2       # G padded to the 8 XCDs
     assert native.plan(4, 6, 2, torch.float32, 3, 3).kernel == 1             # generic kernel
-    assert native.plan(4, 256, 64, torch.float32, 1, 1).kernel == 1
+    assert native.plan(4, 256, 64, torch.float32, 1, 1).kernel == 3             # fp32 MFMA kernel (D 64 / 128)
+    assert native.plan(4, 256, 80, torch.float32, 1, 1).kernel == 1
     assert native.plan(4, 256, 96, torch.bfloat16, 1, 1).kernel == 1
 
 
