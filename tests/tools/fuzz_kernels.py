@@ -75,6 +75,30 @@ def fuzz(cases, seed, log=print):
               log(f"MISMATCH case {case}: B={B} H={H} L={L} D={D} {dt} scale={scale:.3g} env={env} max|d|={d.max().item():.3e}")
       if case % 20 == 0:
           log(f"case {case}: B={B} H={H} L={L} D={D} {dt} ok so far, bad={bad}")
+  # fp32 inputs: the fp32 MFMA kernel against the generic kernel (FA_AMD_F32=generic) and the oracle
+  for case in range(max(1, cases // 5)):
+      D = rng.choice([64, 128])
+      L = rng.choice([rng.randint(1, 300), rng.randint(1, 1200)])
+      B, H = rng.randint(1, 2), rng.randint(1, 4)
+      scale = rng.choice([1.0, D ** -0.5])
+      torch.manual_seed(10_000 + case)
+      if rng.random() < 0.5:
+          x = torch.randn(B, L, 3, H, D, device="cuda")
+          q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+      else:
+          q, k, v = (torch.randn(B, H, L, D, device="cuda") for _ in range(3))
+      os.environ["FA_AMD_F32"] = "generic"
+      base, base_lse = run(q, k, v, H, scale, {})
+      os.environ.pop("FA_AMD_F32")
+      out, lse = run(q, k, v, H, scale, {})
+      ok = bool(torch.isfinite(out).all()) and (out - base).abs().max().item() <= 1e-4 and (lse - base_lse).abs().max().item() <= 1e-4
+      if L <= 500:
+          qkv = torch.stack([t.reshape(B * H, L, D) for t in (q, k, v)]).cpu()
+          ref, _ = dense_causal_attention_lse(qkv, scale=scale, compute_dtype=torch.float64)
+          ok = ok and (out.reshape(B * H, L, D).cpu().double() - ref).abs().max().item() <= 1e-4
+      if not ok:
+          bad += 1
+          log(f"MISMATCH fp32 case {case}: B={B} H={H} L={L} D={D} scale={scale:.3g} max|d|={(out - base).abs().max().item():.3e}")
   for kk in KNOBS:
       os.environ.pop(kk, None)
   return bad, len(variants)
