@@ -1,47 +1,87 @@
 #!/usr/bin/env python3
 """Headline benchmark: forward attention TFLOP/s, causal, L=4096, D=64 (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg2_f16|cfg3|cfg5_shard|cfg5]
 
-A step is one pass of the hot path over one batch of synthetic packed qkv that is already resident
-in HBM: `flash_attention_qkv_packed(qkv[3, 128, 4096, 64] bf16, 8, 8)` per GPU (batch 8 x 16 heads;
-chunk counts = the reference heuristic for L=4096, D=64).  With N > 1 every rank owns its own 128
-groups (weak scaling, groups are independent) and the only exchange is the RCCL all-gather of O,
-double-buffered so the gather of step s overlaps the kernel of step s+1.
+A step is one pass of the hot path over one batch of synthetic packed qkv that is already resident in HBM:
+`flash_attention_qkv_packed(qkv[3, 128, 4096, 64] bf16, 8, 8)` per GPU (batch 8 x 16 heads; chunk counts = the
+reference heuristic for L=4096, D=64).
+
+N > 1: one process per GPU over RCCL.  Started either by the driver's `python -m torch.distributed.run ... bench.py
+--gpus N` (WORLD_SIZE set) or plainly as `python bench.py --gpus N`: then this process - BEFORE it touches the GPU -
+starts N fresh rank processes itself (torch.distributed.run as a child; never an exec) and relays rank 0's JSON
+line and the exit code.
+  * default (cfg2, "scaling": "weak"): every rank owns its own 128 groups (groups are independent, FA.cpp:186); the
+    only exchange is the gather of O, double-buffered so the gather of step s overlaps the kernel of step s+1.
+  * --config cfg5 ("scaling": "strong") = BASELINE configs[4] as written: G = 64*32 = 2048 groups in total, L = 8192,
+    D = 64, G/N groups per rank, cut into slabs so the gather of slab s overlaps the kernel of slab s+1.
+`value` is end-to-end (gather included); `roofline.achieved` is kernel-only (HIP events around the launches) and
+`kernel_only_value` repeats it as a whole-job figure.
+
+N = 1 also reports, in `secondary`, the other single-GPU configs of BASELINE.json (cfg3 long context, the cfg5
+per-GPU shard shape, and cfg4: a GPT-2-small forward step through the automatic SDPA override with the attention
+share) - the headline stays cfg2.
 
 FLOPs = 2*G*L^2*D (causal convention); roofline = MFMA, dense bf16 peak 2.5 PFLOP/s.
 The cpu_baseline leg times the oracle's dense restatement of the reference CPU path
-(flash_attention_ipu/_impl/flash_attention_qkv_packed.py:48-53) on the host cores of the same box.
+(flash_attention_ipu/_impl/flash_attention_qkv_packed.py:48-53) on the host cores of the same box, fp32 and bf16.
 """
 
 import argparse
+import hashlib
 import json
 import os
 import pathlib
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = pathlib.Path(__file__).resolve().parent
-for _p in (ROOT, ROOT / "flash-attention-ipu_amd"):
+for _p in (ROOT, ROOT / "flash-attention-ipu_amd", ROOT / "demo"):
     if str(_p) not in sys.path:
         sys.path.insert(0, str(_p))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 CONFIGS = {
-    # name: (G per GPU, L, D, dtype, (nq, nk))
-    "cfg2": (128, 4096, 64, "bf16", (8, 8)),        # BASELINE configs[1] - the headline
+    # name: (G per GPU, L, D, dtype, (nq, nk))  -  per-GPU work fixed as N grows ("weak")
+    "cfg2": (128, 4096, 64, "bf16", (8, 8)),         # BASELINE configs[1] - the headline
     "cfg2_f16": (128, 4096, 64, "f16", (8, 8)),
-    "cfg3": (16, 32768, 128, "bf16", (16, 16)),     # long context
+    "cfg3": (16, 32768, 128, "bf16", (16, 16)),      # configs[2] long context
     "cfg5_shard": (256, 8192, 64, "bf16", (16, 8)),  # configs[4] per-GPU shard at 8 GPUs
+    # total work fixed ("strong"): G is the TOTAL group count, G/N per rank
+    "cfg5": (2048, 8192, 64, "bf16", (16, 8)),       # configs[4]: batch 64 x heads 32, seq 8192, head_dim 64
 }
+STRONG = {"cfg5"}
 PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-DT = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 
-def cpu_baseline(L, D, budget_s=12.0):
-    """Reference CPU path (dense fp32 torch, restated in oracle/) on this box's host cores."""
+def csrc_fingerprint() -> str:
+    """sha256 over the kernel sources: ties a profiled HBM-traffic figure to the code that was profiled."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "flash-attention-ipu_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h", ".cpp"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes, started before any GPU call."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(pathlib.Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode      # stdout/stderr inherited: rank 0's JSON line passes through
+
+
+def cpu_baseline(L, D, budget_s=9.0):
+    """Reference CPU path (dense torch, restated in oracle/) on this box's host cores: fp32 leg (the reported
+    value) and bf16 leg, each a bounded sample."""
+    import torch
     from oracle import dense_causal_attention
 
     cores = os.cpu_count() or 1
@@ -53,22 +93,175 @@ def cpu_baseline(L, D, budget_s=12.0):
     torch.set_num_threads(cores)
     slab = 8
     gen = torch.Generator().manual_seed(0)
-    qkv = torch.randn(3, slab, L, D, generator=gen)
-    dense_causal_attention(qkv)  # warm-up
-    times = []
-    t_start = time.perf_counter()
-    while time.perf_counter() - t_start < budget_s and len(times) < 30:
-        t0 = time.perf_counter()
-        dense_causal_attention(qkv)
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+    qkv32 = torch.randn(3, slab, L, D, generator=gen)
     flops = 2.0 * slab * L * L * D
+    legs = {}
+    for name, qkv in (("fp32", qkv32), ("bf16", qkv32.bfloat16())):
+        dense_causal_attention(qkv)  # warm-up
+        times = []
+        t_start = time.perf_counter()
+        while time.perf_counter() - t_start < budget_s and len(times) < 30:
+            t0 = time.perf_counter()
+            dense_causal_attention(qkv)
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        med = times[len(times) // 2]
+        legs[name] = {"value": round(flops / med / 1e12, 5), "reps": len(times), "median_ms_per_slab": round(med * 1e3, 1)}
     return {
-        "value": round(flops / med / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-        "sample": f"{len(times)} reps of a {slab}-group slab (of 128) at L={L}, D={D}, fp32 dense torch "
-                  f"restatement of fa.py:48-53, median {med * 1e3:.1f} ms/slab, scaled linearly in G",
+        "value": legs["fp32"]["value"], "unit": "TFLOP/s", "cores": cores, "kind": "port",
+        "sample": f"{legs['fp32']['reps']} reps of a {slab}-group slab (of 128) at L={L}, D={D}, fp32 dense torch "
+                  f"restatement of fa.py:48-53, median {legs['fp32']['median_ms_per_slab']} ms/slab, scaled linearly in G",
+        "bf16": {"value": legs["bf16"]["value"], "unit": "TFLOP/s",
+                 "sample": f"{legs['bf16']['reps']} reps of the same slab in bf16 (the reference CPU path run on bf16 "
+                           f"tensors), median {legs['bf16']['median_ms_per_slab']} ms/slab"},
     }
+
+
+def time_kernel(fn, steps, warmup, ramp_ms=0.0):
+    """avg ms per call of fn() on the current stream: untimed ramp + warm-up, then HIP events around `steps` calls."""
+    import torch
+
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    i = 0
+    while (time.perf_counter() - t0) * 1e3 < ramp_ms:
+        fn()
+        i += 1
+        if i % 16 == 0:
+            torch.cuda.synchronize()
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def secondary_attention(name, dev, steps=20, warmup=5):
+    """One of the other single-GPU BASELINE configs through the same op: value + roofline (kernel-only)."""
+    import torch
+    import flash_attention_amd as fa
+    from flash_attention_amd._impl import _native
+
+    G, L, D, dname, (nq, nk) = CONFIGS[name]
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dname]
+    qkv = torch.randn(3, G, L, D, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(dtype)
+    ms = time_kernel(lambda: fa.flash_attention_qkv_packed(qkv, nq, nk), steps, warmup, ramp_ms=60.0)
+    flops = 2.0 * G * L * L * D
+    plan = _native.plan(G, L, D, dtype, nq, nk)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"metric": f"fwd_attention_tflops_causal_L{L}_D{D}", "value": round(tf, 2), "unit": "TFLOP/s", "dtype": dname,
+            "config": {"workload": f"{name}: packed qkv [3,{G},{L},{D}] {dname}, causal, num_chunks=({nq},{nk})",
+                       "tile": f"{plan.block_q} query rows x {plan.block_kv} keys ({plan.waves} waves, {plan.qb} query blocks per wave)"},
+            "steps": steps, "warmup": warmup,
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_TFLOPS, 4), "traffic": profiled_traffic(name, plan)[0],
+                         "kernel": kernel_name(plan), "avg_launch_ms": round(ms, 4), "algorithmic_bytes": 4 * G * L * D * 2}}
+
+
+def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
+    """BASELINE configs[3]: GPT-2 small (12 layers, 12 heads, n_embd 768, T = 1024) forward step through the
+    automatic SDPA override; whole-step time and the attention share (HIP events around the 12 op calls)."""
+    import torch
+    import torch.nn.functional as F
+    import flash_attention_amd.auto  # noqa: F401  (patches F.scaled_dot_product_attention)
+    from model import TinyGPT, gpt2_init_
+
+    T, H, hs, layers = 1024, 12, 64, 12
+    torch.manual_seed(0)
+    model = gpt2_init_(TinyGPT(vocab=50304, block=T, n_layer=layers, n_head=H, n_embd=H * hs)).to(dev).eval()
+    idx = torch.randint(0, 50304, (batch, T), device=dev)
+    patched = F.scaled_dot_product_attention
+    spans = []
+
+    def timed_sdpa(*a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = patched(*a, **kw)
+        e1.record()
+        spans.append((e0, e1))
+        return out
+
+    def fwd():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return model(idx)
+
+    def run(n, instrument):
+        F.scaled_dot_product_attention = timed_sdpa if instrument else patched
+        try:
+            for _ in range(warmup):
+                fwd()
+            spans.clear()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fwd()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        finally:
+            F.scaled_dot_product_attention = patched
+
+    step_ms = run(steps, False)
+    run(steps, True)
+    attn_ms = sum(a.elapsed_time(b) for a, b in spans) / steps
+    F.scaled_dot_product_attention = patched.__wrapped__
+    try:
+        for _ in range(warmup):
+            fwd()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fwd()
+        e1.record()
+        torch.cuda.synchronize()
+        stock_ms = e0.elapsed_time(e1) / steps
+    finally:
+        F.scaled_dot_product_attention = patched
+    flops = layers * 2.0 * batch * H * T * T * hs
+    tf = flops / (attn_ms * 1e-3) / 1e12
+    return {"metric": "gpt2_small_fwd_step_ms_T1024", "value": round(step_ms, 3), "unit": "ms", "higher_is_better": False,
+            "dtype": "bf16", "steps": steps, "warmup": warmup,
+            "config": {"workload": f"cfg4: GPT-2 small forward (12 layers, 12 heads, n_embd 768, T=1024, batch {batch}, vocab 50304, "
+                                   f"bf16 autocast, random init, synthetic tokens) through `import flash_attention_amd.auto`"},
+            "tokens_per_s": round(batch * T / (step_ms * 1e-3)),
+            "attention_ms_per_step": round(attn_ms, 3), "attention_share": round(attn_ms / step_ms, 4),
+            "attention_tflops": round(tf, 2),
+            "fwd_step_ms_stock_torch_sdpa": round(stock_ms, 3),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None, "kernel": "fa_fwd_dma_kernel (12 launches per step, "
+                         f"[{batch},12,1024,64] head-inner views)", "avg_launch_ms": round(attn_ms / layers, 4),
+                         "algorithmic_bytes": 4 * batch * H * T * hs * 2}}
+
+
+def kernel_name(plan):
+    return {0: "fa_fwd_dma_kernel", 1: "fa_fwd_generic_kernel", 2: "fa_fwd_pipe_kernel", 3: "fa_fwd_f32_kernel"}[plan.kernel]
+
+
+def profiled_traffic(config, plan):
+    """HBM bytes per launch from the PMC passes of scripts/profile.sh (profiles/hbm_traffic.json), valid only for
+    the kernel sources and the kernel it was measured on - otherwise null with the reason."""
+    tfile = ROOT / "profiles" / "hbm_traffic.json"
+    if not tfile.exists():
+        return None, "no profiles/hbm_traffic.json"
+    try:
+        rec = json.loads(tfile.read_text()).get(config)
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable profiles/hbm_traffic.json: {e}"
+    if not rec:
+        return None, f"no PMC record for {config}"
+    if rec.get("csrc_sha256_16") != csrc_fingerprint():
+        return None, f"PMC record is for kernel sources {rec.get('csrc_sha256_16')}, this build is {csrc_fingerprint()}: re-run scripts/profile.sh"
+    if rec.get("kernel") and not rec["kernel"].startswith(kernel_name(plan)):
+        return None, f"PMC record is for {rec.get('kernel')}, this run launched {kernel_name(plan)}"
+    return rec.get("hbm_bytes_per_launch"), f"rocprofv3 PMC passes ({rec.get('source', 'profiles/')}), FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE"
 
 
 def main():
@@ -81,22 +274,38 @@ def main():
                          "to reach its sustained clock (measured: 784 TFLOP/s after 10 warm-up launches, 886 after 400)")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of O (kernel only)")
+    ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the cfg3 / cfg4 / cfg5-shard records")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gather of O (kernel only)")
+    ap.add_argument("--gather", default="allgather", choices=("allgather", "direct", "root"),
+                    help="N>1: RCCL all-gather (default), direct point-to-point gather, or gather to rank 0")
+    ap.add_argument("--slabs", type=int, default=8, help="cfg5: slabs per rank (gather of slab s under the kernel of slab s+1)")
+    ap.add_argument("--print-csrc-fingerprint", action="store_true")
     args = ap.parse_args()
+    if args.print_csrc_fingerprint:
+        print(csrc_fingerprint())
+        return 0
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)          # (nothing above has imported torch.cuda or made a HIP call)
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no fallback)")
     # FA_BENCH_REHEARSE=1: developer rehearsal of the N>1 control flow on a ONE-GPU box (all ranks on
     # cuda:0, gloo instead of RCCL).  Never set by the driver; the numbers it prints mean nothing.
     rehearse = os.environ.get("FA_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -104,39 +313,71 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     import flash_attention_amd as fa
     from flash_attention_amd._impl import _native
-    from flash_attention_amd.distributed import gather_output
+    from flash_attention_amd.distributed import SlabGather, gather_output
 
     assert _native.library_path() is not None
-    G, L, D, dname, (nq, nk) = CONFIGS[args.config]
+    DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+    Gc, L, D, dname, (nq, nk) = CONFIGS[args.config]
+    strong = args.config in STRONG
+    if strong and Gc % (world * args.slabs) != 0:
+        raise SystemExit(f"{args.config}: {Gc} groups do not split over {world} ranks x {args.slabs} slabs")
+    G = Gc // world if strong else Gc              # groups on this rank
     dtype = DT[dname]
     gen = torch.Generator(device=dev).manual_seed(rank)
     qkv = torch.randn(3, G, L, D, device=dev, generator=gen).to(dtype)
-    flops_step = 2.0 * G * L * L * D           # per GPU per step
-    plan = _native.plan(G, L, D, dtype, nq, nk)
+    flops_step = 2.0 * G * L * L * D               # per GPU per step
+    g_launch = G // args.slabs if strong else G    # groups per kernel launch
+    plan = _native.plan(g_launch, L, D, dtype, nq, nk)
 
     do_gather = world > 1 and not args.no_gather
-    gathered = [torch.empty(world * G, L, D, dtype=dtype, device=dev) for _ in range(2)] if do_gather else None
-    pending = [None, None]
+    use_gloo = rehearse
+    launches_per_step = args.slabs if strong else 1
+    kernel_events = []                             # (start, end) per launch inside the timed region (N > 1)
+    record = [False]
 
-    def step(i):
-        out = fa.flash_attention_qkv_packed(qkv, nq, nk)
-        if do_gather:
+    if strong:
+        sg = SlabGather(G, L, D, dtype, dev if not use_gloo else dev, slabs=args.slabs, mode=args.gather, gather=do_gather and not use_gloo)
+
+        def step(i):
+            if record[0]:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            out = sg.run(qkv, nq, nk)
+            if record[0]:
+                e1.record()
+                kernel_events.append((e0, e1))
+            return out
+
+        def drain():
+            sg.wait()
+    else:
+        gathered = [torch.empty(world * G, L, D, dtype=dtype, device=dev) for _ in range(2)] if do_gather and not use_gloo else None
+        pending = [None, None]
+
+        def step(i):
             b = i & 1
-            if pending[b] is not None:
+            if gathered is not None and pending[b] is not None:
                 pending[b][1].wait()           # buffer b is free again (gather of step i-2 done)
-            _, work = gather_output(out, out=gathered[b], async_op=True)
-            pending[b] = (out, work)           # keep `out` alive until its gather completes
-        return out
+            if record[0]:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            out = fa.flash_attention_qkv_packed(qkv, nq, nk)
+            if record[0]:
+                e1.record()
+                kernel_events.append((e0, e1))
+            if gathered is not None:
+                _, work = gather_output(out, out=gathered[b], async_op=True, mode=args.gather)
+                pending[b] = (out, work)       # keep `out` alive until its gather completes
+            return out
 
-    def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b][1].wait()
-                pending[b] = None
+        def drain():
+            for b in range(2):
+                if pending[b] is not None:
+                    pending[b][1].wait()
+                    pending[b] = None
 
     step(0)                      # first call pays one-off host costs (library load, op registration)
     drain()
@@ -158,93 +399,127 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
 
+    record[0] = world > 1 and not strong          # per-launch events only where a collective shares the stream
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
         step(i)
-    ev1.record()                                # kernels only: recorded on the launch stream before the drain
+    ev1.record()
     drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # avg launch duration incl. launch gaps (HIP events)
+    record[0] = False
+    if kernel_events:      # N > 1, weak: kernel-only = events right around each launch (the waits on gathers sit before them)
+        kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / len(kernel_events)
+        kernel_note = "HIP events around each launch (exchange stalls excluded)"
+    else:
+        kernel_ms = ev0.elapsed_time(ev1) / (args.steps * launches_per_step)   # avg launch duration incl. launch gaps (HIP events)
+        kernel_note = "HIP events over the timed region / launches" + (" (includes stalls on the slab gathers)" if strong and do_gather else "")
+    if strong and do_gather:
+        # kernel-only for the slab pipeline: the same slabs, no gather, a few untimed-region repeats
+        sgk = SlabGather(G, L, D, dtype, dev, slabs=args.slabs, gather=False)
+        kernel_ms = time_kernel(lambda: sgk.run(qkv, nq, nk), max(3, args.steps // 4), 2) / args.slabs
+        kernel_note = "HIP events over a gather-free repeat of the same slab launches"
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 and not use_gloo:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elif world > 1:
+        tc = t.cpu()
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        t = tc
     elapsed, kernel_ms = t[0].item(), t[1].item()
 
-    measured_peak = measured_peak_random = None
+    rc = 0
     if rank == 0:
+        lib_ = _native.load_native_library()
         with torch.cuda.device(dev):
-            lib_ = _native.load_native_library()
             mp = lib_.fa_probe_mfma_peak(_native.FA_DTYPE[dtype], 4000, 0)
             mpr = lib_.fa_probe_mfma_peak(_native.FA_DTYPE[dtype], 40000, 1)   # ~30 ms per repetition: clock settles
         measured_peak = round(mp, 1) if mp > 0 else None
         measured_peak_random = round(mpr, 1) if mpr > 0 else None
-    # which core clock does the device hold under this load?  (untimed repeat of the steps with a one-wave clock
-    # sampler on a side stream: the kernels are power-bound; nominal peak assumes 2400 MHz)
-    clock_mhz = None
-    if rank == 0:
+        # which core clock does the device hold under this load?  (untimed repeat of the kernel with a one-wave clock
+        # sampler on a side stream: the kernels are power-bound; nominal peak assumes 2400 MHz)
+        qk = qkv[:, :g_launch].contiguous() if strong else qkv
         side = torch.cuda.Stream(device=dev)
         buf = torch.zeros(2, dtype=torch.int64, device=dev)
-        n_rep = max(args.steps, int(60.0 / max(kernel_ms, 1e-3)))          # >= 60 ms of load
+        n_rep = max(8 + 2, int(60.0 / max(kernel_ms, 1e-3)))                   # >= 60 ms of load
         for i in range(n_rep):
-            fa.flash_attention_qkv_packed(qkv, nq, nk)                      # (kernel only: no collective on one rank)
-            if i == 8:                                                      # the load is running: start sampling
-                _native.load_native_library().fa_probe_clock(buf.data_ptr(), 15000, side.cuda_stream)   # ~30-40 ms
+            fa.flash_attention_qkv_packed(qk, nq, nk)                           # (kernel only: no collective on one rank)
+            if i == 8:                                                          # the load is running: start sampling
+                lib_.fa_probe_clock(buf.data_ptr(), 15000, side.cuda_stream)   # ~30-40 ms
         torch.cuda.synchronize()
         cyc, ticks = (int(x) for x in buf.tolist())
         clock_mhz = round(cyc / ticks * 100.0) if ticks > 0 else None
-    if rank == 0:
+
         total_tflops = world * flops_step * args.steps / elapsed / 1e12
-        achieved = flops_step / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        tfile = ROOT / "profiles" / "hbm_traffic.json"
-        if tfile.exists():
-            try:
-                traffic = json.loads(tfile.read_text()).get(args.config, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        flops_launch = 2.0 * g_launch * L * L * D
+        achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
+        traffic, traffic_note = profiled_traffic(args.config if not strong else "cfg5_slab", plan)
+        metric = "fwd_attention_tflops_causal_L4096_D64" if args.config.startswith("cfg2") else f"fwd_attention_tflops_causal_L{L}_D{D}_{args.config}"
+        exchange = "none"
+        if do_gather:
+            exchange = {"allgather": "rccl all-gather of O", "direct": "direct point-to-point gather of O (rccl send/recv)",
+                        "root": "gather of O to rank 0 (rccl send/recv)"}[args.gather]
+            exchange += f", {args.slabs} slabs per rank, gather of slab s under the kernel of slab s+1" if strong else ", double-buffered: gather of step s under the kernel of step s+1"
         line = {
-            "metric": "fwd_attention_tflops_causal_L4096_D64" if args.config.startswith("cfg2") else f"fwd_attention_tflops_{args.config}",
+            "metric": metric,
             "value": round(total_tflops, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dname,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": dname,
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: packed qkv [3,{G},{L},{D}] {dname} per GPU, causal, "
-                                   f"num_chunks=({nq},{nk}), flash_attention_qkv_packed forward",
+            "config": {"workload": f"{args.config}: packed qkv [3,{G},{L},{D}] {dname} per GPU"
+                                   + (f" ({Gc} groups in total over {world} GPUs)" if strong else "")
+                                   + f", causal, num_chunks=({nq},{nk}), flash_attention_qkv_packed forward",
                        "groups_per_gpu": G, "seq_len": L, "head_dim": D,
-                       "tile": f"{plan.block_q} query rows x {plan.block_kv} keys per workgroup step ({plan.waves} waves)",
-                       "exchange": "rccl all-gather of O, overlapped" if do_gather else "none",
+                       "tile": f"{plan.block_q} query rows x {plan.block_kv} keys per workgroup step ({plan.waves} waves, {plan.qb} query blocks per wave)",
+                       "plan_source": {0: "built-in rules", 1: "measured tuning table", 2: "debug override"}.get(plan.source),
+                       "exchange": exchange,
                        "flops_per_step_per_gpu": flops_step,
                        "device": {"name": torch.cuda.get_device_name(dev),
                                   "compute_units": torch.cuda.get_device_properties(dev).multi_processor_count,
                                   "clock_mhz": getattr(torch.cuda.get_device_properties(dev), "clock_rate", 0) // 1000 or None}},
             "pct_mfma_peak": round(100.0 * total_tflops / (world * PEAK_TFLOPS), 2),
+            "kernel_only_value": round(world * achieved, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "shader_clock_mhz_under_load": clock_mhz,
                          "frac_at_that_clock": round(achieved / (PEAK_TFLOPS * clock_mhz / 2400.0), 4) if clock_mhz else None,
                          "measured_mfma_peak": measured_peak,
                          "frac_of_measured_peak": round(achieved / measured_peak, 4) if measured_peak else None,
                          "measured_mfma_peak_random_operands": measured_peak_random,
                          "frac_of_measured_peak_random_operands": round(achieved / measured_peak_random, 4) if measured_peak_random else None,
-                         "kernel": "fa_fwd_pipe_kernel" if plan.kernel == 2 else "fa_fwd_dma_kernel", "avg_launch_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes": 4 * G * L * D * 2},
+                         "kernel": kernel_name(plan), "avg_launch_ms": round(kernel_ms, 4), "avg_launch_note": kernel_note,
+                         "flops_per_launch": flops_launch,
+                         "algorithmic_bytes": 4 * g_launch * L * D * 2},
         }
+        if world == 1 and not args.no_secondary and not strong:
+            sec = {}
+            for name in ("cfg3", "cfg5_shard"):
+                if name != args.config:
+                    try:
+                        sec[name] = secondary_attention(name, dev)
+                    except Exception as e:  # noqa: BLE001  (a secondary record must never cost the headline)
+                        sec[name] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                sec["cfg4_gpt2_fwd"] = secondary_gpt2_forward(dev)
+            except Exception as e:  # noqa: BLE001
+                sec["cfg4_gpt2_fwd"] = {"error": f"{type(e).__name__}: {e}"}
+            line["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(L, D)
+            line["cpu_baseline"] = cpu_baseline(4096, 64) if args.config.startswith("cfg2") else cpu_baseline(min(L, 4096), D)
         elif world > 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -15,13 +15,13 @@ import sys
 import time
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd"), str(ROOT / "tests")]
+sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd"), str(ROOT / "demo")]
 
 import torch
 import torch.nn.functional as F
 from torch.nn.attention import SDPBackend, sdpa_kernel
 
-from test_gpu_nanogpt import TinyGPT  # the GPT-2-small-shaped model used by the tests
+from model import TinyGPT  # demo/model.py
 
 
 def run(model, idx, tgt, steps, ctx):

@@ -12,12 +12,12 @@ import pathlib
 import sys
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd"), str(ROOT / "tests")]
+sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd"), str(ROOT / "demo")]
 
 import torch
 import torch.nn.functional as F
 
-from test_gpu_nanogpt import TinyGPT
+from model import TinyGPT  # demo/model.py
 
 
 def make_batch(batch, block, vocab, gen):

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dq_kernel(const Bwd
     float acc[GB_MAXD_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < GB_MAXD_PER_THREAD; ++i) acc[i] = 0.f;
-    const int nkeys = row + 1;
+    const int nkeys = p.causal ? row + 1 : p.L;
     for (int k0 = 0; k0 < nkeys; k0 += GB_CHUNK) {
         const int kn = nkeys - k0 < GB_CHUNK ? nkeys - k0 : GB_CHUNK;
         for (int c = tid; c < kn; c += GB_THREADS) {
@@ -104,11 +104,12 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dkdv_kernel(const B
     float ak[GB_MAXD_PER_THREAD], av[GB_MAXD_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < GB_MAXD_PER_THREAD; ++i) { ak[i] = 0.f; av[i] = 0.f; }
-    const int nrows = L - key;   // rows key .. L-1 can see this key
+    const int row_lo = p.causal ? key : 0;   // causal: rows key .. L-1 can see this key; otherwise every row
+    const int nrows = L - row_lo;
     for (int r0 = 0; r0 < nrows; r0 += GB_CHUNK) {
         const int rn = nrows - r0 < GB_CHUNK ? nrows - r0 : GB_CHUNK;
         for (int c = tid; c < rn; c += GB_THREADS) {
-            const int row = key + r0 + c;
+            const int row = row_lo + r0 + c;
             const T* qp = qg + (int64_t)row * p.q_sl;
             const T* gp = gg + (int64_t)row * p.do_sl;
             float s = 0.f, dp = 0.f;
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dkdv_kernel(const B
             const int d = tid + i * GB_THREADS;
             if (d < D) {
                 float a = ak[i], b = av[i];
-                const T* qp = qg + (int64_t)(key + r0) * p.q_sl + d;
-                const T* gp = gg + (int64_t)(key + r0) * p.do_sl + d;
+                const T* qp = qg + (int64_t)(row_lo + r0) * p.q_sl + d;
+                const T* gp = gg + (int64_t)(row_lo + r0) * p.do_sl + d;
                 for (int c = 0; c < rn; ++c) {
                     a = __builtin_fmaf(dsbuf[c], (float)qp[(int64_t)c * p.q_sl], a);
                     b = __builtin_fmaf(pbuf[c], (float)gp[(int64_t)c * p.do_sl], b);
@@ -150,10 +151,10 @@ template <typename T>
 static hipError_t launch_bwd_generic_t(const BwdParams& p, hipStream_t stream) {
     const unsigned rows = (unsigned)((int64_t)p.G * p.L);
     const size_t dyn = 2 * (size_t)p.D * sizeof(float);
-    hipLaunchKernelGGL((fa_bwd_generic_dsum_kernel<T>), dim3(rows), dim3(64), 0, stream, p);
-    hipLaunchKernelGGL((fa_bwd_generic_dq_kernel<T>), dim3(rows), dim3(GB_THREADS), dyn, stream, p);
-    hipLaunchKernelGGL((fa_bwd_generic_dkdv_kernel<T>), dim3(rows), dim3(GB_THREADS), dyn, stream, p);
-    return hipGetLastError();
+    hipError_t e = launch1((const void*)(fa_bwd_generic_dsum_kernel<T>), dim3(rows), dim3(64), 0, stream, p);
+    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_generic_dq_kernel<T>), dim3(rows), dim3(GB_THREADS), dyn, stream, p);
+    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_generic_dkdv_kernel<T>), dim3(rows), dim3(GB_THREADS), dyn, stream, p);
+    return e;
 }
 
 hipError_t launch_bwd_generic(const BwdParams& p, int dtype, hipStream_t stream) {

@@ -161,8 +161,10 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     const int trb0 = rowin8 * 64 + ((c4 ^ h) << 4) + (lane & 1) * 8;
     const int trb1 = rowin8 * 64 + ((c4 ^ (2 + h)) << 4) + (lane & 1) * 8;
 
-    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    const bool causal = p.causal != 0;             // 0: no mask, every key (keys past L are masked)
+    const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
     const int n_tiles = (kv_end + BK - 1) / BK;
+    const int wave_last = causal ? q_row0 : L - 1, wave_kv_last = causal ? q_row0 + 31 : L - 1, klim = causal ? qrow : L - 1;
 
     f32x16 dq[DT];
 #pragma unroll
@@ -173,7 +175,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 #define FA_DQ_TILE(T_, BUF_)                                                                       \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
-        if (wave_active && kv0 <= q_row0 + 31) {                                                   \
+        if (wave_active && kv0 <= wave_kv_last) {                                                  \
             const unsigned char* kb_ = smem + (BUF_) * IMG_B;                                      \
             const unsigned char* vb_ = smem_v + (BUF_) * IMG_B;                                    \
             f32x16 s0, s1, t0, t1;                                                                 \
@@ -184,11 +186,11 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
                 t0 = E::mfma(*(const vec8*)(vb_ + a_rd[ks]), dof[ks], t0);                         \
                 t1 = E::mfma(*(const vec8*)(vb_ + 2048 + a_rd[ks]), dof[ks], t1);                  \
             }                                                                                      \
-            if (kv0 + BK - 1 > q_row0) {                                                           \
+            if (kv0 + BK - 1 > wave_last) {                                                        \
                 _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                   \
                     const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;                          \
-                    if (key > qrow) s0[e] = -INFINITY;                                             \
-                    if (key + 32 > qrow) s1[e] = -INFINITY;                                        \
+                    if (key > klim) s0[e] = -INFINITY;                                             \
+                    if (key + 32 > klim) s1[e] = -INFINITY;                                        \
                 }                                                                                  \
             }                                                                                      \
             /* dS^T = P^T o (dP^T - Dsum), P^T = 2^(S^T c - lse2): the row constants are lane scalars */ \
@@ -351,7 +353,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 
     // query tiles that can see this workgroup's keys: i0 .. n_qt-1
     const int n_qt = (L + BQ - 1) / BQ;
-    const int i0 = (kb * BKW) / BQ;
+    const bool causal = p.causal != 0;             // 0: every query tile sees this workgroup's keys, no mask
+    const int i0 = causal ? (kb * BKW) / BQ : 0;
 
     f32x16 dk[DT], dv[DT];
 #pragma unroll
@@ -363,7 +366,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #define FA_DKDV_TILE(I_, BUF_)                                                                     \
     {                                                                                              \
         const int q0 = (I_) * BQ;                                                                  \
-        if (wave_active && q0 + BQ - 1 >= key0) {                                                  \
+        if (wave_active && (!causal || q0 + BQ - 1 >= key0)) {                                     \
             const unsigned char* qb_ = smem + (BUF_) * IMG_B;                                      \
             const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
             const float* rc_ = rowc + (BUF_) * 128;                                                \
@@ -376,7 +379,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 t0 = E::mfma(*(const vec8*)(gb_ + a_rd[ks]), vf[ks], t0);                          \
                 t1 = E::mfma(*(const vec8*)(gb_ + 2048 + a_rd[ks]), vf[ks], t1);                   \
             }                                                                                      \
-            if (q0 < key0 + 31) { /* diagonal tile: query < key is masked */                       \
+            if (causal && q0 < key0 + 31) { /* diagonal tile: query < key is masked */             \
                 _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                   \
                     const int qq = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;                            \
                     if (qq < key) s0[e] = -INFINITY;                                               \
@@ -488,9 +491,9 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dkdv_kernel(const BwdParam
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
 static hipError_t launch_bwd_t(const BwdParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nk_tiles)), dim3(256), 0, stream, p);
-    return hipGetLastError();
+    hipError_t e = launch1((const void*)(fa_bwd_dq_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
+    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nk_tiles)), dim3(256), 0, stream, p);
+    return e;
 }
 
 hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream) {

@@ -5,12 +5,15 @@
 #include "flash_attention_amd.h"
 
 #include <math.h>
+#include <atomic>
+#include <mutex>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
 #include "fa_params.h"
+#include "fa_tuning_table.h"
 
 namespace {
 
@@ -27,131 +30,190 @@ int fail(int code, const char* fmt, ...) {
 
 int elt_size(int dtype) { return dtype == FA_DTYPE_F32 ? 4 : 2; }
 
+// Developer / test overrides of the tile plan.  They are NOT read per launch: the FA_AMD_* environment variables
+// are parsed ONCE (first use), afterwards only fa_debug_set_option() changes them (tests force every kernel
+// variant through it).  Every field is a relaxed atomic, 0 / -1 = "no override", so concurrent fa_fwd calls see
+// either the old or the new value of one knob and never a torn one; fa_plan() and fa_fwd() go through the same
+// make_plan(), so a reported plan is the launched plan.
+struct Options {
+    std::atomic<int> kernel{0};     // 0 auto, 'd' | 'p' | 't'
+    std::atomic<int> qb{0};         // 0 auto, 1 | 2 query blocks per wave
+    std::atomic<int> waves{0};      // 0 auto, 1 | 2 | 4 | 8
+    std::atomic<int> sched{0};      // 0 auto, else groups per L2 bunch
+    std::atomic<int> skipmax{-1};   // -1 auto, 0 | 1
+    std::atomic<int> f32_generic{0};
+    std::atomic<int> table{1};      // 1 = consult the measured tuning table (fa_tuning_table.h), 0 = built-in rules only
+};
+Options g_opt;
+std::once_flag g_opt_once;
+
+int parse_kernel(const char* v) { return (v && (v[0] == 't' || v[0] == 'd' || v[0] == 'p')) ? v[0] : 0; }
+
+const Options& options() {
+    std::call_once(g_opt_once, [] {
+        if (const char* e = getenv("FA_AMD_KERNEL")) g_opt.kernel = parse_kernel(e);
+        if (const char* e = getenv("FA_AMD_QB")) g_opt.qb = atoi(e);
+        if (const char* e = getenv("FA_AMD_WAVES")) g_opt.waves = atoi(e);
+        if (const char* e = getenv("FA_AMD_SCHED")) g_opt.sched = atoi(e);
+        if (const char* e = getenv("FA_AMD_SKIPMAX")) { if (*e) g_opt.skipmax = atoi(e); }
+        if (const char* e = getenv("FA_AMD_F32")) g_opt.f32_generic = e[0] == 'g';
+        if (const char* e = getenv("FA_AMD_TABLE")) { if (*e) g_opt.table = atoi(e); }
+    });
+    return g_opt;
+}
+
 // num_chunks -> hardware tile.  The reference's chunk sizes (L/num_chunks, FA.cpp:193-195) are
 // upper bounds on the scheduling tile: the result is independent of them (semantic
 // contract), so a chunk larger than one workgroup can hold is subdivided into hardware tiles, and a
-// chunk that IS a hardware tile size is honoured exactly.  Tiles: 32 q rows per wave, 1..8 waves.
+// chunk that IS a hardware tile size is honoured exactly.  q tiles: 32 rows per wave and query block, 1..8 waves;
+// kv steps: 64-key tiles or 32-key pipelined steps.
 // The base tile is 4 waves = 128 rows (4 workgroups per CU at D=64, 2 at D=128): fastest on short sequences and
-// grids that under-fill the chip; long sequences on full grids get 256-row workgroups (make_plan / pick_kernel:
-// two query blocks per wave at head_dim 64, 8 waves at head_dim 128).
-int pick_waves(int64_t L, int64_t chunk_q) {
-    int64_t want = chunk_q < L ? chunk_q : L;
-    const char* env = getenv("FA_AMD_WAVES");
-    if (env && *env) {
-        int w = atoi(env);
-        if (w == 1 || w == 2 || w == 4 || w == 8) return w;
-    }
-    if (want >= 128) return 4;
-    if (want >= 64) return 2;
-    return 1;
-}
+// grids that under-fill the chip; long sequences on full grids get 256-row workgroups (two query blocks per
+// wave at head_dim 64, 8 waves at head_dim 128).
+int waves_for_chunk(int64_t want) { return want >= 128 ? 4 : want >= 64 ? 2 : 1; }
 
-bool tile_kernel_ok(int64_t D, int dtype, const void* const ptrs[4], const int64_t* const strides[4]) {
-    if (!(dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16)) return false;
+bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* const strides[4]) {
     if (!(D == 64 || D == 128)) return false;
     for (int i = 0; i < 4; ++i) {
         if (ptrs[i] && (reinterpret_cast<uintptr_t>(ptrs[i]) & 15)) return false;
         if (strides[i]) {
             for (int j = 0; j < 3; ++j)
-                if (strides[i][j] % 8) return false;   // 16-byte rows for 16-bit elements
+                if (strides[i][j] % (16 / elt)) return false;   // 16-byte rows
         }
     }
     return true;
 }
 
-// fp32 inputs: the v_mfma_f32_32x32x2_f32 kernel (fa_fwd_f32.hip) needs head_dim 64 / 128 and 16-byte rows
-bool f32_kernel_ok(int64_t D, int dtype, const void* const ptrs[4], const int64_t* const strides[4]) {
-    if (dtype != FA_DTYPE_F32 || !(D == 64 || D == 128)) return false;
-    if (const char* e = getenv("FA_AMD_F32")) { if (e[0] == 'g') return false; }   // FA_AMD_F32=generic: A/B knob
-    for (int i = 0; i < 4; ++i) {
-        if (ptrs[i] && (reinterpret_cast<uintptr_t>(ptrs[i]) & 15)) return false;
-        if (strides[i]) {
-            for (int j = 0; j < 3; ++j)
-                if (strides[i][j] % 4) return false;
-        }
-    }
-    return true;
-}
-
-// Which MFMA kernel serves a request:
+// The ONE selection function behind fa_plan() and fa_fwd().
 //   'd' fa_fwd_dma_kernel   64-key tiles, LDS-DMA staged (fa_fwd_dma.hip)
-//   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic only
-//   't' fa_fwd_tile_kernel  register-staged A/B baseline (FA_AMD_KERNEL=tile)
-// and qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
-// Default: head_dim 64 with 4 waves, skip-max arithmetic, L >= 4096 and a grid of >= 1024 workgroups -> 'p' with
-// qb 2 (256-row workgroups: +1..6 % measured at L 4096 .. 32768 under sustained load; slower on short sequences
-// and under-filled grids); everything else -> 'd' with qb 1.
-// FA_AMD_KERNEL=dma|pipe|tile and FA_AMD_QB=1|2 override (developer knobs).
-struct KernelChoice { char which; int qb; };
-KernelChoice pick_kernel(int64_t G, int64_t L, int64_t D, int waves, int64_t chunk_q, bool skip_ok) {
-    const char* kv = getenv("FA_AMD_KERNEL");
-    const char forced = (kv && (kv[0] == 't' || kv[0] == 'd' || kv[0] == 'p')) ? kv[0] : 0;
-    const char* qe = getenv("FA_AMD_QB");
-    const int qb_env = (qe && *qe) ? atoi(qe) : 0;
-    KernelChoice kc{'d', 1};
-    const bool pipe_ok = skip_ok && waves <= 4;
-    if (forced == 't') return KernelChoice{'t', 1};
-    if (forced == 'p' && pipe_ok) kc.which = 'p';
-    // (256-row workgroups at 2 per CU: below ~2 workgroups per slot of a 256-CU device the coarser grid loses)
-    const int64_t wgs_qb2 = (G + 7) / 8 * 8 * ((L + 255) / 256);
-    if (forced == 0 && pipe_ok && D == 64 && waves == 4 && chunk_q >= 256 && L >= 4096 && wgs_qb2 >= 1024) kc = KernelChoice{'p', 2};
-    const bool qb2_ok = D == 64 && L >= 256 && waves == 4 && chunk_q >= 256;   // (the chunk bounds the q tile)
-    if (qb_env == 1) kc.qb = 1;
-    if (qb_env == 2 && qb2_ok) kc.qb = 2;
-    if (forced == 'p' && kc.which == 'p' && qb_env == 0) kc.qb = (qb2_ok && waves == 4) ? 2 : 1;
-    return kc;
-}
+//   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic, causal only
+//   't' fa_fwd_tile_kernel  register-staged A/B baseline (debug override only)
+// qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
+// Order: debug overrides > measured table (fa_tuning_table.h) > built-in rules; the num_chunks_* bounds and the
+// kernels' own constraints are enforced on whatever was picked.
+struct Selection {
+    fa_plan_t plan;
+    char which;      // 'd' | 'p' | 't' | 'g' generic | 'f' fp32 MFMA
+};
 
-int make_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, bool tile_ok, bool f32_ok, bool skip_ok,
-              fa_plan_t* plan, KernelChoice* choice) {
+int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, float scale, int32_t causal,
+                bool mfma16_ok, bool f32_ok, Selection* sel) {
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1 (got %lld, %lld, %lld)", (long long)G, (long long)L, (long long)D);
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     if (nq < 1 || L % nq != 0) return fail(FA_ERR_CHUNKS_Q, "sequence length %lld is not divisible by num_chunks_q=%d", (long long)L, nq);
     if (nk < 1 || L % nk != 0) return fail(FA_ERR_CHUNKS_KV, "sequence length %lld is not divisible by num_chunks_kv=%d", (long long)L, nk);
     if (L > (1ll << 30) || G > (1ll << 30)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30");
+    if (!(scale > 0.0f) || !isfinite(scale)) return fail(FA_ERR_BAD_SCALE, "softmax_scale must be finite and > 0 (got %g)", (double)scale);
+    if (!(causal == 0 || causal == 1)) return fail(FA_ERR_NOT_CAUSAL, "causal must be 0 or 1 (got %d)", causal);
+    const Options& opt = options();
+    fa_plan_t* plan = &sel->plan;
     memset(plan, 0, sizeof(*plan));
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
-    if (tile_ok) {
-        plan->waves = pick_waves(L, plan->chunk_q);
-        // head_dim 128, skip-max arithmetic: 8-wave / 256-row workgroups halve the K/V DMA traffic per FLOP
-        // (+2..3 % measured at L >= 4096 on full grids; slower on short sequences, small grids and with the
-        // per-tile row max of unscaled f16)
-        {
-            const char* we = getenv("FA_AMD_WAVES");
-            const int64_t wgs256 = (G + 7) / 8 * 8 * ((L + 255) / 256);
-            if (!(we && *we) && plan->waves == 4 && D == 128 && skip_ok && plan->chunk_q >= 256 && L >= 4096 && wgs256 >= 512)
-                plan->waves = 8;
+    const int64_t g8 = (G + 7) / 8 * 8;
+    const int es = elt_size(dtype);
+    if (mfma16_ok) {
+        // f16 skip-max pays off when logits are small against the 2^15 headroom of f16 P: a softmax scale
+        // <= 0.25 means 1/sqrt(D)-style scaled attention (D >= 16); the packed op (scale 1) keeps the row max
+        int skip = dtype == FA_DTYPE_BF16 ? 1 : (scale <= 0.25f ? 1 : 0);
+        if (dtype == FA_DTYPE_F16 && opt.skipmax >= 0) skip = opt.skipmax != 0;
+        const int64_t cq = plan->chunk_q < L ? plan->chunk_q : L;
+        const int64_t ck = plan->chunk_kv < L ? plan->chunk_kv : L;
+        const int wmax = waves_for_chunk(cq);            // the q chunk bounds the workgroup's rows
+        const bool pipe_ok = skip && causal;              // (the pipelined kernel: skip-max arithmetic, causal order)
+        const bool want32 = ck < 64;                      // a kv chunk below 64 keys is served by 32-key steps
+        char which = 'd';
+        int waves = wmax, qb = 1, sched = 0, source = 0;
+        // ---- built-in rules (round-1 measurements)
+        const int64_t wgs256 = g8 * ((L + 255) / 256);
+        if (D == 64 && pipe_ok && waves == 4 && cq >= 256 && L >= 4096 && wgs256 >= 1024) { which = 'p'; qb = 2; }
+        if (D == 128 && skip && waves == 4 && cq >= 256 && L >= 4096 && wgs256 >= 512) waves = 8;
+        // ---- measured table
+        if (opt.table) {
+            const int64_t wgs128 = g8 * ((L + 127) / 128);
+            for (const fa::TuneRow& r : fa::kTuneTable) {
+                if (r.D != D || r.skip != skip || r.causal != causal || L < r.L_lo || L > r.L_hi || wgs128 < r.wg_lo || wgs128 > r.wg_hi) continue;
+                if (32 * r.waves * r.qb > (cq > 32 ? cq : 32)) continue;   // the q chunk forbids the row's tile
+                if (r.kernel == 'p' && !pipe_ok) continue;
+                which = r.kernel; waves = r.waves; qb = r.qb; sched = r.sched; source = 1;
+                break;
+            }
         }
-        const KernelChoice kc = pick_kernel(G, L, D, plan->waves, plan->chunk_q < L ? plan->chunk_q : L, skip_ok);
-        if (choice) *choice = kc;
-        plan->kernel = kc.which == 'p' ? 2 : 0;
-        plan->block_q = 32 * plan->waves * kc.qb;
-        plan->block_kv = kc.which == 'p' ? 32 : 64;
-        const int64_t nqt = (L + plan->block_q - 1) / plan->block_q;
-        const int64_t g8 = (G + 7) / 8 * 8;
-        plan->grid = g8 * nqt;
-        plan->lds_bytes = kc.which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * plan->waves
-                                          : 2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64);
+        // ---- debug overrides
+        const int fk = opt.kernel, fw = opt.waves, fq = opt.qb;
+        if (fk || fw || fq || opt.sched > 0 || (dtype == FA_DTYPE_F16 && opt.skipmax >= 0)) source = 2;
+        if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && (waves > 4)) which = 'd'; }
+        if (fk == 't') { which = 't'; qb = 1; }
+        else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
+        else if (fk == 'p' && pipe_ok && waves <= 4) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
+        if (fq == 1) qb = 1;
+        if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
+        // ---- constraints of the kernels
+        if (want32 && pipe_ok && which == 'd' && fk == 0) { which = 'p'; if (waves > 4) waves = 4; }
+        if (which == 'p' && (waves > 4 || !pipe_ok)) which = 'd';
+        if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
+        if (which == 't' && waves > 4) waves = 4;
+        plan->kernel = which == 'p' ? 2 : 0;
+        plan->waves = waves;
+        plan->qb = qb;
+        plan->block_q = 32 * waves * qb;
+        plan->block_kv = which == 'p' ? 32 : 64;
+        plan->skipmax = skip;
+        plan->source = source;
+        plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
+        plan->lds_bytes = which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
+                                       : 2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64);
+        // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
+        // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
+        {
+            const int64_t kv_bytes = 2 * L * D * es;
+            int64_t bunch = sched > 0 ? sched : (8ll << 20) / kv_bytes;
+            if (opt.sched > 0) bunch = opt.sched;
+            const int64_t ng = g8 / 8;
+            if (bunch < 1) bunch = 1;
+            if (bunch > ng) bunch = ng;
+            plan->sched = (int32_t)bunch;
+        }
+        sel->which = which;
     } else if (f32_ok) {
         plan->kernel = 3;
         plan->waves = 4;
+        plan->qb = 1;
         plan->block_q = 128;
         plan->block_kv = 32;
-        plan->grid = (G + 7) / 8 * 8 * ((L + 127) / 128);
+        plan->grid = g8 * ((L + 127) / 128);
         plan->lds_bytes = 2 * 32 * (D + 1) * 4 + 2 * 32 * D * 4;
+        {
+            int64_t bunch = (8ll << 20) / (2 * L * D * es);
+            if (opt.sched > 0) bunch = opt.sched;
+            const int64_t ng = g8 / 8;
+            if (bunch < 1) bunch = 1;
+            if (bunch > ng) bunch = ng;
+            plan->sched = (int32_t)bunch;
+        }
+        sel->which = 'f';
     } else {
         if (D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic kernel supports D <= 1024 (got %lld)", (long long)D);
         plan->kernel = 1;
         plan->waves = 4;
+        plan->qb = 1;
         plan->block_q = 1;
         plan->block_kv = 1024;
         plan->grid = G * L;
         plan->lds_bytes = 1024 * 4 + 16 + D * 4;
+        plan->sched = 1;
+        sel->which = 'g';
     }
     if (plan->grid > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid of %lld workgroups exceeds 2^31-1", (long long)plan->grid);
     return FA_OK;
 }
+
+struct OptionName { const char* name; std::atomic<int> Options::*field; int lo, hi; };
+const OptionName kOptionNames[] = {
+    {"kernel", &Options::kernel, 0, 127}, {"qb", &Options::qb, 0, 2}, {"waves", &Options::waves, 0, 8},
+    {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
+    {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1},
+};
 
 }  // namespace
 
@@ -170,12 +232,39 @@ const char* fa_error_string(int code) {
         case FA_ERR_CHUNKS_Q: return "sequence length not divisible by num_chunks_q";
         case FA_ERR_CHUNKS_KV: return "sequence length not divisible by num_chunks_kv";
         case FA_ERR_MISALIGNED: return "misaligned pointer or stride";
-        case FA_ERR_NOT_CAUSAL: return "only causal attention is supported";
+        case FA_ERR_NOT_CAUSAL: return "causal must be 0 or 1";
         case FA_ERR_LAUNCH: return "kernel launch failed";
         case FA_ERR_BAD_STRIDE: return "bad stride";
         case FA_ERR_TOO_LARGE: return "problem too large";
+        case FA_ERR_BAD_SCALE: return "softmax_scale must be finite and > 0";
+        case FA_ERR_BAD_OPTION: return "unknown debug option or value out of range";
         default: return "unknown error";
     }
+}
+
+int fa_debug_set_option(const char* name, int32_t value) {
+    if (!name) return fail(FA_ERR_NULL_POINTER, "fa_debug_set_option: null name");
+    (void)options();   // the environment is parsed before the first override, never after it
+    for (const OptionName& o : kOptionNames) {
+        if (strcmp(o.name, name) != 0) continue;
+        if (value < o.lo || value > o.hi) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: %s=%d out of range [%d, %d]", name, value, o.lo, o.hi);
+        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 't'))
+            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p' or 't'");
+        if (o.field == &Options::waves && !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
+            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: waves must be 0, 1, 2, 4 or 8");
+        (g_opt.*(o.field)).store(value);
+        return FA_OK;
+    }
+    return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: unknown option '%s'", name);
+}
+
+int fa_debug_get_option(const char* name, int32_t* value) {
+    if (!name || !value) return fail(FA_ERR_NULL_POINTER, "fa_debug_get_option: null argument");
+    const Options& opt = options();
+    for (const OptionName& o : kOptionNames) {
+        if (strcmp(o.name, name) == 0) { *value = (opt.*(o.field)).load(); return FA_OK; }
+    }
+    return fail(FA_ERR_BAD_OPTION, "fa_debug_get_option: unknown option '%s'", name);
 }
 
 double fa_probe_mfma_peak(int32_t dtype, int32_t iters, int32_t random_data) {
@@ -201,24 +290,27 @@ int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_sh
     return FA_OK;
 }
 
-int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q, int32_t num_chunks_kv, fa_plan_t* plan) {
+int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q, int32_t num_chunks_kv,
+            float softmax_scale, int32_t causal, fa_plan_t* plan) {
     if (!plan) return fail(FA_ERR_NULL_POINTER, "null plan pointer");
-    const void* const ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
-    const int64_t* const strides[4] = {nullptr, nullptr, nullptr, nullptr};
-    // (the packed op has softmax scale 1: f16 keeps the per-tile row max, bf16 runs the skip-max arithmetic)
-    return make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_kernel_ok(D, dtype, ptrs, strides),
-                     f32_kernel_ok(D, dtype, ptrs, strides), dtype == FA_DTYPE_BF16, plan, nullptr);
+    const bool d_ok = D == 64 || D == 128;
+    Selection sel;
+    const int rc = select_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal,
+                               d_ok && (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16),
+                               d_ok && dtype == FA_DTYPE_F32 && !options().f32_generic, &sel);
+    if (rc == FA_OK) *plan = sel.plan;
+    return rc;
 }
 
 int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
-           int64_t G, int64_t L, int64_t D, int64_t heads,
+           int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,
            const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
            int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,
            float softmax_scale, int32_t causal, void* stream) {
     if (!q || !k || !v || !out) return fail(FA_ERR_NULL_POINTER, "q, k, v and out must be non-null");
     if (!q_strides || !k_strides || !v_strides || !o_strides) return fail(FA_ERR_NULL_POINTER, "stride arrays must be non-null");
-    if (!causal) return fail(FA_ERR_NOT_CAUSAL, "only causal attention is supported (reference: sdpa.py:29-32)");
     if (heads < 1 || (G >= 1 && G % heads != 0)) return fail(FA_ERR_BAD_SHAPE, "G=%lld must be a positive multiple of heads=%lld", (long long)G, (long long)heads);
+    if (heads_kv < 1 || heads % heads_kv != 0) return fail(FA_ERR_BAD_SHAPE, "heads=%lld must be a positive multiple of heads_kv=%lld", (long long)heads, (long long)heads_kv);
     const void* const ptrs[4] = {q, k, v, out};
     const int64_t* const strides[4] = {q_strides, k_strides, v_strides, o_strides};
     for (int i = 0; i < 4; ++i)
@@ -228,19 +320,14 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     for (int i = 0; i < 4; ++i)
         if (reinterpret_cast<uintptr_t>(ptrs[i]) % elt_size(dtype)) return fail(FA_ERR_MISALIGNED, "pointer %d is not element aligned", i);
 
-    fa_plan_t plan;
-    bool tile_ok = tile_kernel_ok(D, dtype, ptrs, strides);
-    // the MFMA kernel addresses K/V rows with 32-bit element offsets from the group base
-    if (tile_ok && (L * k_strides[2] >= (1ll << 31) || L * v_strides[2] >= (1ll << 31))) tile_ok = false;
-    // f16 skip-max pays off when logits are small against the 2^15 headroom of f16 P: a softmax scale
-    // <= 0.25 means 1/sqrt(D)-style scaled attention (D >= 16); the packed op (scale 1) keeps the row max
-    int skipmax = softmax_scale <= 0.25f ? 1 : 0;
-    if (const char* sm = getenv("FA_AMD_SKIPMAX")) skipmax = atoi(sm);
-    KernelChoice kc{'d', 1};
-    bool f32_ok = f32_kernel_ok(D, dtype, ptrs, strides);
-    if (f32_ok && (L * k_strides[2] >= (1ll << 31) || L * v_strides[2] >= (1ll << 31))) f32_ok = false;
-    int rc = make_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, tile_ok, f32_ok, dtype == FA_DTYPE_BF16 || skipmax != 0, &plan, &kc);
+    // the MFMA kernels need 16-byte rows and address K/V rows with 32-bit element offsets from the group base
+    bool wide_ok = aligned16(D, elt_size(dtype), ptrs, strides) && L * k_strides[2] < (1ll << 31) && L * v_strides[2] < (1ll << 31);
+    const bool mfma16_ok = wide_ok && (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16);
+    const bool f32_ok = wide_ok && dtype == FA_DTYPE_F32 && !options().f32_generic;
+    Selection sel;
+    const int rc = select_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal, mfma16_ok, f32_ok, &sel);
     if (rc != FA_OK) return rc;
+    const fa_plan_t& plan = sel.plan;
 
     fa::FwdParams p;
     p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse;
@@ -251,29 +338,21 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     p.G = (int32_t)G;
     p.G8 = (int32_t)((G + 7) / 8 * 8);
     p.H = (int32_t)heads;
+    p.kv_div = (int32_t)(heads / heads_kv);
     p.L = (int32_t)L;
     p.D = (int32_t)D;
+    p.causal = causal;
     p.nq_tiles = plan.kernel != 1 ? (int32_t)((L + plan.block_q - 1) / plan.block_q) : 0;
-    // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
-    // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
-    {
-        const int64_t kv_bytes = 2 * L * D * elt_size(dtype);
-        int64_t bunch = kv_bytes > 0 ? (8ll << 20) / kv_bytes : 1;
-        const char* sched = getenv("FA_AMD_SCHED");
-        if (sched && *sched) bunch = atoi(sched);
-        const int64_t ng = p.G8 / 8;
-        if (bunch < 1) bunch = 1;
-        if (bunch > ng) bunch = ng;
-        p.sched = (int32_t)bunch;
-    }
+    p.sched = plan.sched;
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    p.skipmax = skipmax;
-    hipError_t e = plan.kernel == 1    ? fa::launch_fwd_generic(p, dtype, (hipStream_t)stream)
-                   : plan.kernel == 3 ? fa::launch_fwd_f32(p, (hipStream_t)stream)
-                   : kc.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, kc.qb, (hipStream_t)stream)
-                   : kc.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves, kc.qb, (hipStream_t)stream)
-                                     : fa::launch_fwd_tile(p, dtype, plan.waves, (hipStream_t)stream);
+    p.skipmax = plan.skipmax;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = sel.which == 'g'   ? fa::launch_fwd_generic(p, dtype, st)
+                   : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
+                   : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
+                   : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves, plan.qb, st)
+                                      : fa::launch_fwd_tile(p, dtype, plan.waves, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
 }
@@ -284,8 +363,9 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
            int32_t dtype, float softmax_scale, int32_t causal, void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !dsum_workspace || !strides)
         return fail(FA_ERR_NULL_POINTER, "fa_bwd: every pointer argument must be non-null");
-    if (!causal) return fail(FA_ERR_NOT_CAUSAL, "only causal attention is supported (reference: sdpa.py:29-32)");
+    if (!(causal == 0 || causal == 1)) return fail(FA_ERR_NOT_CAUSAL, "causal must be 0 or 1 (got %d)", causal);
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1");
+    if (!(softmax_scale > 0.0f) || !isfinite(softmax_scale)) return fail(FA_ERR_BAD_SCALE, "softmax_scale must be finite and > 0 (got %g)", (double)softmax_scale);
     if (heads < 1 || G % heads != 0) return fail(FA_ERR_BAD_SHAPE, "G=%lld must be a positive multiple of heads=%lld", (long long)G, (long long)heads);
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     if (L > (1ll << 30) || G > (1ll << 30)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30");
@@ -315,11 +395,12 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
     p.dk_sb = strides[6][0]; p.dk_sh = strides[6][1]; p.dk_sl = strides[6][2];
     p.dv_sb = strides[7][0]; p.dv_sh = strides[7][1]; p.dv_sl = strides[7][2];
     p.G = (int32_t)G; p.G8 = (int32_t)((G + 7) / 8 * 8); p.H = (int32_t)heads; p.L = (int32_t)L; p.D = (int32_t)D;
+    p.causal = causal;
     p.nq_tiles = (int32_t)((L + 127) / 128);
     p.nk_tiles = (int32_t)((L + 127) / 128);
     {
         int64_t bunch = (8ll << 20) / (2 * L * D * 2);
-        if (const char* sched = getenv("FA_AMD_SCHED")) { if (*sched) bunch = atoi(sched); }
+        if (options().sched > 0) bunch = options().sched;
         const int64_t ng = p.G8 / 8;
         if (bunch < 1) bunch = 1;
         if (bunch > ng) bunch = ng;
@@ -341,7 +422,7 @@ int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t
     const int64_t es = elt_size(dtype);
     const int64_t strides[3] = {L * D, 0, D};
     const char* base = static_cast<const char*>(qkv);
-    return fa_fwd(base, base + G * L * D * es, base + 2 * G * L * D * es, out, lse, G, L, D, 1,
+    return fa_fwd(base, base + G * L * D * es, base + 2 * G * L * D * es, out, lse, G, L, D, 1, 1,
                   strides, strides, strides, strides, num_chunks_q, num_chunks_kv, dtype, 1.0f, 1, stream);
 }
 

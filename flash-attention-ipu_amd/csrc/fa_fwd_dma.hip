@@ -73,8 +73,8 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.H, hh = g - bb * p.H;
     const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
-    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
-    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
+    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
     const int q_row0 = qi * BQ + wave * WQ;
     const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
@@ -138,8 +138,13 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     }
     const int v_rd = (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
-    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    // causal: keys up to the workgroup's last row; otherwise every key.  `klim`: the last key a row may see is
+    // min(row, L - 1) under the causal mask and L - 1 without it (rows past L are clamped duplicates, never stored)
+    const bool causal = p.causal != 0;
+    const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
     const int n_tiles = (kv_end + BK - 1) / BK;
+    const int wave_last = causal ? q_row0 : L - 1;      // a tile reaching past this key carries a mask for the wave
+    const int wave_kv_last = causal ? q_row0 + WQ - 1 : L - 1;   // tiles starting after it hold nothing for the wave
 
     f32x16 o[QB][DT];
     float m[QB], l[QB];
@@ -175,12 +180,13 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                 s1[b] = E::mfma(k1, qf[b][ks], s1[b]);                                             \
             }                                                                                      \
         }                                                                                          \
-        if (kv0 + BK - 1 > q_row0) { /* a diagonal tile of the wave */                             \
+        if (kv0 + BK - 1 > wave_last) { /* a diagonal tile of the wave / the ragged last tile */   \
             _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                       \
+                const int klim = causal ? qrow + 32 * b : L - 1;                                   \
                 _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                   \
                     const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;                          \
-                    if (key > qrow + 32 * b) s0[b][e] = -INFINITY;                                 \
-                    if (key + 32 > qrow + 32 * b) s1[b][e] = -INFINITY;                            \
+                    if (key > klim) s0[b][e] = -INFINITY;                                          \
+                    if (key + 32 > klim) s1[b][e] = -INFINITY;                                     \
                 }                                                                                  \
             }                                                                                      \
         }                                                                                          \
@@ -241,7 +247,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #define FA_COMPUTE(T_, BUF_)                                                                       \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
-        if (wave_active && kv0 <= q_row0 + WQ - 1) {                                               \
+        if (wave_active && kv0 <= wave_kv_last) {                                                  \
             f32x16 s0[QB], s1[QB];                                                                 \
             float ls[QB];                                                                          \
             FA_QK(BUF_)                                                                            \
@@ -340,19 +346,19 @@ static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, hipStream_
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
     if (qb == 2) {   // 64 query rows per wave (head_dim 64, 4 waves): half the LDS operand reads and half the K/V DMA per FLOP
         if constexpr (D == 64) {
-            hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 4, SKIP, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-            return hipGetLastError();
+            return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         } else {
             return hipErrorInvalidValue;
         }
     }
+    hipError_t e;
     switch (waves) {
-        case 8: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 8, SKIP, 1>), dim3((unsigned)grid), dim3(512), 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 4, SKIP, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 2, SKIP, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
-        default: hipLaunchKernelGGL((fa_fwd_dma_kernel<T, D, 1, SKIP, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
+        case 8: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 8, SKIP, 1>), dim3((unsigned)grid), dim3(512), 0, stream, p); break;
+        case 4: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 2, SKIP, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
+        default: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 1, SKIP, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
     }
-    return hipGetLastError();
+    return e;
 }
 
 // qb = 32-row query blocks per wave (1, or 2 for head_dim 64 with 4 waves; the host sized p.nq_tiles for it)

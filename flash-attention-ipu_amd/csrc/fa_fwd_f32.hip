@@ -56,8 +56,8 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_f32_kernel(const FwdParams
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.H, hh = g - bb * p.H;
     const float* __restrict__ qg = (const float*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
-    const float* __restrict__ kg = (const float*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
-    const float* __restrict__ vg = (const float*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+    const float* __restrict__ kg = (const float*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
+    const float* __restrict__ vg = (const float*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
     const int q_row0 = qi * BQ + wave * 32;
     const int qrow = q_row0 + r;
@@ -72,8 +72,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_f32_kernel(const FwdParams
         for (int s = 0; s < D / 2; ++s) qf[s] = qp[2 * s];
     }
 
-    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    const bool causal = p.causal != 0;             // 0: no mask, every key (only keys past L are masked)
+    const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
     const int n_tiles = (kv_end + BK - 1) / BK;
+    const int wave_last = causal ? q_row0 : L - 1, wave_kv_last = causal ? q_row0 + 31 : L - 1, klim = causal ? qrow : L - 1;
 
     // global -> registers -> LDS staging: chunk c = tid + j NT covers floats 4c .. 4c+3 of the tile
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -120,18 +122,18 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_f32_kernel(const FwdParams
         const int buf = t & 1;
         if (t + 1 < n_tiles) load_tile(t + 1);          // in flight under this tile's MFMAs
         const int kv0 = t * BK;
-        if (wave_active && kv0 <= q_row0 + 31) {
+        if (wave_active && kv0 <= wave_kv_last) {
             f32x16 s;
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = 0.f;
             const float* kb = &ks[buf][r * KP + h];
 #pragma unroll
             for (int d2 = 0; d2 < D / 2; ++d2) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[2 * d2], qf[d2], s, 0, 0, 0);
-            if (kv0 + BK - 1 > q_row0) {                // the wave's diagonal tile
+            if (kv0 + BK - 1 > wave_last) {             // the wave's diagonal tile / the ragged last tile
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (key > qrow) s[e] = -INFINITY;
+                    if (key > klim) s[e] = -INFINITY;
                 }
             }
             float mx = s[0];
@@ -185,9 +187,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_f32_kernel(const FwdParams
 // fp32, D in {64, 128}, rows 16-byte aligned; p.nq_tiles = ceil(L / 128)
 hipError_t launch_fwd_f32(const FwdParams& p, hipStream_t stream) {
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
-    if (p.D == 64) hipLaunchKernelGGL((fa_fwd_f32_kernel<64, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((fa_fwd_f32_kernel<128, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    return hipGetLastError();
+    hipError_t e;
+    if (p.D == 64) e = launch1((const void*)(fa_fwd_f32_kernel<64, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else e = launch1((const void*)(fa_fwd_f32_kernel<128, 4>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    return e;
 }
 
 }  // namespace fa

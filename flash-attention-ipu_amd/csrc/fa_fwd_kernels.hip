@@ -91,8 +91,8 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.H, hh = g - bb * p.H;
     const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
-    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
-    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
+    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
     const int q_row0 = qi * BQ + wave * 32;   // first query row of this wave
     const int qrow = q_row0 + r;              // this lane's query row (both halves hold the same row)
@@ -139,8 +139,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
     // 4*q4 + pp supplies row (4h + q4) of the 8-key block, cols 4pp..4pp+3 of the 16-col half.
     const int v_rd = (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
-    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    const bool causal = p.causal != 0;             // 0: no mask, every key (only keys past L are masked)
+    const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
     const int n_tiles = (kv_end + BK - 1) / BK;
+    const int wave_last = causal ? q_row0 : L - 1, wave_kv_last = causal ? q_row0 + 31 : L - 1, klim = causal ? qrow : L - 1;
 
     u32x4 kreg[CPT], vreg[CPT];
 #define FA_ISSUE_LOADS(T_)                                                                        \
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
         const int kv0 = t * BK;
         if (t + 1 < n_tiles) FA_ISSUE_LOADS(t + 1)
 
-        if (wave_active && kv0 <= q_row0 + 31) {
+        if (wave_active && kv0 <= wave_kv_last) {
             const unsigned char* kb_ = smem + buf * KTILE_B;
             const unsigned char* vb_ = smem_v + buf * VTILE_B;
 
@@ -209,12 +211,12 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_fwd_tile_kernel(const FwdParam
             }
 
             // ---- causal predicate, diagonal tiles only (wave-uniform branch)
-            if (kv0 + BK - 1 > q_row0) {
+            if (kv0 + BK - 1 > wave_last) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (key > qrow) s0[e] = -INFINITY;
-                    if (key + 32 > qrow) s1[e] = -INFINITY;
+                    if (key > klim) s0[e] = -INFINITY;
+                    if (key + 32 > klim) s1[e] = -INFINITY;
                 }
             }
 
@@ -366,8 +368,8 @@ __global__ __launch_bounds__(GEN_THREADS) void fa_fwd_generic_kernel(const FwdPa
     const int row = blockIdx.x - g * L;
     const int bb = g / p.H, hh = g - bb * p.H;
     const T* qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh + (int64_t)row * p.q_sl;
-    const T* kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
-    const T* vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+    const T* kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
+    const T* vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
     const int tid = threadIdx.x;
 
     for (int d = tid; d < D; d += GEN_THREADS) qrow_s[d] = to_f32(qg[d]);
@@ -377,8 +379,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fa_fwd_generic_kernel(const FwdPa
 #pragma unroll
     for (int i = 0; i < GEN_MAXD_PER_THREAD; ++i) oacc[i] = 0.f;
     float m = -INFINITY, l = 0.f;
-    const int nkeys = row + 1;   // causal: keys 0..row
-    (void)L;
+    const int nkeys = p.causal ? row + 1 : L;   // causal: keys 0..row
 
     for (int k0 = 0; k0 < nkeys; k0 += GEN_CHUNK) {
         const int kn = nkeys - k0 < GEN_CHUNK ? nkeys - k0 : GEN_CHUNK;
@@ -432,8 +433,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fa_fwd_generic_kernel(const FwdPa
 template <typename T, int D, int NWAVES>
 static hipError_t launch_tile(const FwdParams& p, hipStream_t stream) {
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
-    hipLaunchKernelGGL((fa_fwd_tile_kernel<T, D, NWAVES>), dim3((unsigned)grid), dim3(NWAVES * 64), 0, stream, p);
-    return hipGetLastError();
+    return launch1((const void*)(fa_fwd_tile_kernel<T, D, NWAVES>), dim3((unsigned)grid), dim3(NWAVES * 64), 0, stream, p);
 }
 
 template <typename T, int D>
@@ -456,10 +456,11 @@ hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream) {
     dim3 grid((unsigned)((int64_t)p.L * p.G));
     const size_t dyn = (size_t)p.D * sizeof(float);
-    if (dtype == 1) hipLaunchKernelGGL((fa_fwd_generic_kernel<__bf16>), grid, dim3(GEN_THREADS), dyn, stream, p);
-    else if (dtype == 0) hipLaunchKernelGGL((fa_fwd_generic_kernel<_Float16>), grid, dim3(GEN_THREADS), dyn, stream, p);
-    else hipLaunchKernelGGL((fa_fwd_generic_kernel<float>), grid, dim3(GEN_THREADS), dyn, stream, p);
-    return hipGetLastError();
+    hipError_t e;
+    if (dtype == 1) e = launch1((const void*)(fa_fwd_generic_kernel<__bf16>), grid, dim3(GEN_THREADS), dyn, stream, p);
+    else if (dtype == 0) e = launch1((const void*)(fa_fwd_generic_kernel<_Float16>), grid, dim3(GEN_THREADS), dyn, stream, p);
+    else e = launch1((const void*)(fa_fwd_generic_kernel<float>), grid, dim3(GEN_THREADS), dyn, stream, p);
+    return e;
 }
 
 }  // namespace fa

@@ -103,8 +103,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.H, hh = g - bb * p.H;
     const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
-    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
-    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
+    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
     const int q_row0 = qi * BQ + wave * WQ;
     const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
@@ -566,18 +566,18 @@ static hipError_t launch_pipe_w(const FwdParams& p, int waves, int qb, hipStream
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
     if (qb == 2) {
         if constexpr (D == 64) {
-            hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 4, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-            return hipGetLastError();
+            return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         } else {
             return hipErrorInvalidValue;
         }
     }
+    hipError_t e;
     switch (waves) {
-        case 4: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 4, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 2, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
-        default: hipLaunchKernelGGL((fa_fwd_pipe_kernel<T, D, 1, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
+        case 4: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 2, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
+        default: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 1, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
     }
-    return hipGetLastError();
+    return e;
 }
 
 // callers guarantee: D in {64, 128}, waves in {1, 2, 4}, skip-max arithmetic wanted (bf16, or f16 with p.skipmax);

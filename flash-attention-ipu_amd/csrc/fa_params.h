@@ -21,6 +21,8 @@ struct FwdParams {
     int32_t G;             // groups = batch * heads
     int32_t G8;            // G rounded up to a multiple of 8 (XCD-aware grid)
     int32_t H;             // inner group count (heads) for the 2-level group stride
+    int32_t kv_div;        // query heads per key/value head (1 = multi-head attention): K/V head = head / kv_div
+    int32_t causal;        // 1 causal mask, 0 none
     int32_t L;
     int32_t D;
     int32_t nq_tiles;      // q tiles per group
@@ -39,11 +41,22 @@ struct BwdParams {
     int64_t q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl, do_sb, do_sh, do_sl;
     int64_t dq_sb, dq_sh, dq_sl, dk_sb, dk_sh, dk_sl, dv_sb, dv_sh, dv_sl;
     int32_t G, G8, H, L, D;
+    int32_t causal;        // 1 causal mask, 0 none
     int32_t nq_tiles;      // workgroup row tiles per group (32 rows x waves x query blocks per wave each)
     int32_t nk_tiles;      // 128-key blocks per group
     int32_t sched;         // groups per XCD bunch
     float scale, scale_log2;
 };
+// One launch, reporting ITS OWN status: hipLaunchKernel returns this launch's result, whereas hipGetLastError()
+// after a <<<>>> launch also returns (and clears) a stale error left on the thread by an unrelated earlier HIP
+// call of the host framework.
+template <typename P>
+inline hipError_t launch1(const void* kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t stream, const P& p) {
+    P arg = p;
+    void* args[] = {&arg};
+    return hipLaunchKernel(kernel, grid, block, args, dyn_lds, stream);
+}
+
 hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream);
 hipError_t launch_bwd_generic(const BwdParams& p, int dtype, hipStream_t stream);
 

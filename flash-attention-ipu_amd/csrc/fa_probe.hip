@@ -89,8 +89,8 @@ __global__ void fa_clock_sampler_kernel(unsigned long long* out, int spins) {
 }
 
 hipError_t launch_clock_sampler(unsigned long long* out, int spins, hipStream_t stream) {
-    hipLaunchKernelGGL(fa_clock_sampler_kernel, dim3(1), dim3(64), 0, stream, out, spins);
-    return hipGetLastError();
+    void* args[] = {&out, &spins};
+    return hipLaunchKernel((const void*)fa_clock_sampler_kernel, dim3(1), dim3(64), args, 0, stream);
 }
 
 }  // namespace fa

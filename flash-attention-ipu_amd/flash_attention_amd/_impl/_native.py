@@ -17,7 +17,7 @@ _LIB = None
 _LIB_PATH = None
 
 FA_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class FaPlan(ctypes.Structure):
@@ -30,6 +30,10 @@ class FaPlan(ctypes.Structure):
         ("chunk_kv", ctypes.c_int32),
         ("grid", ctypes.c_int64),
         ("lds_bytes", ctypes.c_int64),
+        ("qb", ctypes.c_int32),
+        ("sched", ctypes.c_int32),
+        ("skipmax", ctypes.c_int32),
+        ("source", ctypes.c_int32),
     ]
 
 
@@ -77,9 +81,13 @@ def _declare(lib):
     lib.fa_infer_output_shape.restype = ctypes.c_int
     lib.fa_infer_output_shape.argtypes = [p64, i32, p64]
     lib.fa_plan.restype = ctypes.c_int
-    lib.fa_plan.argtypes = [i64, i64, i64, i32, i32, i32, ctypes.POINTER(FaPlan)]
+    lib.fa_plan.argtypes = [i64, i64, i64, i32, i32, i32, ctypes.c_float, i32, ctypes.POINTER(FaPlan)]
+    lib.fa_debug_set_option.restype = ctypes.c_int
+    lib.fa_debug_set_option.argtypes = [ctypes.c_char_p, i32]
+    lib.fa_debug_get_option.restype = ctypes.c_int
+    lib.fa_debug_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
     lib.fa_fwd.restype = ctypes.c_int
-    lib.fa_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, p64, p64, p64, p64,
+    lib.fa_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, p64, p64, p64, p64,
                            i32, i32, i32, ctypes.c_float, i32, vp]
     lib.fa_bwd.restype = ctypes.c_int
     lib.fa_bwd.argtypes = [vp] * 10 + [i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32, vp]
@@ -94,18 +102,54 @@ def _declare(lib):
 def _raise(rc):
     lib = load_native_library()
     msg = lib.fa_last_error().decode() or lib.fa_error_string(rc).decode()
-    if rc in (-2, -3, -4, -5, -7, -9):
+    if rc in (-2, -3, -4, -5, -7, -9, -11, -12):
         raise ValueError(f"flash_attention_amd: {msg}")
     raise RuntimeError(f"flash_attention_amd: {msg} (code {rc})")
 
 
-def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv) -> FaPlan:
+def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale: float = 1.0, causal: bool = True) -> FaPlan:
+    """The tile plan fa_fwd would launch for contiguous operands (same selection function, host only)."""
     lib = load_native_library()
     out = FaPlan()
-    rc = lib.fa_plan(G, L, D, FA_DTYPE[dtype], num_chunks_q, num_chunks_kv, ctypes.byref(out))
+    rc = lib.fa_plan(G, L, D, FA_DTYPE[dtype], num_chunks_q, num_chunks_kv, float(softmax_scale), int(bool(causal)),
+                     ctypes.byref(out))
     if rc != 0:
         _raise(rc)
     return out
+
+
+_KERNEL_CODE = {"auto": 0, "": 0, None: 0, "dma": ord("d"), "pipe": ord("p"), "tile": ord("t")}
+_OPTION_AUTO = {"kernel": 0, "qb": 0, "waves": 0, "sched": 0, "skipmax": -1, "f32_generic": 0, "table": 1}
+
+
+def set_debug_option(name: str, value) -> None:
+    """TEST / TUNING ONLY: fa_debug_set_option (kernel accepts 'dma' | 'pipe' | 'tile' | 'auto')."""
+    lib = load_native_library()
+    if name == "kernel" and not isinstance(value, int):
+        value = _KERNEL_CODE[value]
+    rc = lib.fa_debug_set_option(name.encode(), int(value))
+    if rc != 0:
+        _raise(rc)
+
+
+class debug_options:
+    """Context manager for tests and tuning tools: force knobs of the tile plan, restore "auto" on exit.
+
+        with _native.debug_options(kernel="pipe", qb=2, waves=4): ...
+    """
+
+    def __init__(self, **knobs):
+        self.knobs = {k: v for k, v in knobs.items() if v is not None}
+
+    def __enter__(self):
+        for k in _OPTION_AUTO:
+            set_debug_option(k, self.knobs.get(k, _OPTION_AUTO[k]))
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in _OPTION_AUTO.items():
+            set_debug_option(k, v)
+        return False
 
 
 def _strides3(arr):
@@ -124,15 +168,17 @@ def fwd_packed(qkv: torch.Tensor, out: torch.Tensor, lse, num_chunks_q: int, num
         _raise(rc)
 
 
-def fwd_strided(q, k, v, out, lse, G, L, D, heads, qs, ks, vs, os_, num_chunks_q, num_chunks_kv, scale):
+def fwd_strided(q, k, v, out, lse, G, L, D, heads, qs, ks, vs, os_, num_chunks_q, num_chunks_kv, scale,
+                causal: bool = True, heads_kv=None):
     """Strided three-view forward: see fa_fwd in include/flash_attention_amd.h."""
     lib = load_native_library()
     with torch.cuda.device(q.device):
         stream = torch.cuda.current_stream().cuda_stream
         rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                         lse.data_ptr() if lse is not None else None, G, L, D, heads,
+                        heads if heads_kv is None else heads_kv,
                         _strides3(qs), _strides3(ks), _strides3(vs), _strides3(os_),
-                        num_chunks_q, num_chunks_kv, FA_DTYPE[q.dtype], float(scale), 1, stream)
+                        num_chunks_q, num_chunks_kv, FA_DTYPE[q.dtype], float(scale), int(bool(causal)), stream)
     if rc != 0:
         _raise(rc)
 
@@ -144,7 +190,7 @@ def group_strides(t: torch.Tensor, heads: int):
     return (t.stride(0), t.stride(1), t.stride(2))
 
 
-def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale):
+def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale, causal: bool = True):
     """Backward through the C ABI (fa_bwd).  Tensors are [G,L,D] or [B,H,L,D] views with unit inner stride."""
     lib = load_native_library()
     tensors = (q, k, v, out, dout, dq, dk, dv)
@@ -157,6 +203,6 @@ def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale):
         stream = torch.cuda.current_stream().cuda_stream
         rc = lib.fa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
                         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(), G, L, D, heads, arr,
-                        FA_DTYPE[q.dtype], float(scale), 1, stream)
+                        FA_DTYPE[q.dtype], float(scale), int(bool(causal)), stream)
     if rc != 0:
         _raise(rc)

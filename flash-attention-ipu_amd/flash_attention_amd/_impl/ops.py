@@ -76,56 +76,59 @@ fwd_qkv_packed.register_autograd(_packed_backward, setup_context=_packed_setup)
 # ---- three [G, L, D] operands with a softmax scale (training path of the SDPA override) ---------------
 @custom_op("flash_attention_amd::fwd", mutates_args=())
 def fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, softmax_scale: float,
-        num_chunks_q: int, num_chunks_kv: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        num_chunks_q: int, num_chunks_kv: int, causal: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     q, k, v = _rows(q), _rows(k), _rows(v)
     G, L, D = q.shape
     out = torch.empty((G, L, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((G, L), dtype=torch.float32, device=q.device)
     if out.numel() > 0:
         _native.fwd_strided(q, k, v, out, lse, G, L, D, 1, _st3(q), _st3(k), _st3(v), _st3(out),
-                            num_chunks_q, num_chunks_kv, softmax_scale)
+                            num_chunks_q, num_chunks_kv, softmax_scale, causal)
     return out, lse
 
 
 @fwd.register_fake
-def _(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv):
+def _(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
     G, L, D = q.shape
     return q.new_empty((G, L, D)), q.new_empty((G, L), dtype=torch.float32)
 
 
 @custom_op("flash_attention_amd::bwd", mutates_args=())
 def bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor,
-        lse: torch.Tensor, softmax_scale: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        lse: torch.Tensor, softmax_scale: float, causal: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     q, k, v, out, dout = (_rows(t) for t in (q, k, v, out, dout))
     G, L, D = q.shape
     dq, dk, dv = (torch.empty((G, L, D), dtype=q.dtype, device=q.device) for _ in range(3))
     if dq.numel() > 0:
-        _native.bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, 1, softmax_scale)
+        _native.bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, 1, softmax_scale, causal)
     return dq, dk, dv
 
 
 @bwd.register_fake
-def _(q, k, v, out, dout, lse, softmax_scale):
+def _(q, k, v, out, dout, lse, softmax_scale, causal=True):
     return q.new_empty(q.shape), q.new_empty(q.shape), q.new_empty(q.shape)
 
 
 def _fwd_setup(ctx, inputs, output):
-    q, k, v, softmax_scale, _, _ = inputs
+    q, k, v, softmax_scale, _, _, causal = inputs
     out, lse = output
     ctx.save_for_backward(q, k, v, out, lse)
     ctx.softmax_scale = softmax_scale
+    ctx.causal = causal
 
 
 def _fwd_backward(ctx, dout, _dlse):
     q, k, v, out, lse = ctx.saved_tensors
-    dq, dk, dv = bwd(q, k, v, out, dout, lse, ctx.softmax_scale)
-    return dq, dk, dv, None, None, None
+    dq, dk, dv = bwd(q, k, v, out, dout, lse, ctx.softmax_scale, ctx.causal)
+    return dq, dk, dv, None, None, None, None
 
 
 fwd.register_autograd(_fwd_backward, setup_context=_fwd_setup)
 
 
 # ---- inference on [B, H, L, D] views without any copy (strided heads, head-inner output) ---------------
+# key / value may carry fewer heads than the query (grouped-query attention): query head h reads head
+# h // (H / H_kv), resolved inside the kernel - K and V are never expanded.
 def _bhld_out_like(query: torch.Tensor) -> torch.Tensor:
     B, H, L, D = query.shape
     if query.stride(1) < query.stride(2):   # head-inner input ([B, L, H, D] viewed [B, H, L, D]): same layout out
@@ -135,17 +138,17 @@ def _bhld_out_like(query: torch.Tensor) -> torch.Tensor:
 
 @custom_op("flash_attention_amd::fwd_bhld", mutates_args=())
 def fwd_bhld(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, softmax_scale: float,
-             num_chunks_q: int, num_chunks_kv: int) -> torch.Tensor:
+             num_chunks_q: int, num_chunks_kv: int, causal: bool = True) -> torch.Tensor:
+    out = _bhld_out_like(q)   # layout decided from the ORIGINAL argument, exactly as the fake implementation does
     q, k, v = _rows(q), _rows(k), _rows(v)
     B, H, L, D = q.shape
-    out = _bhld_out_like(q)
     if out.numel() > 0:
         st = lambda t: (t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
         _native.fwd_strided(q, k, v, out, None, B * H, L, D, H, st(q), st(k), st(v), st(out),
-                            num_chunks_q, num_chunks_kv, softmax_scale)
+                            num_chunks_q, num_chunks_kv, softmax_scale, causal, heads_kv=k.shape[1])
     return out
 
 
 @fwd_bhld.register_fake
-def _(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv):
+def _(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
     return _bhld_out_like(q)

@@ -26,6 +26,12 @@ def chunk_heuristic(L: int, D: int):
     return int(2 ** (ceil(log2(ratio) / 2))), int(2 ** (floor(log2(ratio) / 2)))
 
 
+def _gqa_ok(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor) -> bool:
+    """[B, H, L, D] query with [B, H_kv, L, D] key / value, H a multiple of H_kv (grouped- / multi-query)."""
+    return (query.ndim == 4 and key.ndim == 4 and key.shape == value.shape and query.shape[0] == key.shape[0]
+            and query.shape[2:] == key.shape[2:] and key.shape[1] >= 1 and query.shape[1] % key.shape[1] == 0)
+
+
 @patch_function(torch.nn.functional.scaled_dot_product_attention, [torch.nn.functional])
 def _scaled_dot_product_attention_amd(
     orig_fn: Callable,
@@ -38,13 +44,19 @@ def _scaled_dot_product_attention_amd(
     scale: Optional[float] = None,
     enable_gqa: bool = False,
 ) -> torch.Tensor:
+    on_device = query.is_cuda and key.is_cuda and value.is_cuda and query.dtype in _native.FA_DTYPE \
+        and query.dtype == key.dtype == value.dtype and query.ndim >= 2
+    # The reference's guards, same order and messages (sdpa.py:21-41).  Two of them are WIDENED on the GPU
+    # (SURVEY 8f-4): is_causal=False and grouped-/multi-query shapes are served by the HIP kernels instead of
+    # raising; off the GPU they raise exactly like the reference.
     if attn_mask is not None:
         raise NotImplementedError("flash_attention_ipu does not currently support passing attn_mask")
     if dropout_p > 0.0:
         raise NotImplementedError("flash_attention_ipu does not currently support non-zero dropout_p")
-    if not is_causal:
+    if not is_causal and not on_device:
         raise NotImplementedError("flash_attention_ipu does not currently support is_causal=False")
-    if query.shape != key.shape:
+    gqa = query.shape != key.shape
+    if gqa and not (on_device and _gqa_ok(query, key, value)):
         raise NotImplementedError(
             "flash_attention_ipu does not currently support Grouped- or Multi-query \
              attention (query.shape != key.shape)"
@@ -52,25 +64,33 @@ def _scaled_dot_product_attention_amd(
     if key.shape != value.shape:
         raise NotImplementedError("flash_attention_ipu does not currently support value.shape != key.shape")
 
-    on_device = query.is_cuda and key.is_cuda and value.is_cuda and query.dtype in _native.FA_DTYPE \
-        and query.dtype == key.dtype == value.dtype and query.ndim >= 2
-    if on_device:
-        L, D = query.shape[-2:]
-        batch_shape = query.shape[:-2]
-        num_chunks_q, num_chunks_kv = chunk_heuristic(L, D)
-        softmax_scale = D ** -0.5 if scale is None else scale
-
-        needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
-        if not needs_grad and query.ndim == 4 and query.numel() > 0:
-            # inference on [B, H, L, D] views (e.g. slices of a fused [B, T, 3C] projection): no copies at all
-            return ops.fwd_bhld(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv)
-        out, _ = ops.fwd(query.reshape(-1, L, D), key.reshape(-1, L, D), value.reshape(-1, L, D),
-                         softmax_scale, num_chunks_q, num_chunks_kv)
-        return out.view(*batch_shape, L, D)
-
     extra = {}
     if scale is not None:
         extra["scale"] = scale
     if enable_gqa:
         extra["enable_gqa"] = enable_gqa
+    # the kernels assume a positive finite scale (exp2 of scale * log2(e) * s with a fixed reference max); anything
+    # else is stock SDPA's business
+    if on_device and scale is not None and not (scale > 0.0 and scale < float("inf")):
+        on_device = False
+    if on_device:
+        L, D = query.shape[-2:]
+        batch_shape = query.shape[:-2]
+        num_chunks_q, num_chunks_kv = chunk_heuristic(L, D)
+        softmax_scale = D ** -0.5 if scale is None else scale
+        causal = bool(is_causal)
+
+        needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
+        if not needs_grad and query.ndim == 4 and query.numel() > 0:
+            # inference on [B, H, L, D] views (e.g. slices of a fused [B, T, 3C] projection): no copies at all;
+            # grouped-query K/V heads are resolved inside the kernel
+            return ops.fwd_bhld(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+        if gqa:   # training with grouped K/V heads: expand them (autograd sums the head gradients back)
+            rep = query.shape[1] // key.shape[1]
+            key = key.repeat_interleave(rep, dim=1)
+            value = value.repeat_interleave(rep, dim=1)
+        out, _ = ops.fwd(query.reshape(-1, L, D), key.reshape(-1, L, D), value.reshape(-1, L, D),
+                         softmax_scale, num_chunks_q, num_chunks_kv, causal)
+        return out.view(*batch_shape, L, D)
+
     return orig_fn(query, key, value, attn_mask, dropout_p, is_causal, **extra)

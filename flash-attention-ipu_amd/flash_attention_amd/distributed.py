@@ -2,18 +2,30 @@
 
 The reference has no distributed layer (it only *describes* head sharding, "no communication between
 chips", demo notebook line 904); groups are a pure batch dimension of every op in the forward
-(FA.cpp:186, grouped matmuls / per-row reductions), so rank r of W simply owns groups
-[r*G/W, (r+1)*G/W) and runs the same kernel on them.  The single exchange step is the gather of the
-output: one RCCL all-gather of [G/W, L, D] per rank over xGMI (`torch.distributed` backend "nccl" is
-RCCL on ROCm; "gloo" on CPU tensors is used by the CPU tests).
+(FA.cpp:186, grouped matmuls / per-row reductions), so rank r of W simply owns G/W groups and runs the same
+kernel on them.  The single exchange step is the gather of the output over xGMI (`torch.distributed` backend
+"nccl" is RCCL on ROCm; "gloo" on CPU tensors is used by the CPU tests).  Three ways to move it:
+
+  "allgather"  one RCCL all-gather of [G/W, L, D] per rank (every rank ends up with the full O);
+  "direct"     the same result as W-1 grouped point-to-point sends and receives per rank: on MI355X every pair of
+               GPUs has its own xGMI link, so each link carries exactly one shard per direction and no ring
+               forwards anything (a ring all-gather is bound by ONE link: ~7x the bytes per link);
+  "root"       gather to rank 0 only (what "a gather of the output" needs at minimum): 1/W of the total traffic,
+               the same per-link load on rank 0's seven links.
+
+`SlabGather` overlaps the exchange with compute inside one call: the local shard is cut into slabs and the gather
+of slab s runs (on RCCL's stream) under the kernel of slab s + 1.
 """
 
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
+from ._impl import _native
 from ._impl.flash_attention_qkv_packed import flash_attention_qkv_packed
+
+GATHER_MODES = ("allgather", "direct", "root")
 
 
 def shard_range(num_groups: int, rank: int, world_size: int) -> Tuple[int, int]:
@@ -24,22 +36,117 @@ def shard_range(num_groups: int, rank: int, world_size: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
-def gather_output(out_local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None, async_op: bool = False):
-    """all-gather of the per-rank outputs [G/W, L, D] -> [G, L, D] (rank-major = group order)."""
+class _Works:
+    """wait() on several point-to-point requests (the handle `gather_output(..., async_op=True)` returns)."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
+
+
+def gather_output(out_local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None, async_op: bool = False,
+                  mode: str = "allgather"):
+    """Gather of the per-rank outputs [G/W, L, D] -> [G, L, D] (rank-major = group order).
+
+    mode "allgather" / "direct": every rank receives everything; "root": only rank 0's buffer is complete (the
+    other ranks' buffers hold their own shard).  Returns `out`, or `(out, work)` with async_op=True."""
+    if mode not in GATHER_MODES:
+        raise ValueError(f"mode must be one of {GATHER_MODES}")
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     out_local = out_local.contiguous()
+    n = out_local.shape[0]
     if out is None:
-        out = torch.empty((world * out_local.shape[0], *out_local.shape[1:]), dtype=out_local.dtype,
-                          device=out_local.device)
-    work = dist.all_gather_into_tensor(out, out_local, group=group, async_op=async_op)
-    return (out, work) if async_op else out
+        out = torch.empty((world * n, *out_local.shape[1:]), dtype=out_local.dtype, device=out_local.device)
+    if mode == "allgather":
+        work = dist.all_gather_into_tensor(out, out_local, group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    # point-to-point forms: my own slot is a local copy, every other slot is filled by its owner
+    out[rank * n:(rank + 1) * n].copy_(out_local)
+    ops: List[dist.P2POp] = []
+    if mode == "direct":
+        for step in range(1, world):   # rank r talks to r+step / r-step: every link busy in both directions at once
+            dst, src = (rank + step) % world, (rank - step) % world
+            ops.append(dist.P2POp(dist.isend, out_local, dist.get_global_rank(group, dst) if group else dst, group))
+            ops.append(dist.P2POp(dist.irecv, out[src * n:(src + 1) * n], dist.get_global_rank(group, src) if group else src, group))
+    elif rank == 0:
+        for src in range(1, world):
+            ops.append(dist.P2POp(dist.irecv, out[src * n:(src + 1) * n], dist.get_global_rank(group, src) if group else src, group))
+    else:
+        ops.append(dist.P2POp(dist.isend, out_local, dist.get_global_rank(group, 0) if group else 0, group))
+    works = _Works(dist.batch_isend_irecv(ops) if ops else [])
+    if async_op:
+        return out, works
+    works.wait()
+    return out
 
 
 def flash_attention_qkv_packed_sharded(qkv_local: torch.Tensor, num_chunks_q: int, num_chunks_kv: int,
-                                       group=None, gather: bool = True) -> torch.Tensor:
+                                       group=None, gather: bool = True, mode: str = "allgather") -> torch.Tensor:
     """Each rank passes ITS shard `qkv_local` [3, G/W, L, D]; returns the full [G, L, D] on every rank
     (or the local [G/W, L, D] with gather=False).  No collective touches Q, K or V."""
     out_local = flash_attention_qkv_packed(qkv_local, num_chunks_q, num_chunks_kv)
     if not gather or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return out_local
-    return gather_output(out_local, group=group)
+    return gather_output(out_local, group=group, mode=mode)
+
+
+class SlabGather:
+    """Forward of one rank's shard in `slabs` pieces with the gather of slab s overlapped with the kernel of
+    slab s + 1 (the exchange of BASELINE config 5: 268 MB of O per rank against ~2 ms of compute).
+
+    Ownership is slab-cyclic so that the gathered buffer IS the global group order: with Gs = G_local / slabs
+    groups per slab, global group g belongs to rank (g // Gs) % W, slab g // (Gs * W); the gathered tensor is
+    [slabs * W * Gs, L, D] = [G, L, D].  (Groups are independent - FA.cpp:186 - so any partition is valid.)
+    Buffers are allocated once; `run` may be called repeatedly (a step of bench.py)."""
+
+    def __init__(self, groups_local: int, L: int, D: int, dtype, device, slabs: int = 4, group=None,
+                 mode: str = "allgather", gather: bool = True):
+        if groups_local % slabs != 0:
+            raise ValueError(f"local groups {groups_local} must be divisible by slabs={slabs}")
+        self.group, self.mode, self.slabs = group, mode, slabs
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.gather = gather and self.world > 1
+        self.gs = groups_local // slabs
+        self.local = torch.empty((slabs, self.gs, L, D), dtype=dtype, device=device)
+        self.full = torch.empty((slabs, self.world * self.gs, L, D), dtype=dtype, device=device) if self.gather else None
+        self.pending = [None] * slabs
+
+    def owned_groups(self, rank: int) -> torch.Tensor:
+        """Global group ids of `rank`'s shard, in the order of its local [G_local] axis."""
+        s = torch.arange(self.slabs)[:, None]
+        i = torch.arange(self.gs)[None, :]
+        return ((s * self.world + rank) * self.gs + i).reshape(-1)
+
+    def run(self, qkv_local: torch.Tensor, num_chunks_q: int, num_chunks_kv: int) -> torch.Tensor:
+        """qkv_local: contiguous [3, G_local, L, D] on this rank's GPU.  Returns [G, L, D] (every rank, or rank 0
+        with mode "root"), or this rank's [G_local, L, D] when there is nothing to gather.  The kernels are
+        enqueued on the current stream, the exchanges on the backend's; the caller synchronises (or calls wait())."""
+        _, gl, L, D = qkv_local.shape
+        gs = self.gs
+        q, k, v = qkv_local[0], qkv_local[1], qkv_local[2]
+        st = (L * D, 0, D)
+        for s in range(self.slabs):
+            if self.pending[s] is not None:        # slab s of the previous call: its gather still reads local[s]
+                self.pending[s].wait()
+                self.pending[s] = None
+            sl = slice(s * gs, (s + 1) * gs)
+            if qkv_local.is_cuda:   # no copy: the slab's q, k, v are contiguous [Gs, L, D] pieces of the shard
+                _native.fwd_strided(q[sl], k[sl], v[sl], self.local[s], None, gs, L, D, 1, st, st, st, st,
+                                    num_chunks_q, num_chunks_kv, 1.0)
+            else:                   # CPU tensors: the op's own CPU branch (fa.py:47-53), as in the packed op
+                self.local[s].copy_(flash_attention_qkv_packed(qkv_local[:, sl], num_chunks_q, num_chunks_kv))
+            if self.gather:
+                _, self.pending[s] = gather_output(self.local[s], group=self.group, out=self.full[s], async_op=True,
+                                                   mode=self.mode)
+        return self.full.view(-1, L, D) if self.gather else self.local.view(gl, L, D)
+
+    def wait(self):
+        for s in range(self.slabs):
+            if self.pending[s] is not None:
+                self.pending[s].wait()
+                self.pending[s] = None

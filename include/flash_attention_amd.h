@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 1
+#define FA_ABI_VERSION 2
 
 /* element types (reference allows FLOAT16 and FLOAT, FA.cpp:609; bf16 is new here) */
 enum { FA_DTYPE_F16 = 0, FA_DTYPE_BF16 = 1, FA_DTYPE_F32 = 2 };
@@ -61,10 +61,13 @@ enum {
     FA_ERR_CHUNKS_Q = -4,           /* L % num_chunks_q != 0   (FA.cpp:190, fa.py:28-31) */
     FA_ERR_CHUNKS_KV = -5,          /* L % num_chunks_kv != 0  (FA.cpp:191, fa.py:32-35) */
     FA_ERR_MISALIGNED = -6,         /* MFMA path needs 16-byte aligned rows */
-    FA_ERR_NOT_CAUSAL = -7,         /* the reference path is causal only (sdpa.py:29-32) */
+    FA_ERR_NOT_CAUSAL = -7,         /* causal must be 0 or 1 (the reference path is causal only, sdpa.py:29-32;
+                                       causal = 0 is a widening) */
     FA_ERR_LAUNCH = -8,             /* hipGetLastError() after the launch */
     FA_ERR_BAD_STRIDE = -9,
-    FA_ERR_TOO_LARGE = -10          /* grid or offsets exceed what the kernel indexes */
+    FA_ERR_TOO_LARGE = -10,         /* grid or offsets exceed what the kernel indexes */
+    FA_ERR_BAD_SCALE = -11,         /* softmax_scale must be finite and > 0 */
+    FA_ERR_BAD_OPTION = -12         /* fa_debug_set_option: unknown name or value out of range */
 };
 
 /* hardware tile the request was mapped to (fa_plan) */
@@ -79,6 +82,12 @@ typedef struct fa_plan_t {
     int32_t chunk_kv;    /* L / num_chunks_kv : the reference's chunkedKVLen */
     int64_t grid;        /* workgroups launched */
     int64_t lds_bytes;   /* LDS per workgroup */
+    int32_t qb;          /* 32-row query blocks per wave (block_q = 32 * waves * qb) */
+    int32_t sched;       /* groups per XCD bunch of the block -> (group, q tile) map */
+    int32_t skipmax;     /* 1 = reference max fixed on a wave's first tile + overflow-triggered redo (bf16 always;
+                            f16 when softmax_scale <= 0.25), 0 = per-tile row max with lazy rescale */
+    int32_t source;      /* 0 = built-in rules, 1 = a row of the measured tuning table (fa_tuning_table.h),
+                            2 = a debug override was in force (fa_debug_set_option / FA_AMD_* at load) */
 } fa_plan_t;
 
 int fa_abi_version(void);
@@ -105,9 +114,25 @@ int fa_probe_clock(void* out2, int32_t spins, void* stream);
 /* [3,G,L,D] -> [G,L,D]; returns FA_OK or FA_ERR_BAD_SHAPE (rank != 4 or dim0 != 3). */
 int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_shape[3]);
 
-/* Host-only: which kernel/tile would serve this request. No GPU needed. */
+/* Host-only: which kernel/tile would serve this request (contiguous, 16-byte aligned operands assumed).
+ * No GPU needed.  fa_fwd() goes through the same selection function with the same inputs, so for aligned
+ * operands the reported plan IS the launched plan.
+ * num_chunks_q  : L / num_chunks_q  is the upper bound of the q tile  (>= 128 -> 4-wave workgroups, 64 -> 2, 32 -> 1)
+ * num_chunks_kv : L / num_chunks_kv is the upper bound of the kv step: >= 64 -> 64-key tiles (or 32-key pipelined
+ *                 steps where those are faster), 32..63 -> 32-key steps; the hardware minimum is 32 keys, smaller
+ *                 chunks are served by 32-key steps (the result does not depend on the chunking). */
 int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q, int32_t num_chunks_kv,
-            fa_plan_t* plan);
+            float softmax_scale, int32_t causal, fa_plan_t* plan);
+
+/* TEST / TUNING ONLY - not part of the data path contract.  Overrides one knob of the tile plan for the whole
+ * process until set back to its "auto" value.  The FA_AMD_* environment variables of round 1 are read ONCE, at the
+ * first call into the library, into the same knobs; nothing reads the environment per launch.
+ *   "kernel"  0 auto | 'd' (64-key tiles, LDS-DMA) | 'p' (pipelined 32-key steps) | 't' (register-staged baseline)
+ *   "qb"      0 auto | 1 | 2        "waves"  0 auto | 1 | 2 | 4 | 8        "sched"  0 auto | n >= 1
+ *   "skipmax" -1 auto | 0 | 1       "f32_generic" 0 | 1                    "table"  1 use the tuning table | 0 rules only
+ * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
+int fa_debug_set_option(const char* name, int32_t value);
+int fa_debug_get_option(const char* name, int32_t* value);
 
 /*
  * Forward on three strided views.  All pointers are device pointers.
@@ -117,12 +142,16 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  *   lse   : optional float32 [G, L] contiguous (NULL to skip)  - the reference's logSumExp stash
  *   heads : inner group count for the 2-level group stride (1 => strides[1] unused, strides[0] is
  *           the group stride)
- *   softmax_scale : multiplies the logits (1.0f reproduces the packed op)
- *   causal : must be 1
+ *   heads_kv : key/value heads (grouped-query attention; the reference rejects it, sdpa.py:33-37):
+ *           must divide `heads`; query head h reads key/value head h / (heads / heads_kv), addressed with
+ *           k_strides / v_strides.  heads_kv == heads is ordinary multi-head attention.
+ *   softmax_scale : multiplies the logits (1.0f reproduces the packed op); must be finite and > 0
+ *   causal : 1 = causal mask (the reference path); 0 = no mask (widening, SURVEY 8f-4: the reference raises
+ *           NotImplementedError, sdpa.py:29-32)
  *   stream : hipStream_t (NULL = default stream)
  */
 int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
-           int64_t G, int64_t L, int64_t D, int64_t heads,
+           int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,
            const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
            const int64_t o_strides[3],
            int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,

@@ -14,6 +14,8 @@ under tests/golden/ (tests/test_oracle.py re-checks the latter on every run).
 from .dense_attention import (  # noqa: F401
     dense_causal_attention,
     dense_causal_attention_lse,
+    dense_causal_attention_rows,
+    dense_attention_lse,
     sdpa_chunk_heuristic,
     frozen_randn,
 )

@@ -63,6 +63,49 @@ def dense_causal_attention_lse(qkv: torch.Tensor, scale: float = 1.0, compute_dt
     return out, lse
 
 
+def dense_attention_lse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float = 1.0, causal: bool = True,
+                        compute_dtype=torch.float64):
+    """Checker for the WIDENED modes (is_causal=False and grouped-/multi-query attention, which the
+    reference rejects - scaled_dot_product_attention.py:29-37 - so there is no reference behaviour to restate):
+    the same dense arithmetic as dense_causal_attention_lse (fa.py:48-53), with the mask optional and with
+    q [B, H, L, D] against k, v [B, H_kv, L, D], query head h reading key/value head h // (H / H_kv)
+    (the semantics of torch SDPA's enable_gqa).  Returns (out [B, H, L, D], lse [B, H, L])."""
+    q, k, v = q.to(compute_dtype), k.to(compute_dtype), v.to(compute_dtype)
+    H, Hkv, L = q.shape[1], k.shape[1], q.shape[2]
+    assert H % Hkv == 0
+    if Hkv != H:
+        k = k.repeat_interleave(H // Hkv, dim=1)
+        v = v.repeat_interleave(H // Hkv, dim=1)
+    s = (q @ k.transpose(-1, -2)) * scale
+    if causal:
+        s = s + torch.triu(torch.full((L, L), MASK_VALUE, dtype=q.dtype), 1)
+    m = s.max(dim=-1, keepdim=True).values
+    p = torch.exp(s - m)
+    l = p.sum(dim=-1, keepdim=True)
+    return (p / l) @ v, (m + torch.log(l)).squeeze(-1)
+
+
+def dense_causal_attention_rows(qkv: torch.Tensor, rows, scale: float = 1.0, compute_dtype=torch.float64):
+    """Rows `rows` of dense_causal_attention_lse's output for EVERY group, without the [L, L] score matrix:
+    out[g, i] = softmax(scale * q[g, rows[i]] @ k[g]^T + mask[rows[i]]) @ v[g]  (fa.py:48-53 restricted to a few
+    query rows) - the oracle for full-size configs (L = 8192 .. 32768) that a dense evaluation cannot reach.
+    qkv: [3, G, L, D] CPU tensor; returns (out [G, len(rows), D], lse [G, len(rows)])."""
+    rows = torch.as_tensor(rows, dtype=torch.long)
+    L = qkv.shape[2]
+    q = qkv[0][:, rows].to(compute_dtype)
+    outs, lses = [], []
+    cols = torch.arange(L)[None, :]
+    mask = torch.where(cols > rows[:, None], torch.tensor(MASK_VALUE, dtype=compute_dtype), torch.tensor(0.0, dtype=compute_dtype))
+    for g in range(qkv.shape[1]):
+        s = (q[g] @ qkv[1, g].to(compute_dtype).T) * scale + mask
+        m = s.max(dim=-1, keepdim=True).values
+        p = torch.exp(s - m)
+        l = p.sum(dim=-1, keepdim=True)
+        outs.append((p / l) @ qkv[2, g].to(compute_dtype))
+        lses.append((m + torch.log(l)).squeeze(-1))
+    return torch.stack(outs), torch.stack(lses)
+
+
 def sdpa_chunk_heuristic(L: int, D: int):
     """(num_chunks_q, num_chunks_kv) exactly as sdpa.py:52-53 chooses them."""
     r = max(L, D) // D

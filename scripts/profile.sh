@@ -1,14 +1,17 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun) from the repo root:  bash scripts/profile.sh <tag> [bench args]
-# Produces gpurun_out/prof_<tag>/{kernel_stats.csv, pmc_*.csv summaries}.  Counters are collected in
-# their own passes (never together with sys/hip tracing), as the pool requires.
+# Run on the GPU box (via gpurun) from the repo root:  bash scripts/profile.sh <tag> [bench args, e.g. --config cfg3]
+# Produces gpurun_out/prof_<tag>/{kernel_stats.csv, pmc_*.csv summaries, hbm_traffic_entry.json}.  Counters are
+# collected in their own passes (never together with sys/hip tracing), as the pool requires.
+# hbm_traffic_entry.json = the record to merge into profiles/hbm_traffic.json under the config's name: HBM bytes per
+# launch (2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE), the kernel's name and the
+# sha256 of the kernel sources it was measured on - bench.py reports `traffic` only when both still match.
 set -u
 TAG=${1:-run}; shift || true
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline $*"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-secondary $*"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH --steps 20 --warmup 5 > $OUT/kt.log 2>&1
 python3 - "$OUT" <<'PY'
@@ -55,5 +58,27 @@ pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc l2 TCC_HIT_sum TCC_MISS_sum
 pmc grbm GRBM_GUI_ACTIVE
+python3 - "$OUT" "$TAG" "$(python3 $R/bench.py --print-csrc-fingerprint)" <<'PY'
+import csv, json, sys
+out, tag, sha = sys.argv[1:4]
+def val(name, counter):
+    for r in csv.DictReader(open(f"{out}/pmc_{name}.csv")):
+        if r["counter"] == counter:
+            return float(r["mean_per_dispatch"])
+    return None
+fetch, write = val("fetch", "FETCH_SIZE"), val("write", "WRITE_SIZE")   # KiB per dispatch
+import re
+kern = ""
+try:
+    m = re.search(r"fa_fwd_[a-z0-9]+_kernel", open(f"{out}/dispatch_info.txt").read())
+    kern = m.group(0) if m else ""
+except Exception:
+    pass
+rec = {"kernel": kern, "csrc_sha256_16": sha, "source": f"profiles/{tag}",
+       "fetch_size_kib": fetch, "write_size_kib": write,
+       "hbm_bytes_per_launch": round((2 * fetch + write) * 1024) if fetch is not None and write is not None else None}
+json.dump(rec, open(f"{out}/hbm_traffic_entry.json", "w"), indent=1)
+print(json.dumps(rec))
+PY
 rm -rf $OUT/kt $OUT/pmc_*/
 ls $OUT

@@ -35,6 +35,8 @@ def getlib(name):
         lib = ctypes.CDLL(str(path))
         lib.fa_fwd_qkv_packed.restype = ctypes.c_int
         lib.fa_fwd_qkv_packed.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_int32] * 3 + [ctypes.c_void_p]
+        lib.fa_debug_set_option.restype = ctypes.c_int
+        lib.fa_debug_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int32]
         libs[name] = lib
     return libs[name]
 
@@ -42,18 +44,21 @@ def parse(spec):
     name, _, rest = spec.rpartition(":")
     return name, rest
 
-def setenv(rest):
-    for k in ("FA_AMD_KERNEL", "FA_AMD_WAVES", "FA_AMD_SCHED", "FA_AMD_QB"):
-        os.environ.pop(k, None)
+def setknobs(lib, rest):
+    """knobs go through fa_debug_set_option of THAT library (the environment is only read once, at load)"""
+    want = {"kernel": 0, "waves": 0, "sched": 0, "qb": 0}
     for kv in rest.split(","):
         if kv:
             k, val = kv.split("=")
-            os.environ[{"K": "FA_AMD_KERNEL", "W": "FA_AMD_WAVES", "S": "FA_AMD_SCHED", "Q": "FA_AMD_QB"}[k]] = val
+            name = {"K": "kernel", "W": "waves", "S": "sched", "Q": "qb"}[k]
+            want[name] = ord(val[0]) if name == "kernel" else int(val)
+    for name, val in want.items():
+        assert lib.fa_debug_set_option(name.encode(), val) == 0, (name, val)
 
 def timeit(spec, n):
     name, rest = parse(spec)
     lib = getlib(name)
-    setenv(rest)
+    setknobs(lib, rest)
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

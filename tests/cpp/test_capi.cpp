@@ -42,7 +42,7 @@ int main() {
 
     if (fa_abi_version() != FA_ABI_VERSION) { std::printf("ABI mismatch\n"); return 1; }
     fa_plan_t plan;
-    if (fa_plan(G, L, D, FA_DTYPE_BF16, 1, 1, &plan) != FA_OK || plan.kernel == 1) { std::printf("plan: %s\n", fa_last_error()); return 1; }   // an MFMA kernel (0 or 2)
+    if (fa_plan(G, L, D, FA_DTYPE_BF16, 1, 1, 1.0f, 1, &plan) != FA_OK || plan.kernel == 1) { std::printf("plan: %s\n", fa_last_error()); return 1; }   // an MFMA kernel (0 or 2)
     if (fa_fwd_qkv_packed(d_qkv, d_out, d_lse, G, L, D, 7, 1, FA_DTYPE_BF16, nullptr) != FA_ERR_CHUNKS_Q) { std::printf("expected FA_ERR_CHUNKS_Q\n"); return 1; }
     int rc = fa_fwd_qkv_packed(d_qkv, d_out, d_lse, G, L, D, 1, 1, FA_DTYPE_BF16, nullptr);
     if (rc != FA_OK) { std::printf("fa_fwd_qkv_packed: %s\n", fa_last_error()); return 1; }

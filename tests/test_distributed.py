@@ -1,4 +1,5 @@
-"""world_size-2 gloo tests of the sharded path on CPU (runs without a GPU)."""
+"""world_size-2 (and 3) gloo tests of the sharded path on CPU (runs without a GPU): the all-gather, the direct
+point-to-point gather, the gather to rank 0 and the slab-overlapped variant, plus bench.py's self-launch."""
 
 import os
 import socket
@@ -39,13 +40,35 @@ def _worker(rank, world, port, G, L, D, q):
         out, work = gather_output(local, async_op=True)
         work.wait()
         ok = ok and torch.equal(out, full)
+        for mode in ("direct", "root"):
+            got = flash_attention_qkv_packed_sharded(qkv[:, lo:hi].contiguous(), 2, 2, mode=mode)
+            if mode == "direct" or rank == 0:
+                ok = ok and torch.equal(got, full)
+            else:
+                ok = ok and torch.equal(got[lo:hi], full[lo:hi])
+            out, work = gather_output(local, async_op=True, mode=mode)
+            work.wait()
+            ok = ok and (torch.equal(out, full) if (mode == "direct" or rank == 0) else torch.equal(out[lo:hi], local))
+        # slab-overlapped gather: slab-cyclic ownership, the gathered buffer is in global group order
+        from flash_attention_amd.distributed import SlabGather
+
+        for mode in ("allgather", "direct"):
+            sg = SlabGather(G // world, L, D, torch.float32, "cpu", slabs=G // world, mode=mode)
+            mine = sg.owned_groups(rank)
+            for _ in range(2):    # twice: the second call waits for the first call's exchanges per slab
+                got = sg.run(qkv[:, mine].contiguous(), 2, 2)
+            sg.wait()
+            ok = ok and got.shape == (G, L, D) and torch.allclose(got, ref, atol=1e-6)
+        owners = torch.cat([SlabGather(G // world, L, D, torch.float32, "cpu", slabs=G // world).owned_groups(r) for r in range(world)])
+        ok = ok and sorted(owners.tolist()) == list(range(G))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_forward_world2_gloo():
-    world, G, L, D = 2, 6, 32, 8
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_forward_gloo(world):
+    G, L, D = 6, 32, 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -56,7 +79,7 @@ def test_sharded_forward_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(results) == [(0, True), (1, True)]
+    assert sorted(results) == [(r, True) for r in range(world)]
 
 
 def test_shard_range():
@@ -65,3 +88,21 @@ def test_shard_range():
     assert [shard_range(128, r, 8) for r in (0, 7)] == [(0, 16), (112, 128)]
     with pytest.raises(ValueError):
         shard_range(10, 0, 4)
+
+
+def test_bench_self_launches_rank_processes_before_touching_the_gpu():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts 2 fresh rank processes (one
+    torch.distributed.run child) and relays their exit code.  On this CPU-only box each rank stops at "needs a GPU" -
+    which proves the ranks were started (RANK/WORLD_SIZE set) and that the parent itself never needed the GPU."""
+    import pathlib
+    import subprocess
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check (on a GPU box the N > 1 control flow is rehearsed with FA_BENCH_REHEARSE=1)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0
+    assert res.stderr.count("bench.py needs a GPU") >= 2, res.stderr[-2000:]
+    assert "but WORLD_SIZE" not in res.stderr

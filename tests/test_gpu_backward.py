@@ -58,13 +58,13 @@ def test_packed_backward_vs_oracle(dtype, G, L, D):
 
 
 @pytest.mark.parametrize("kernel", ["pipe", "tile"])
-def test_backward_after_every_forward_kernel(monkeypatch, kernel):
+def test_backward_after_every_forward_kernel(knobs, kernel):
     """The backward consumes the forward's `out` and log-sum-exp: the same gradients whichever forward kernel
     produced them (the default at these sizes is the 64-key-tile kernel, covered above)."""
     import flash_attention_amd as fa
     from oracle import frozen_randn
 
-    monkeypatch.setenv("FA_AMD_KERNEL", kernel)
+    knobs.set("FA_AMD_KERNEL", kernel)
     G, L, D, dtype = 2, 1024, 64, torch.bfloat16
     qkv = (frozen_randn(SEED + L + D, (3, G, L, D)) * 0.5).to(dtype)
     dout = frozen_randn(SEED + 1, (G, L, D)).to(dtype)

@@ -79,17 +79,17 @@ def test_packed_vs_oracle(dtype, G, L, D, nq, nk):
 
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
 @pytest.mark.parametrize("D", [64, 128])
-def test_every_tile_variant(monkeypatch, waves, D):
+def test_every_tile_variant(knobs, waves, D):
     """All hardware q-tile sizes (32..256 rows) give the same answer."""
     fa, native, _ = _mods()
     from oracle import frozen_randn
 
-    monkeypatch.setenv("FA_AMD_WAVES", str(waves))
+    knobs.set("FA_AMD_WAVES", str(waves))
     qkv = frozen_randn(SEED + waves, (3, 3, 600, D)).to(torch.bfloat16)
     ref, _ = _oracle(qkv)
     out = fa.flash_attention_qkv_packed(qkv.cuda(), 1, 1)
     _check(out, ref, torch.bfloat16, f"waves={waves} D={D}")
-    monkeypatch.setenv("FA_AMD_SCHED", "1")
+    knobs.set("FA_AMD_SCHED", "1")
     out_b = fa.flash_attention_qkv_packed(qkv.cuda(), 1, 1)
     assert torch.equal(out, out_b), "block->tile schedule changed the result"
 
@@ -99,15 +99,15 @@ MFMA_KERNELS = [("dma", 1), ("dma", 2), ("pipe", 1), ("pipe", 2), ("tile", 1)]
 
 @pytest.mark.parametrize("kernel,qb", MFMA_KERNELS)
 @pytest.mark.parametrize("G,L,D", [(2, 32, 64), (9, 257, 64), (3, 600, 64), (2, 2304, 64), (1, 4608, 64), (2, 1000, 128)])
-def test_every_mfma_kernel(monkeypatch, kernel, qb, G, L, D):
+def test_every_mfma_kernel(knobs, kernel, qb, G, L, D):
     """The three MFMA kernels (64-key tiles with LDS-DMA, software-pipelined 32-key steps, register-staged
     baseline), with one and two 32-row query blocks per wave, against the oracle - whatever the default
     selection for a shape is.  (Two blocks exist for head_dim 64 only; the request falls back to one otherwise.)"""
     _, _, with_lse = _mods()
     from oracle import frozen_randn
 
-    monkeypatch.setenv("FA_AMD_KERNEL", kernel)
-    monkeypatch.setenv("FA_AMD_QB", str(qb))
+    knobs.set("FA_AMD_KERNEL", kernel)
+    knobs.set("FA_AMD_QB", str(qb))
     qkv = frozen_randn(SEED + 7 * L + D, (3, G, L, D)).to(torch.bfloat16)
     ref, ref_lse = _oracle(qkv)
     out, lse = with_lse(qkv.cuda(), 1, 1)
@@ -128,7 +128,7 @@ def test_tiny_fp32_all_chunk_pairs(golden_dir, nq, nk):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("G,L,D", [(2, 6, 2), (2, 33, 7), (3, 70, 24), (2, 300, 80), (8, 256, 128), (1, 1500, 32), (2, 1, 64), (1, 1, 1)])
-def test_generic_kernel(monkeypatch, dtype, G, L, D):
+def test_generic_kernel(knobs, dtype, G, L, D):
     """Shapes the generic kernel serves (odd D, L=1, and fp32 at any head dim when the fp32 MFMA kernel is switched
     off) - incl. t_cpp:256-259's fp32 8x256x128."""
     fa, native, _ = _mods()
@@ -137,7 +137,7 @@ def test_generic_kernel(monkeypatch, dtype, G, L, D):
     if dtype != torch.float32 and D in (64, 128):
         pytest.skip("served by the MFMA kernel")
     if dtype == torch.float32 and D in (64, 128):
-        monkeypatch.setenv("FA_AMD_F32", "generic")      # (the fp32 MFMA kernel has its own test below)
+        knobs.set("FA_AMD_F32", "generic")      # (the fp32 MFMA kernel has its own test below)
     qkv = (frozen_randn(SEED + D, (3, G, L, D)) * (1.0 if D > 16 else 2.0)).to(dtype)
     assert native.plan(G, L, D, dtype, 1, 1).kernel == 1
     ref, ref_lse = _oracle(qkv)
@@ -213,7 +213,7 @@ def test_sdpa_override_vs_oracle(dtype, batch_shape, L):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("kernel", ["", "dma", "pipe"])
-def test_sdpa_long_sequence_scaled_logits(monkeypatch, dtype, kernel):
+def test_sdpa_long_sequence_scaled_logits(knobs, dtype, kernel):
     """The SDPA override at L = 4096 with a [B, T, 3C]-style head-inner projection (strided q/k/v views): the
     1/sqrt(D) scale selects the skip-max arithmetic for f16 too, so the default here is the pipelined kernel for
     both dtypes (G = 64 groups x 16 row tiles = 1024 workgroups); forced kernels for comparison."""
@@ -224,7 +224,7 @@ def test_sdpa_long_sequence_scaled_logits(monkeypatch, dtype, kernel):
     from oracle import frozen_randn
 
     if kernel:
-        monkeypatch.setenv("FA_AMD_KERNEL", kernel)
+        knobs.set("FA_AMD_KERNEL", kernel)
     B, H, L, D = 4, 16, 4096, 64
     assert native.plan(B * H, L, D, torch.bfloat16, 8, 8).kernel == (0 if kernel == "dma" else 2)
     x = frozen_randn(SEED + 4096, (B, L, 3 * H * D)).to(dtype).cuda()
@@ -280,7 +280,7 @@ def test_forced_rescale_spike():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_full_size_properties_config2(monkeypatch, dtype):
+def test_full_size_properties_config2(knobs, dtype):
     """BASELINE config 2 (G=128, L=4096, D=64): size-independent properties + oracle on sampled groups."""
     fa, native, _ = _mods()
     G, L, D = 128, 4096, 64
@@ -314,11 +314,11 @@ def test_full_size_properties_config2(monkeypatch, dtype):
     d_, r_ = (trunc.float() - out[:, :Lt].float()).abs(), out[:, :Lt].float().abs()
     assert bool((d_ <= 1e-2 + 2.0 ** -6 * r_).all()), f"truncated, default kernel: max|delta|={d_.max().item():.3e}"
     plan = native.plan(G, L, D, dtype, 8, 8)
-    monkeypatch.setenv("FA_AMD_KERNEL", "pipe" if plan.kernel == 2 else "dma")
-    monkeypatch.setenv("FA_AMD_QB", str(plan.block_q // (32 * plan.waves)))
+    knobs.set("FA_AMD_KERNEL", "pipe" if plan.kernel == 2 else "dma")
+    knobs.set("FA_AMD_QB", str(plan.block_q // (32 * plan.waves)))
     assert torch.equal(fa.flash_attention_qkv_packed(qkv[:, :, :Lt].contiguous(), 8, 8), out[:, :Lt])
-    monkeypatch.delenv("FA_AMD_KERNEL")
-    monkeypatch.delenv("FA_AMD_QB")
+    knobs.reset("FA_AMD_KERNEL")
+    knobs.reset("FA_AMD_QB")
     # (6) the chunk counts never change the result beyond rounding; same hardware tile => identical
     assert torch.equal(fa.flash_attention_qkv_packed(qkv, 16, 4), out)
     # (7) oracle on sampled groups
@@ -343,6 +343,60 @@ def test_long_context_config3_sampled():
     ref = torch.softmax(s, dim=-1) @ qkv[2].double()
     err = (out[:, rows].double() - ref).abs()
     assert bool((err <= 1e-2 + 1e-2 * ref.abs()).all()), err.max().item()
+
+
+def test_long_context_config3_full_groups_vs_oracle_rows():
+    """BASELINE config 3 as written (G = 16, L = 32768, D = 128, bf16): the whole launch, checked against the CPU
+    oracle (oracle.dense_causal_attention_rows: fa.py:48-53 restricted to sampled query rows) for every group."""
+    fa, native, with_lse = _mods()
+    from oracle import dense_causal_attention_rows
+
+    G, L, D = 16, 32768, 128
+    plan = native.plan(G, L, D, torch.bfloat16, 16, 16)
+    assert (plan.kernel, plan.waves, plan.block_q) == (0, 8, 256)          # the 8-wave D = 128 kernel
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    qkv = torch.randn(3, G, L, D, device="cuda", generator=gen).to(torch.bfloat16)
+    out, lse = with_lse(qkv, 16, 16)
+    assert torch.isfinite(out).all() and torch.equal(out[:, 0], qkv[2, :, 0])
+    rows = [1, 31, 32, 255, 256, 4095, 4096, 16383, 20000, 32767]
+    ref, ref_lse = dense_causal_attention_rows(qkv.cpu(), rows)
+    _check(out[:, rows], ref, torch.bfloat16, "config 3, G=16, sampled rows")
+    torch.testing.assert_close(lse[:, rows].cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+
+
+def test_config5_per_gpu_shard_shape(knobs):
+    """BASELINE config 5's per-GPU shard at 8 GPUs: [3, 256, 8192, 64] bf16 (G = 2048 / 8): size-independent
+    properties on the whole launch + the dense oracle on sampled groups + oracle rows on every group."""
+    fa, native, with_lse = _mods()
+    from oracle import dense_causal_attention_rows
+
+    G, L, D = 256, 8192, 64
+    plan = native.plan(G, L, D, torch.bfloat16, 16, 8)
+    assert (plan.kernel, plan.block_q) == (2, 256)                          # pipelined kernel, 128 steps per last wave
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    qkv = torch.randn(3, G, L, D, device="cuda", generator=gen).to(torch.bfloat16)
+    out, lse = with_lse(qkv, 16, 8)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out[:, 0], qkv[2, :, 0])                             # row 0 sees key 0 only
+    v32 = qkv[2].float()
+    lo, hi = torch.cummin(v32, dim=1).values, torch.cummax(v32, dim=1).values
+    assert bool(((out.float() >= lo - 2e-2) & (out.float() <= hi + 2e-2)).all())   # convexity
+    del v32, lo, hi
+    perm = torch.randperm(G, device="cuda", generator=gen)                  # groups are independent
+    assert torch.equal(fa.flash_attention_qkv_packed(qkv[:, perm].contiguous(), 16, 8), out[perm])
+    Lt = 4352                                                               # causal truncation, same kernel forced
+    knobs.set("kernel", "pipe")
+    knobs.set("qb", 2)
+    assert torch.equal(fa.flash_attention_qkv_packed(qkv[:, :, :Lt].contiguous(), 16, 8), out[:, :Lt])
+    knobs.reset()
+    assert torch.equal(fa.flash_attention_qkv_packed(qkv, 4, 4), out)       # chunk counts change nothing (same tile)
+    rows = [1, 63, 64, 255, 256, 4095, 4096, 8000, 8191]
+    ref, ref_lse = dense_causal_attention_rows(qkv.cpu(), rows)
+    _check(out[:, rows], ref, torch.bfloat16, "config 5 shard, sampled rows of every group")
+    torch.testing.assert_close(lse[:, rows].cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+    for gidx in (0, 255):
+        ref, _ = _oracle(qkv[:, gidx:gidx + 1])
+        _check(out[gidx:gidx + 1], ref, torch.bfloat16, f"config 5 shard group {gidx}")
 
 
 def test_error_paths_through_c_abi():
@@ -427,7 +481,7 @@ def test_cpp_caller_of_the_c_abi(tmp_path):
 @pytest.mark.parametrize("kernel,qb", [("", 0), ("dma", 2), ("pipe", 1), ("pipe", 2)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
-def test_growing_logits_force_the_redo_branch(monkeypatch, dtype, step, kernel, qb):
+def test_growing_logits_force_the_redo_branch(knobs, dtype, step, kernel, qb):
     """The bf16 kernel keeps its reference max from the first tile and only redoes a tile (exact max +
     rescale) when a row sum shows that some P left the safe range (cdna guide rule 26: a rare,
     data-dependent branch needs inputs that FORCE it and a full-tensor independent reference).
@@ -438,8 +492,8 @@ def test_growing_logits_force_the_redo_branch(monkeypatch, dtype, step, kernel, 
     from oracle import frozen_randn
 
     if kernel:
-        monkeypatch.setenv("FA_AMD_KERNEL", kernel)
-        monkeypatch.setenv("FA_AMD_QB", str(qb))
+        knobs.set("FA_AMD_KERNEL", kernel)
+        knobs.set("FA_AMD_QB", str(qb))
 
     G, L, D = 2, 1024, 64
     x = frozen_randn(SEED + 55, (3, G, L, D)) * 0.05

@@ -1,0 +1,191 @@
+"""GPU tests of the modes the reference REJECTS and this build serves (the guards at
+flash_attention_ipu/_impl/scaled_dot_product_attention.py:29-37): is_causal=False and grouped-/multi-query
+attention, forward and backward, plus the host-side edge cases around them (softmax scale <= 0, kv chunk -> kv step).
+The checker is oracle.dense_attention_lse (the reference's dense arithmetic, fa.py:48-53, with the mask optional and
+K/V heads expanded) evaluated in fp64 on the same 16-bit-rounded inputs; tolerances as in test_gpu_parity.py."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+SEED = 1123581321
+MAXABS = {torch.float16: 1e-2, torch.bfloat16: 3e-2, torch.float32: 1e-4}
+
+
+def _check(out, ref, dtype, what):
+    out = out.detach().cpu().double()
+    err = (out - ref).abs()
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    if dtype != torch.float32:
+        bad = err > (1e-2 + 1e-2 * ref.abs())
+        assert not bool(bad.any()), f"{what}: {int(bad.sum())} elements out of tolerance, max|delta|={err.max().item():.3e}"
+    assert err.max().item() <= MAXABS[dtype], f"{what}: max|delta|={err.max().item():.3e}"
+
+
+def _fwd(q, k, v, scale, causal, lse=True):
+    """fa_fwd through the C ABI on [B, H, L, D] q and [B, H_kv, L, D] k, v."""
+    from flash_attention_amd._impl import _native
+
+    B, H, L, D = q.shape
+    out = torch.empty_like(q)
+    lse_t = torch.empty(B * H, L, device=q.device, dtype=torch.float32) if lse else None
+    st = lambda t: (t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
+    _native.fwd_strided(q, k, v, out, lse_t, B * H, L, D, H, st(q), st(k), st(v), st(out), 1, 1, scale, causal,
+                        heads_kv=k.shape[1])
+    return out, lse_t
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("B,H,L,D", [(1, 2, 32, 64), (2, 3, 200, 64), (1, 5, 257, 64), (2, 2, 1000, 128), (1, 3, 70, 24), (1, 1, 2304, 64)])
+def test_noncausal_forward_vs_oracle(dtype, B, H, L, D):
+    from oracle import dense_attention_lse, frozen_randn
+
+    x = frozen_randn(SEED + L + D, (3, B, H, L, D)).to(dtype)
+    scale = D ** -0.5
+    ref, ref_lse = dense_attention_lse(x[0], x[1], x[2], scale=scale, causal=False)
+    q, k, v = x.cuda()
+    out, lse = _fwd(q, k, v, scale, False)
+    _check(out, ref, dtype, f"non-causal {dtype} {B}x{H}x{L}x{D}")
+    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("kernel,qb,waves", [("dma", 1, 4), ("dma", 2, 4), ("dma", 1, 8), ("dma", 1, 1), ("tile", 1, 4), ("pipe", 2, 4)])
+def test_noncausal_every_kernel_variant(knobs, kernel, qb, waves):
+    """is_causal=False through every MFMA kernel that serves it (a forced 'pipe' falls back to the 64-key-tile
+    kernel: the pipelined order is causal by construction), ragged L, unscaled bf16 logits."""
+    from oracle import dense_attention_lse, frozen_randn
+
+    knobs.set("kernel", kernel)
+    knobs.set("qb", qb)
+    knobs.set("waves", waves)
+    B, H, L, D = 1, 3, 600, 64
+    x = (frozen_randn(SEED + 5, (3, B, H, L, D)) * 0.6).to(torch.bfloat16)
+    ref, ref_lse = dense_attention_lse(x[0], x[1], x[2], scale=1.0, causal=False)
+    q, k, v = x.cuda()
+    out, lse = _fwd(q, k, v, 1.0, False)
+    _check(out, ref, torch.bfloat16, f"non-causal kernel={kernel} qb={qb} waves={waves}")
+    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("H,Hkv", [(8, 2), (6, 1), (4, 4)])
+def test_grouped_query_forward_vs_oracle(dtype, causal, H, Hkv):
+    """Query head h reads key/value head h // (H / H_kv) inside the kernel; K and V are never expanded."""
+    from oracle import dense_attention_lse, frozen_randn
+
+    B, L, D = 2, 300, 64
+    q = frozen_randn(SEED + H, (B, H, L, D)).to(dtype)
+    k = frozen_randn(SEED + H + 1, (B, Hkv, L, D)).to(dtype)
+    v = frozen_randn(SEED + H + 2, (B, Hkv, L, D)).to(dtype)
+    scale = D ** -0.5
+    ref, ref_lse = dense_attention_lse(q, k, v, scale=scale, causal=causal)
+    out, lse = _fwd(q.cuda(), k.cuda(), v.cuda(), scale, causal)
+    _check(out, ref, dtype, f"gqa {dtype} H={H} Hkv={Hkv} causal={causal}")
+    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+
+
+def test_grouped_query_long_sequence_pipelined_kernel():
+    """GQA through the default kernel of the headline regime (L = 4096, D = 64: pipelined, two query blocks)."""
+    from flash_attention_amd._impl import _native
+    from oracle import dense_attention_lse
+
+    B, H, Hkv, L, D = 4, 16, 4, 4096, 64
+    assert _native.plan(B * H, L, D, torch.bfloat16, 8, 8, softmax_scale=D ** -0.5).kernel == 2
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    q = torch.randn(B, H, L, D, device="cuda", generator=gen).to(torch.bfloat16)
+    k = torch.randn(B, Hkv, L, D, device="cuda", generator=gen).to(torch.bfloat16)
+    v = torch.randn(B, Hkv, L, D, device="cuda", generator=gen).to(torch.bfloat16)
+    out = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True)
+    for b, h in ((0, 0), (3, 15), (2, 9)):
+        ref, _ = dense_attention_lse(q[b:b + 1, h:h + 1].cpu(), k[b:b + 1, h // 4:h // 4 + 1].cpu(),
+                                     v[b:b + 1, h // 4:h // 4 + 1].cpu(), scale=D ** -0.5, causal=True)
+        _check(out[b:b + 1, h:h + 1], ref, torch.bfloat16, f"gqa L=4096 ({b},{h})")
+
+
+def test_sdpa_override_serves_the_widened_modes():
+    """On the GPU the override no longer raises for is_causal=False / grouped-query shapes (it still raises for
+    attn_mask and dropout, like the reference); results agree with the fp64 oracle and with stock SDPA."""
+    import flash_attention_amd.auto  # noqa: F401
+    from oracle import dense_attention_lse, frozen_randn
+
+    patched = F.scaled_dot_product_attention
+    stock = patched.__wrapped__
+    B, H, Hkv, L, D = 2, 6, 2, 384, 64
+    q = frozen_randn(SEED + 40, (B, H, L, D)).to(torch.bfloat16).cuda()
+    k = frozen_randn(SEED + 41, (B, Hkv, L, D)).to(torch.bfloat16).cuda()
+    v = frozen_randn(SEED + 42, (B, Hkv, L, D)).to(torch.bfloat16).cuda()
+    kf, vf = k.repeat_interleave(H // Hkv, 1), v.repeat_interleave(H // Hkv, 1)
+    for causal in (True, False):
+        ref, _ = dense_attention_lse(q.cpu(), k.cpu(), v.cpu(), scale=D ** -0.5, causal=causal)
+        _check(patched(q, k, v, is_causal=causal, enable_gqa=True), ref, torch.bfloat16, f"override gqa causal={causal}")
+        _check(patched(q, kf, vf, is_causal=causal), ref, torch.bfloat16, f"override mha causal={causal}")
+        _check(stock(q, kf, vf, is_causal=causal), ref, torch.bfloat16, f"stock sdpa causal={causal}")   # same yardstick
+    with pytest.raises(NotImplementedError, match="attn_mask"):
+        patched(q, kf, vf, attn_mask=torch.ones(L, L, dtype=torch.bool, device="cuda"))
+    with pytest.raises(NotImplementedError, match="dropout_p"):
+        patched(q, kf, vf, dropout_p=0.1, is_causal=True)
+    with pytest.raises(NotImplementedError, match="Grouped- or Multi-query"):   # 6 query heads over 4 kv heads: not a grouping
+        patched(q, k.repeat_interleave(2, 1), v.repeat_interleave(2, 1), is_causal=True)
+
+
+@pytest.mark.parametrize("scale", [0.0, -0.125])
+def test_sdpa_nonpositive_scale_goes_to_stock_sdpa(scale):
+    """A softmax scale <= 0 is outside what the kernels compute (fixed reference max, exp2 of scale*log2e*s): the
+    override hands it to stock SDPA (valid softmax), and the C ABI refuses it (FA_ERR_BAD_SCALE)."""
+    import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl import _native
+    from oracle import frozen_randn
+
+    patched = F.scaled_dot_product_attention
+    q, k, v = frozen_randn(SEED + 50, (3, 2, 2, 128, 64)).to(torch.bfloat16).cuda()
+    out = patched(q, k, v, is_causal=True, scale=scale)
+    ref = patched.__wrapped__(q, k, v, is_causal=True, scale=scale)
+    assert torch.isfinite(out).all() and torch.equal(out, ref)
+    with pytest.raises(ValueError, match="softmax_scale must be finite and > 0"):
+        _fwd(q, k, v, scale, True)
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.float16, 128), (torch.float32, 64), (torch.bfloat16, 24)])
+def test_backward_causal_and_noncausal_vs_oracle_autograd(dtype, D, causal):
+    """dQ, dK, dV through the SDPA override (MFMA backward kernels, generic kernels for fp32 / odd head dims) against
+    autograd through the fp64 oracle, for both mask modes; grouped K/V heads are expanded for training and autograd
+    sums their gradients back."""
+    import flash_attention_amd.auto  # noqa: F401
+    from oracle import dense_attention_lse, frozen_randn
+
+    B, H, Hkv, L = 2, 4, 2, 200
+    q0 = (frozen_randn(SEED + 60, (B, H, L, D)) * 0.7).to(dtype)
+    k0 = (frozen_randn(SEED + 61, (B, Hkv, L, D)) * 0.7).to(dtype)
+    v0 = frozen_randn(SEED + 62, (B, Hkv, L, D)).to(dtype)
+    g0 = frozen_randn(SEED + 63, (B, H, L, D)).to(dtype)
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q0, k0, v0))
+    ref, _ = dense_attention_lse(qr, kr, vr, scale=D ** -0.5, causal=causal)
+    ref.backward(g0.double())
+    q, k, v = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
+    out = F.scaled_dot_product_attention(q, k, v, is_causal=causal, enable_gqa=True)
+    out.backward(g0.cuda())
+    tol = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2, torch.float32: 1e-5}[dtype]
+    for name, got, want in (("out", out, ref.detach()), ("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+        got = got.detach().cpu().double()
+        err = (got - want).abs()
+        floor = tol * max(1e-3, want.abs().max().item())
+        assert torch.isfinite(got).all(), name
+        assert bool((err <= floor + 2e-2 * want.abs()).all()), f"{name} {dtype} D={D} causal={causal}: max|d|={err.max().item():.3e}"
+
+
+def test_kv_chunk_below_64_keys_runs_32_key_steps(knobs):
+    """num_chunks_kv is honoured where it is a real tile size: a kv chunk of 32 keys selects the 32-key pipelined
+    steps; the result agrees with the default plan within rounding (the reference's chunk-independence)."""
+    import flash_attention_amd as fa
+    from flash_attention_amd._impl import _native
+    from oracle import dense_causal_attention_lse, frozen_randn
+
+    G, L, D = 3, 1024, 64
+    assert _native.plan(G, L, D, torch.bfloat16, 4, 32).block_kv == 32 and _native.plan(G, L, D, torch.bfloat16, 4, 4).block_kv == 64
+    qkv = frozen_randn(SEED + 70, (3, G, L, D)).to(torch.bfloat16)
+    ref, _ = dense_causal_attention_lse(qkv)
+    for nk in (4, 32):
+        _check(fa.flash_attention_qkv_packed(qkv.cuda(), 4, nk), ref, torch.bfloat16, f"num_chunks_kv={nk}")

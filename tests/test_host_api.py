@@ -43,13 +43,13 @@ def test_library_exports_every_declared_symbol(native):
     lib = native.load_native_library()
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/flash_attention_amd.h but not exported"
-    assert lib.fa_abi_version() == 1
+    assert lib.fa_abi_version() == 2
     assert native.library_path().name == "libflash_attention.so"
 
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 1;}\n')
+    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 2;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
 
 
@@ -62,12 +62,42 @@ def test_c_abi_argument_validation(native):
     bad = (ctypes.c_int64 * 4)(2, 8, 128, 64)
     assert lib.fa_infer_output_shape(bad, 4, out) == -2 and b"size 3" in lib.fa_last_error()
     plan = native.FaPlan()
-    assert lib.fa_plan(1, 6, 2, 2, 4, 1, ctypes.byref(plan)) == -4   # L % nq  (FA.cpp:190)
-    assert lib.fa_plan(1, 6, 2, 2, 1, 4, ctypes.byref(plan)) == -5   # L % nk  (FA.cpp:191)
-    assert lib.fa_plan(0, 6, 2, 2, 1, 1, ctypes.byref(plan)) == -2
-    assert lib.fa_plan(1, 6, 2, 7, 1, 1, ctypes.byref(plan)) == -3
+    assert lib.fa_plan(1, 6, 2, 2, 4, 1, 1.0, 1, ctypes.byref(plan)) == -4   # L % nq  (FA.cpp:190)
+    assert lib.fa_plan(1, 6, 2, 2, 1, 4, 1.0, 1, ctypes.byref(plan)) == -5   # L % nk  (FA.cpp:191)
+    assert lib.fa_plan(0, 6, 2, 2, 1, 1, 1.0, 1, ctypes.byref(plan)) == -2
+    assert lib.fa_plan(1, 6, 2, 7, 1, 1, 1.0, 1, ctypes.byref(plan)) == -3
+    # a softmax scale the kernels cannot serve (exp2 of scale*log2e*s against a fixed reference max) is refused
+    for bad_scale in (0.0, -0.125, float("inf"), float("nan")):
+        assert lib.fa_plan(1, 6, 2, 2, 1, 1, bad_scale, 1, ctypes.byref(plan)) == -11
+    assert lib.fa_plan(1, 6, 2, 2, 1, 1, 1.0, 2, ctypes.byref(plan)) == -7   # causal must be 0 or 1
     assert lib.fa_fwd_qkv_packed(None, None, None, 1, 8, 64, 1, 1, 1, None) == -1
     assert lib.fa_error_string(-4).decode().endswith("num_chunks_q")
+
+
+def test_debug_options_are_explicit_and_not_read_from_the_environment_per_call(native, monkeypatch):
+    """The tile-plan knobs are process options set through fa_debug_set_option (tests, tuning); the FA_AMD_*
+    environment variables are parsed once at first use and never per launch."""
+    lib = native.load_native_library()
+    auto = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)
+    assert (auto.kernel, auto.qb, auto.source) in ((2, 2, 0), (2, 2, 1))
+    monkeypatch.setenv("FA_AMD_KERNEL", "dma")           # too late: the environment was read at first use
+    monkeypatch.setenv("FA_AMD_QB", "1")
+    p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)
+    assert (p.kernel, p.qb) == (auto.kernel, auto.qb)
+    with native.debug_options(kernel="dma", qb=2):
+        p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)
+        assert (p.kernel, p.block_q, p.qb, p.source) == (0, 256, 2, 2)
+    with native.debug_options(waves=8):
+        assert native.plan(8, 1024, 128, torch.bfloat16, 1, 1).waves == 8
+    with native.debug_options(sched=3):
+        assert native.plan(128, 4096, 64, torch.bfloat16, 8, 8).sched == 3
+    p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)  # restored
+    assert (p.kernel, p.qb, p.sched) == (auto.kernel, auto.qb, auto.sched)
+    val = ctypes.c_int32(123)
+    assert lib.fa_debug_get_option(b"kernel", ctypes.byref(val)) == 0 and val.value == 0
+    assert lib.fa_debug_set_option(b"no_such_knob", 1) == -12
+    assert lib.fa_debug_set_option(b"waves", 3) == -12
+    assert lib.fa_debug_set_option(b"kernel", ord("x")) == -12
 
 
 def test_plan_maps_chunks_to_hardware_tiles(native):
@@ -89,6 +119,20 @@ def test_plan_maps_chunks_to_hardware_tiles(native):
     p = native.plan(16, 2048, 128, torch.bfloat16, 8, 8)
     assert (p.kernel, p.block_q, p.waves) == (0, 128, 4)
     assert native.plan(4, 4096, 64, torch.float16, 64, 64).block_q == 64     # 64-row chunks honoured
+    # num_chunks_kv bounds the kv step: a chunk below 64 keys is served by 32-key steps where the pipelined kernel
+    # applies (skip-max arithmetic, causal); 64-key tiles otherwise (the result never depends on the chunking)
+    p = native.plan(128, 4096, 64, torch.bfloat16, 8, 128)
+    assert (p.chunk_kv, p.kernel, p.block_kv) == (32, 2, 32)
+    p = native.plan(8, 2048, 64, torch.bfloat16, 8, 64)
+    assert (p.chunk_kv, p.kernel, p.block_kv, p.block_q) == (32, 2, 32, 128)
+    p = native.plan(8, 2048, 64, torch.bfloat16, 8, 32)
+    assert (p.chunk_kv, p.block_kv) == (64, 64)
+    p = native.plan(8, 2048, 64, torch.float16, 8, 64)         # unscaled f16 keeps the per-tile max: 64-key tiles
+    assert (p.chunk_kv, p.block_kv, p.skipmax) == (32, 64, 0)
+    assert native.plan(8, 2048, 64, torch.float16, 8, 64, softmax_scale=0.125).block_kv == 32
+    # the non-causal forward (a widening) runs the 64-key-tile kernel
+    p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8, causal=False)
+    assert (p.kernel, p.block_q, p.block_kv) == (0, 128, 64)
     assert native.plan(4, 4096, 64, torch.float16, 128, 64).block_q == 32    # 32-row chunks honoured
     assert native.plan(5, 200, 64, torch.bfloat16, 1, 1).grid == 8 * 2       # G padded to the 8 XCDs
     assert native.plan(4, 6, 2, torch.float32, 3, 3).kernel == 1             # generic kernel
@@ -148,7 +192,7 @@ def test_sdpa_override_guards_and_passthrough(meta):
     x = torch.zeros(1, 8, 4)
     msgs = meta["errors"]["NotImplementedError"]
     calls = [dict(attn_mask=torch.ones(1, dtype=torch.bool), is_causal=True), dict(dropout_p=0.1, is_causal=True),
-             dict(is_causal=False)]
+             dict(is_causal=False)]   # (off the GPU is_causal=False raises like the reference; on it, it is served)
     for kw, msg in zip(calls, msgs[:3]):
         with pytest.raises(NotImplementedError) as e:
             patched(x, x, x, **kw)
@@ -189,6 +233,8 @@ def test_custom_ops_shape_inference_on_meta_tensors():
     assert o.shape == (2, 4, 16, 8) and o.transpose(1, 2).is_contiguous()
     c = torch.empty(2, 4, 16, 8, device="meta", dtype=torch.float16)
     assert ops.fwd_bhld(c, c, c, 0.35, 1, 1).is_contiguous()
+    g2 = torch.empty(2, 2, 16, 8, device="meta", dtype=torch.float16)            # grouped-query K/V: 2 of 4 heads
+    assert ops.fwd_bhld(c, g2, g2, 0.35, 1, 1, False).shape == (2, 4, 16, 8)
     dq, dk, dv = torch.ops.flash_attention_amd.bwd(c[0], c[0], c[0], c[0], c[0], torch.empty(4, 16, device="meta"), 1.0)
     assert dq.shape == dk.shape == dv.shape == (4, 16, 8)
 

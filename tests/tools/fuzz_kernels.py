@@ -1,6 +1,7 @@
-"""Developer aid (test infrastructure): differential fuzz of the forward kernels.  Random shapes, dtypes, scales and
-layouts; every MFMA kernel variant (dma / pipe x 1 / 2 query blocks per wave, 1..8 waves) against the register-staged
-baseline kernel and, for short sequences, against the fp64 oracle.
+"""Developer aid (test infrastructure): differential fuzz of the forward kernels.  Random shapes, dtypes, scales,
+layouts, mask modes (causal / none) and key-value head counts (grouped-query); every MFMA kernel variant (dma / pipe
+x 1 / 2 query blocks per wave, 1..8 waves) against the register-staged baseline kernel and, for short sequences,
+against the fp64 oracle.  Variants are forced through fa_debug_set_option (_native.debug_options).
 
     python tests/tools/fuzz_kernels.py [cases] [seed]
 """
@@ -9,24 +10,21 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd")]
 import torch
 from flash_attention_amd._impl import _native
-from oracle import dense_causal_attention_lse
+from oracle import dense_attention_lse
 
 lib = _native.load_native_library()
-KNOBS = ("FA_AMD_KERNEL", "FA_AMD_QB", "FA_AMD_WAVES", "FA_AMD_SCHED")
 
 
-def run(q, k, v, heads, scale, env):
-    for kk in KNOBS:
-        os.environ.pop(kk, None)
-    os.environ.update(env)
+def run(q, k, v, heads, scale, knobs, causal=True):
     B, H, L, D = q.shape
     out = torch.empty(B, H, L, D, device="cuda", dtype=q.dtype)
     lse = torch.empty(B * H, L, device="cuda", dtype=torch.float32)
     def st(t):
         return (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
-    rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B * H, L, D, H,
-                    st(q), st(k), st(v), st(out), 1, 1, _native.FA_DTYPE[q.dtype], ctypes.c_float(scale), 1,
-                    torch.cuda.current_stream().cuda_stream)
+    with _native.debug_options(**knobs):
+        rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B * H, L, D, H, k.shape[1],
+                        st(q), st(k), st(v), st(out), 1, 1, _native.FA_DTYPE[q.dtype], ctypes.c_float(scale), int(causal),
+                        torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.fa_last_error().decode()
     torch.cuda.synchronize()
     return out, lse
@@ -42,25 +40,27 @@ def fuzz(cases, seed, log=print):
       dt = rng.choice([torch.bfloat16, torch.float16])
       scale = rng.choice([1.0, D ** -0.5])
       amp = rng.choice([0.3, 1.0]) * float(os.environ.get("FUZZ_AMP", "1"))   # FUZZ_AMP=5: logits far past the skip-max range
+      causal = rng.random() < 0.7
+      Hkv = rng.choice([h for h in range(1, H + 1) if H % h == 0]) if rng.random() < 0.3 else H
       torch.manual_seed(case)
-      if rng.random() < 0.5:      # head-inner projection layout [B, L, 3, H, D] -> strided views
+      if rng.random() < 0.5 and Hkv == H:      # head-inner projection layout [B, L, 3, H, D] -> strided views
           x = (torch.randn(B, L, 3, H, D, device="cuda") * amp).to(dt)
           q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
       else:
-          q, k, v = ((torch.randn(B, H, L, D, device="cuda") * amp).to(dt) for _ in range(3))
-      base, base_lse = run(q, k, v, H, scale, {"FA_AMD_KERNEL": "tile"})
+          q = (torch.randn(B, H, L, D, device="cuda") * amp).to(dt)
+          k, v = ((torch.randn(B, Hkv, L, D, device="cuda") * amp).to(dt) for _ in range(2))
+      base, base_lse = run(q, k, v, H, scale, {"kernel": "tile"}, causal)
       variants = [{}]
       for kern in ("dma", "pipe"):
           for qb in (1, 2):
-              variants.append({"FA_AMD_KERNEL": kern, "FA_AMD_QB": str(qb), "FA_AMD_WAVES": str(rng.choice([1, 2, 4, 4, 8])),
-                               "FA_AMD_SCHED": str(rng.choice([1, 2, 8]))})
+              variants.append({"kernel": kern, "qb": qb, "waves": rng.choice([1, 2, 4, 4, 8]), "sched": rng.choice([1, 2, 8])})
       ulp = 2.0 ** -6 if dt == torch.bfloat16 else 2.0 ** -9
       ref = None
       if L <= 700:
-          qkv = torch.stack([t.reshape(B * H, L, D) for t in (q, k, v)]).cpu()
-          ref, ref_lse = dense_causal_attention_lse(qkv, scale=scale, compute_dtype=torch.float64)
+          ref, ref_lse = dense_attention_lse(q.cpu(), k.cpu(), v.cpu(), scale=scale, causal=causal)
+          ref = ref.reshape(B * H, L, D)
       for env in variants:
-          out, lse = run(q, k, v, H, scale, env)
+          out, lse = run(q, k, v, H, scale, env, causal)
           d = (out.float() - base.float()).abs()
           # output error scales with |V| (P carries 8 / 11 bits); with FUZZ_AMP > 1 the softmax is nearly one-hot and
           # 16-bit P underflow shows as a few more ulps in every kernel: twice the slack there
@@ -72,7 +72,7 @@ def fuzz(cases, seed, log=print):
               ok = ok and bool((e <= max(1.0, amp) * 1e-2 + 1e-2 * ref.abs()).all())
           if not ok:
               bad += 1
-              log(f"MISMATCH case {case}: B={B} H={H} L={L} D={D} {dt} scale={scale:.3g} env={env} max|d|={d.max().item():.3e}")
+              log(f"MISMATCH case {case}: B={B} H={H} Hkv={Hkv} L={L} D={D} {dt} scale={scale:.3g} causal={causal} knobs={env} max|d|={d.max().item():.3e}")
       if case % 20 == 0:
           log(f"case {case}: B={B} H={H} L={L} D={D} {dt} ok so far, bad={bad}")
   # fp32 inputs: the fp32 MFMA kernel against the generic kernel (FA_AMD_F32=generic) and the oracle
@@ -87,20 +87,16 @@ def fuzz(cases, seed, log=print):
           q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
       else:
           q, k, v = (torch.randn(B, H, L, D, device="cuda") for _ in range(3))
-      os.environ["FA_AMD_F32"] = "generic"
-      base, base_lse = run(q, k, v, H, scale, {})
-      os.environ.pop("FA_AMD_F32")
-      out, lse = run(q, k, v, H, scale, {})
+      causal = rng.random() < 0.7
+      base, base_lse = run(q, k, v, H, scale, {"f32_generic": 1}, causal)
+      out, lse = run(q, k, v, H, scale, {}, causal)
       ok = bool(torch.isfinite(out).all()) and (out - base).abs().max().item() <= 1e-4 and (lse - base_lse).abs().max().item() <= 1e-4
       if L <= 500:
-          qkv = torch.stack([t.reshape(B * H, L, D) for t in (q, k, v)]).cpu()
-          ref, _ = dense_causal_attention_lse(qkv, scale=scale, compute_dtype=torch.float64)
-          ok = ok and (out.reshape(B * H, L, D).cpu().double() - ref).abs().max().item() <= 1e-4
+          ref, _ = dense_attention_lse(q.cpu(), k.cpu(), v.cpu(), scale=scale, causal=causal)
+          ok = ok and (out.cpu().double() - ref).abs().max().item() <= 1e-4
       if not ok:
           bad += 1
           log(f"MISMATCH fp32 case {case}: B={B} H={H} L={L} D={D} scale={scale:.3g} max|d|={(out - base).abs().max().item():.3e}")
-  for kk in KNOBS:
-      os.environ.pop(kk, None)
   return bad, len(variants)
 
 
