@@ -12,6 +12,7 @@ namespace fa {
 
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x8 __attribute__((ext_vector_type(8)));
@@ -25,6 +26,10 @@ template <> struct Elt<__bf16> {
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static constexpr unsigned short one_bits = 0x3F80;   // 1.0
 };
 template <> struct Elt<_Float16> {
     using vec8 = f16x8;
@@ -32,6 +37,10 @@ template <> struct Elt<_Float16> {
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static constexpr unsigned short one_bits = 0x3C00;   // 1.0
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -104,6 +113,32 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned lds_base, unsi
 __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_offset(const void* p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
+// ---- row sums of P on the matrix pipe ---------------------------------------------------------------
+// The forward at head_dim 64 is bound by VALU issue, not by the matrix pipe (~7 vector
+// instructions per MFMA against a budget of ~5), and a quarter of those instructions are the fp32 adds of the
+// softmax denominator.  One v_mfma_f32_16x16x32 with a constant 0/1 selector as A sums the 8 packed P values a
+// lane holds as the B operand of the PV product AND the 8 of its partner in the other half-wave, for all 32 rows
+// of a query block at once (16 matrix-pipe cycles and one issue slot instead of 8 v_add_f32 = 32 issue cycles):
+//   B operand of v_mfma_f32_32x32x16 (what a lane holds): P[k = 8 (lane >> 5) + j][n = lane & 31], j = 0..7
+//   the same registers read by v_mfma_f32_16x16x32:       B'[k' = 8 (lane >> 4) + j][n' = lane & 15]
+//   so column n' collects lanes n', n'+16, n'+32, n'+48 = rows n' (both halves) and n'+16 (both halves);
+//   A[i][k'] = 1 where ((i >> 2) & 1) == ((k' >> 3) & 1) picks the even lane groups for output rows 0-3 / 8-11
+//   and the odd ones for rows 4-7 / 12-15: D[i = 4 (lane >> 4) + jj][n'] lands the FULL row sum of query row
+//   lane & 31 in every lane (all four result registers equal) - no half-wave exchange needed afterwards.
+// The sum is taken over the 16-bit-rounded P, i.e. exactly the weights the PV product uses.
+// A 0 in the selector times an overflowed P (+inf) gives NaN, so overflow checks on these sums use
+// sum_left_safe_range(): an integer compare that NaN cannot slip through (the build uses -fno-honor-nans).
+template <typename T>
+__device__ __forceinline__ typename Elt<T>::vec8 rowsum_selector(int lane) {
+    const bool one = (((lane & 15) >> 2) & 1) == ((lane >> 4) & 1);
+    const unsigned w = one ? (unsigned)Elt<T>::one_bits * 0x10001u : 0u;
+    const u32x4 v = {w, w, w, w};
+    return __builtin_bit_cast(typename Elt<T>::vec8, v);
+}
+__device__ __forceinline__ bool sum_left_safe_range(float x) {   // |x| > 2^100, +-inf or NaN
+    return (__builtin_bit_cast(unsigned, x) & 0x7fffffffu) > 0x71800000u;
 }
 
 // Lazy rescale threshold in log2 units: the running max m is only raised (and O, l rescaled) when a

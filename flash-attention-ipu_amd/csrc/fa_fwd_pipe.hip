@@ -46,6 +46,10 @@
 #ifndef FA_PIPE_ABL
 #define FA_PIPE_ABL 0
 #endif
+// 1: the row sums of P in the hand-scheduled steps run on the matrix pipe (fa_device.h, rowsum_selector)
+#ifndef FA_PIPE_MFMASUM
+#define FA_PIPE_MFMASUM 1
+#endif
 #if FA_PIPE_ABL == 1
 #define FA_PIPE_BARRIER() asm volatile("" ::: "memory")
 #else
@@ -171,10 +175,16 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 
     f32x16 o[QB][DT];
     float m[QB], l[QB];
+    // row sums of the hand-scheduled steps, formed on the matrix pipe: full-row sums, identical in the 4 registers
+    // (l[] keeps the per-lane partial sums of the compiler-scheduled steps; the epilogue adds the two)
+    f32x4 lsum[QB];
+    const vec8 asel = rowsum_selector<T>(lane);
+    (void)asel;
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         m[b] = -INFINITY;
         l[b] = 0.f;
+        lsum[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -311,10 +321,14 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         {                                                                                          \
             constexpr int b_ = (V_) / 8, p_ = (V_) % 8, e_ = 2 * p_;                               \
             if constexpr (!FA_ITEM_DEAD(MASK_, b_)) {                                              \
-                ls[b_] += SC_[b_][e_];                                                             \
-                ls[b_] += SC_[b_][e_ + 1];                                                         \
+                if constexpr (!FA_PIPE_MFMASUM) {                                                  \
+                    ls[b_] += SC_[b_][e_];                                                         \
+                    ls[b_] += SC_[b_][e_ + 1];                                                     \
+                }                                                                                  \
                 PC_[b_][p_ >> 2][2 * (p_ & 3)] = (T)SC_[b_][e_];                                   \
                 PC_[b_][p_ >> 2][2 * (p_ & 3) + 1] = (T)SC_[b_][e_ + 1];                           \
+                if constexpr (FA_PIPE_MFMASUM && (p_ & 3) == 3)   /* a B fragment of P is complete */ \
+                    lsum[b_] = E::mfma16(asel, PC_[b_][p_ >> 2], lsum[b_]);                        \
             } else {                                                                               \
                 PC_[b_][p_ >> 2][2 * (p_ & 3)] = (T)0.f;                                           \
                 PC_[b_][p_ >> 2][2 * (p_ & 3) + 1] = (T)0.f;                                       \
@@ -365,8 +379,10 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             __builtin_amdgcn_sched_barrier(0);                                                     \
         });                                                                                        \
         _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                           \
-            bad |= !(ls[b] <= P_LIMIT);                                                            \
-            l[b] += ls[b];                                                                         \
+            if constexpr (!FA_PIPE_MFMASUM) {                                                      \
+                bad |= !(ls[b] <= P_LIMIT);                                                        \
+                l[b] += ls[b];                                                                     \
+            }                                                                                      \
             /* pin this step's vector work to this step (hipcc otherwise sinks it below the       \
                barrier, in front of the PV that needs it) */                                      \
             asm volatile("" : "+v"(PC_[b][0]), "+v"(PC_[b][1]), "+v"(l[b]));                       \
@@ -478,6 +494,9 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 
     bool bad = false;
     FA_RUN(false)
+    // (sums of non-negative P only grow, and an overflowed P makes them inf or NaN for good: one check per pass)
+#pragma unroll
+    for (int b = 0; b < QB; ++b) bad |= sum_left_safe_range(lsum[b][0]);
     // Did any row of the workgroup leave the safe range?  (All waves must agree: the fallback pass re-streams
     // K/V through the same barriers.)  Practically never taken: logits must outgrow the first step's row max
     // by 2^60 (bf16) / 2^15 (f16, 1/sqrt(D)-scaled logits only).
@@ -492,6 +511,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         for (int b = 0; b < QB; ++b) {
             m[b] = -INFINITY;
             l[b] = 0.f;
+            lsum[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -530,7 +550,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        const float lt = half_swap_sum(l[b]);
+        const float lt = half_swap_sum(l[b]) + lsum[b][0];
         const float inv = __builtin_amdgcn_rcpf(lt);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {

