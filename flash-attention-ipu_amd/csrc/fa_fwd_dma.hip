@@ -49,6 +49,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KTILE_B + 2 * VTILE_B];  // K0 K1 V0 V1
     unsigned char* const smem_v = smem + 2 * KTILE_B;
+    __shared__ int flags[NWAVES];
 
     const int b = blockIdx.x;
     const int nq = p.nq_tiles;
@@ -147,24 +148,33 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const int wave_kv_last = causal ? q_row0 + WQ - 1 : L - 1;   // tiles starting after it hold nothing for the wave
 
     f32x16 o[QB][DT];
-    float m[QB], l[QB];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        m[b] = -INFINITY;
-        l[b] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[b][dt][e] = 0.f;
+    float m[QB];
+    // Softmax denominators are formed on the matrix pipe (fa_device.h, rowsum_selector): lsum[b] holds the FULL row
+    // sum of query block b's rows (both half-waves), identical in its four registers.
+    f32x4 lsum[QB];
+    const vec8 asel = rowsum_selector<T>(lane);
+#define FA_RESET_STATE()                                                                           \
+    _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
+        m[b] = -INFINITY;                                                                          \
+        lsum[b] = f32x4{0.f, 0.f, 0.f, 0.f};                                                       \
+        _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                          \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) o[b][dt][e] = 0.f;                      \
     }
+    FA_RESET_STATE()
     const float c = p.scale_log2;
-    // bf16 P keeps the fp32 exponent range, so the reference max may lag by 2^60 before a tile has to be
-    // redone.  f16 P must stay below 65504 (limit 2^15): on unscaled logits (std sqrt(D)) the redo fires
-    // every few tiles (measured -4 %), on 1/sqrt(D)-scaled logits it practically never does (+7 %).
-    // bf16 always takes the skip-max path; f16 has both instantiations and the host picks one from the
-    // softmax scale (fa_capi.cpp)
+    // Two arithmetic modes per kv tile:
+    //   fast (MODE_ 0, "skip-max"): the reference max m is set exactly on the wave's first tile and then left alone -
+    //     any reference value cancels in O/l, it only has to keep P finite.  bf16 P keeps the fp32 exponent range, so
+    //     the max may lag by ~2^100 before anything overflows; f16 P must stay below 65504, which 1/sqrt(D)-scaled
+    //     logits practically always satisfy (the host picks this mode for f16 from the softmax scale, fa_capi.cpp).
+    //     Nothing is checked per tile: an overflowed P turns the row sum into inf/NaN for good, the pass is
+    //     OPTIMISTIC, and if any wave of the workgroup finds such a sum at its end, the workgroup re-streams K/V
+    //     through an exact pass.  Worth +7 % at D=64 when it replaced the per-tile max (the 16-deep v_max3 chain, the
+    //     half-wave swap and the rescale decision leave every tile) and +2..4 % more when the row sums moved to the
+    //     matrix pipe (32 v_add_f32 per tile and block replaced by 4 small MFMAs; no per-tile overflow test).
+    //   exact (MODE_ 1): per-tile row max with lazy rescale (O, l rescaled only when a row max outgrows m by more
+    //     than 2^RESCALE_THR) - unscaled f16, and the fallback pass of the fast mode.
     constexpr bool SKIPMAX = FA_DMA_SKIPMAX && SKIP;
-    constexpr float P_LIMIT = E::is_f16 ? 32768.0f : 1152921504606846976.0f;   // 2^15 | 2^60
 
     // ---- the pieces of one kv tile (buffer index BUF_ is compile-time); same arithmetic as fa_fwd_tile_kernel
 #define FA_QK(BUF_)                                                                                \
@@ -202,23 +212,21 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             const float m_new = max2(m[b], mx);                                                    \
             const float alpha = fast_exp2((m[b] - m_new) * c);                                     \
             m[b] = m_new;                                                                          \
-            l[b] *= alpha;                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) lsum[b][j] *= alpha;                     \
             _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                      \
                 _Pragma("unroll") for (int e = 0; e < 16; ++e) o[b][dt][e] *= alpha;               \
         }                                                                                          \
     }
-    // P = 2^(s*c - m*c) in place, ls = this lane's part of the row sum
+    // P = 2^(s*c - m*c) in place
 #define FA_SOFTMAX()                                                                               \
     _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
         const float mc = m[b] * c;                                                                 \
-        ls[b] = 0.f;                                                                               \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                           \
             s0[b][e] = fast_exp2(__builtin_fmaf(s0[b][e], c, -mc));                                \
             s1[b][e] = fast_exp2(__builtin_fmaf(s1[b][e], c, -mc));                                \
-            ls[b] += s0[b][e];                                                                     \
-            ls[b] += s1[b][e];                                                                     \
         }                                                                                          \
     }
+    // pack P to 16 bits, row sums += selector x P (matrix pipe), O^T += V^T P^T
 #define FA_PV(BUF_)                                                                                \
     {                                                                                              \
         const unsigned char* vb_ = smem_v + (BUF_) * VTILE_B;                                      \
@@ -231,6 +239,8 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                 pf[b][3][j] = (T)s1[b][8 + j];                                                     \
             }                                                                                      \
         }                                                                                          \
+        _Pragma("unroll") for (int b = 0; b < QB; ++b)                                             \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) lsum[b] = E::mfma16(asel, pf[b][kk], lsum[b]); \
         _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                        \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                     \
                 const unsigned char* vp = vb_ + dt * VBLK_B + kk * 1024 + v_rd;                    \
@@ -244,56 +254,69 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             }                                                                                      \
         }                                                                                          \
     }
-#define FA_COMPUTE(T_, BUF_)                                                                       \
+#define FA_COMPUTE(T_, BUF_, MODE_)                                                                \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
         if (wave_active && kv0 <= wave_kv_last) {                                                  \
             f32x16 s0[QB], s1[QB];                                                                 \
-            float ls[QB];                                                                          \
             FA_QK(BUF_)                                                                            \
-            if (SKIPMAX) {                                                                         \
+            if ((MODE_) == 0) {                                                                    \
                 if (kv0 == 0) FA_MAX_RESCALE(0.0f)       /* first tile: m = -inf -> exact max */    \
-                FA_SOFTMAX()                                                                       \
-                /* (the fences keep hipcc from hoisting the PV operand reads above the rare branch, \
-                   which costs 26 VGPRs and a wave per SIMD) */                                    \
-                asm volatile("" ::: "memory");                                                     \
-                bool over_ = ls[0] > P_LIMIT;                                                      \
-                _Pragma("unroll") for (int b = 1; b < QB; ++b) over_ |= ls[b] > P_LIMIT;           \
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(over_) != 0, 0)) {                \
-                    FA_QK(BUF_)                                                                    \
-                    FA_MAX_RESCALE(0.0f)                                                           \
-                    FA_SOFTMAX()                                                                   \
-                }                                                                                  \
-                asm volatile("" ::: "memory");                                                     \
             } else {                                                                               \
                 FA_MAX_RESCALE(RESCALE_THR)                                                        \
-                FA_SOFTMAX()                                                                       \
             }                                                                                      \
-            _Pragma("unroll") for (int b = 0; b < QB; ++b) l[b] += ls[b];                          \
+            FA_SOFTMAX()                                                                           \
             FA_PV(BUF_)                                                                            \
         }                                                                                          \
     }
+    // one pass over the workgroup's kv tiles (the kv loop is unrolled by two: LDS addresses are base + immediate)
+#define FA_PASS(MODE_)                                                                             \
+    {                                                                                              \
+        FA_DMA_TILE(0, 0)                                                                          \
+        FA_TILE_BARRIER()                                                                          \
+        for (int t = 0; t < n_tiles; t += 2) {                                                     \
+            if (t + 1 < n_tiles) FA_DMA_TILE(t + 1, 1)                                             \
+            FA_COMPUTE(t, 0, MODE_)                                                                \
+            FA_TILE_BARRIER()                                                                      \
+            if (t + 1 < n_tiles) {                                                                 \
+                if (t + 2 < n_tiles) FA_DMA_TILE(t + 2, 0)                                         \
+                FA_COMPUTE(t + 1, 1, MODE_)                                                        \
+                FA_TILE_BARRIER()                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
 
-    FA_DMA_TILE(0, 0)
-    FA_TILE_BARRIER()
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int b = 0; b < QB; ++b) asm volatile("" : "+v"(qf[b][ks]));   // Q landed (see fa_fwd_tile_kernel)
+        for (int b = 0; b < QB; ++b) asm volatile("" : "+v"(qf[b][ks]));   // Q loads issued (see fa_fwd_tile_kernel)
 
-    for (int t = 0; t < n_tiles; t += 2) {
-        if (t + 1 < n_tiles) FA_DMA_TILE(t + 1, 1)
-        FA_COMPUTE(t, 0)
-        FA_TILE_BARRIER()
-        if (t + 1 < n_tiles) {
-            if (t + 2 < n_tiles) FA_DMA_TILE(t + 2, 0)
-            FA_COMPUTE(t + 1, 1)
-            FA_TILE_BARRIER()
+    if constexpr (SKIPMAX) {
+        FA_PASS(0)
+        // Did any row of the workgroup leave the safe range?  (All waves must agree: the exact pass re-streams K/V
+        // through the same barriers.)  Practically never taken: logits must outgrow the first tile's row max by
+        // ~2^100 (bf16) / 2^16 (f16, 1/sqrt(D)-scaled logits only).
+        bool bad = false;
+#pragma unroll
+        for (int b = 0; b < QB; ++b) bad |= wave_active && sum_left_safe_range(lsum[b][0]);
+        flags[wave] = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
+        __syncthreads();
+        int any_bad = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) any_bad |= flags[w];
+        if (any_bad) {
+            __syncthreads();   // (flags are rewritten only by a later launch; this orders the LDS buffer reuse)
+            FA_RESET_STATE()
+            FA_PASS(1)
         }
+    } else {
+        FA_PASS(1)
     }
 #undef FA_DMA_TILE
 #undef FA_TILE_BARRIER
 #undef FA_COMPUTE
+#undef FA_PASS
+#undef FA_RESET_STATE
 #undef FA_QK
 #undef FA_MAX_RESCALE
 #undef FA_SOFTMAX
@@ -311,7 +334,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        const float lt = half_swap_sum(l[b]);
+        const float lt = lsum[b][0];
         const float inv = __builtin_amdgcn_rcpf(lt);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
