@@ -145,3 +145,24 @@ def test_tiny_gpt_trains_through_the_override():
         F.scaled_dot_product_attention = wrapped
     assert abs(ours[0] - stock[0]) < 5e-2, (ours[0], stock[0])       # same init, same data, same first loss
     assert stock[-1] < 0.6 * stock[0] and abs(ours[-1] - stock[-1]) < 0.35 * stock[0], (ours[-1], stock[-1])
+
+
+@pytest.mark.parametrize("block,batch,steps", [(256, 32, 40), (1024, 8, 16)])
+def test_char_level_training_curves_with_and_without_the_override(block, batch, steps):
+    """demo/train_char_gpt.py at reduced steps (the reference's table: nb:826-878 block 256 with/without flash
+    attention, nb:736 block 1024): same seed, same batches -> the loss curve through the HIP forward + backward must
+    track the stock-SDPA curve, both must fall, and the override must not need more memory than the dense path."""
+    from train_char_gpt import train
+
+    ours = train("override", block, batch, steps)
+    stock = train("stock", block, batch, steps)
+    dense = train("math", block, batch, steps)
+    lo, ls, ld = ours["losses"], stock["losses"], dense["losses"]
+    assert all(x == x for x in lo), "NaN loss"
+    assert abs(lo[0] - ls[0]) < 2e-2 and abs(lo[0] - ld[0]) < 2e-2, (lo[0], ls[0], ld[0])      # same init, same first batch
+    assert lo[-1] < 0.75 * lo[0] and ls[-1] < 0.75 * ls[0], (lo[0], lo[-1], ls[-1])           # both learn
+    tail = max(1, steps // 4)
+    mo, ms = sum(lo[-tail:]) / tail, sum(ls[-tail:]) / tail
+    assert abs(mo - ms) < 0.08 * ms, (mo, ms)                                                 # and stay together
+    assert ours["peak_mib"] <= 1.05 * dense["peak_mib"], (ours["peak_mib"], dense["peak_mib"])
+    assert ours["it_per_s"] > 0 and stock["it_per_s"] > 0
