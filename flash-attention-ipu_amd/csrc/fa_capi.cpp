@@ -313,15 +313,20 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     if (heads_kv < 1 || heads % heads_kv != 0) return fail(FA_ERR_BAD_SHAPE, "heads=%lld must be a positive multiple of heads_kv=%lld", (long long)heads, (long long)heads_kv);
     const void* const ptrs[4] = {q, k, v, out};
     const int64_t* const strides[4] = {q_strides, k_strides, v_strides, o_strides};
+    bool wide_rows = false;
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 3; ++j)
-            if (strides[i][j] < 0) return fail(FA_ERR_BAD_STRIDE, "negative strides are not supported");
+            if (strides[i][j] < 0 || strides[i][j] > (1ll << 40)) return fail(FA_ERR_BAD_STRIDE, "strides must be in [0, 2^40] elements");
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     for (int i = 0; i < 4; ++i)
         if (reinterpret_cast<uintptr_t>(ptrs[i]) % elt_size(dtype)) return fail(FA_ERR_MISALIGNED, "pointer %d is not element aligned", i);
+    // (sizes are bounded before anything is multiplied: the products below must not overflow)
+    if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1 (got %lld, %lld, %lld)", (long long)G, (long long)L, (long long)D);
+    if (L > (1ll << 30) || G > (1ll << 30) || D > (1ll << 20)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30, D < 2^20");
+    if (k_strides[2] > (1ll << 32) || v_strides[2] > (1ll << 32)) wide_rows = true;
 
     // the MFMA kernels need 16-byte rows and address K/V rows with 32-bit element offsets from the group base
-    bool wide_ok = aligned16(D, elt_size(dtype), ptrs, strides) && L * k_strides[2] < (1ll << 31) && L * v_strides[2] < (1ll << 31);
+    const bool wide_ok = !wide_rows && aligned16(D, elt_size(dtype), ptrs, strides) && L * k_strides[2] < (1ll << 31) && L * v_strides[2] < (1ll << 31);
     const bool mfma16_ok = wide_ok && (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16);
     const bool f32_ok = wide_ok && dtype == FA_DTYPE_F32 && !options().f32_generic;
     Selection sel;
@@ -376,10 +381,10 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
         if (reinterpret_cast<uintptr_t>(ptrs[i]) % elt_size(dtype)) return fail(FA_ERR_MISALIGNED, "fa_bwd: tensor %d is not element aligned", i);
         if (reinterpret_cast<uintptr_t>(ptrs[i]) & 15) mfma = false;
         for (int j = 0; j < 3; ++j) {
-            if (strides[i][j] < 0) return fail(FA_ERR_BAD_STRIDE, "negative strides are not supported");
+            if (strides[i][j] < 0 || strides[i][j] > (1ll << 40)) return fail(FA_ERR_BAD_STRIDE, "strides must be in [0, 2^40] elements");
             if (strides[i][j] % 8) mfma = false;
         }
-        if (L * strides[i][2] >= (1ll << 31)) mfma = false;
+        if (strides[i][2] > (1ll << 32) || L * strides[i][2] >= (1ll << 31)) mfma = false;
     }
     if (!mfma && D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic backward supports D <= 1024 (got %lld)", (long long)D);
     if (!mfma && G * L > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");

@@ -1,0 +1,122 @@
+// Host-only test of the C ABI's argument validation and plan selection, built with
+// -fsanitize=address,undefined against tests/cpp/hip_stubs.cpp (no GPU, no HIP runtime).  The reference's
+// counterparts are C++ asserts (flash_attention_qkv_packed.cpp:183, :190-191, :573-574); here every bad argument
+// must come back as an error code with a message, never as a crash, an out-of-bounds read or signed overflow.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#include "flash_attention_amd.h"
+
+extern int g_stub_launches;
+extern char g_stub_last;
+
+static int fails = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAILED %s:%d: %s   (last error: %s)\n", __FILE__, __LINE__, #cond, fa_last_error()); ++fails; } } while (0)
+
+int main() {
+    EXPECT(fa_abi_version() == FA_ABI_VERSION);
+    // ---- shape inference
+    int64_t shp[4] = {3, 8, 128, 64}, out[3] = {0, 0, 0};
+    EXPECT(fa_infer_output_shape(shp, 4, out) == FA_OK && out[0] == 8 && out[1] == 128 && out[2] == 64);
+    EXPECT(fa_infer_output_shape(shp, 3, out) == FA_ERR_BAD_SHAPE);
+    EXPECT(fa_infer_output_shape(nullptr, 4, out) == FA_ERR_NULL_POINTER);
+    // ---- plan: every error code, extreme sizes (no overflow: UBSan watches)
+    fa_plan_t plan;
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, 4, 1, 1.0f, 1, &plan) == FA_ERR_CHUNKS_Q);
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, 1, 4, 1.0f, 1, &plan) == FA_ERR_CHUNKS_KV);
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, 0, 1, 1.0f, 1, &plan) == FA_ERR_CHUNKS_Q);
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, -3, 1, 1.0f, 1, &plan) == FA_ERR_CHUNKS_Q);
+    EXPECT(fa_plan(0, 6, 2, FA_DTYPE_F32, 1, 1, 1.0f, 1, &plan) == FA_ERR_BAD_SHAPE);
+    EXPECT(fa_plan(1, 6, 2, 7, 1, 1, 1.0f, 1, &plan) == FA_ERR_BAD_DTYPE);
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, 1, 1, 0.0f, 1, &plan) == FA_ERR_BAD_SCALE);
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, 1, 1, -1.0f, 1, &plan) == FA_ERR_BAD_SCALE);
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, 1, 1, std::numeric_limits<float>::infinity(), 1, &plan) == FA_ERR_BAD_SCALE);
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, 1, 1, std::nanf(""), 1, &plan) == FA_ERR_BAD_SCALE);
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, 1, 1, 1.0f, 5, &plan) == FA_ERR_NOT_CAUSAL);
+    EXPECT(fa_plan(1, 6, 2, FA_DTYPE_F32, 1, 1, 1.0f, 1, nullptr) == FA_ERR_NULL_POINTER);
+    EXPECT(fa_plan((1ll << 30) + 1, 64, 64, FA_DTYPE_BF16, 1, 1, 1.0f, 1, &plan) == FA_ERR_TOO_LARGE);
+    EXPECT(fa_plan(8, (1ll << 30) + 8, 64, FA_DTYPE_BF16, 1, 1, 1.0f, 1, &plan) == FA_ERR_TOO_LARGE);
+    EXPECT(fa_plan(1ll << 30, 1ll << 30, 64, FA_DTYPE_BF16, 1, 1, 1.0f, 1, &plan) == FA_ERR_TOO_LARGE);   // grid > 2^31-1
+    EXPECT(fa_plan(1ll << 62, 1ll << 62, 1ll << 62, FA_DTYPE_F32, 1, 1, 1.0f, 1, &plan) == FA_ERR_TOO_LARGE);
+    EXPECT(fa_plan(4, 256, 2048, FA_DTYPE_BF16, 1, 1, 1.0f, 1, &plan) == FA_ERR_BAD_SHAPE);              // generic kernel: D <= 1024
+    EXPECT(fa_plan(128, 4096, 64, FA_DTYPE_BF16, 8, 8, 1.0f, 1, &plan) == FA_OK && plan.block_q * plan.grid >= 128 * 4096);
+    EXPECT(fa_plan(128, 4096, 64, FA_DTYPE_BF16, 8, 8, 1.0f, 0, &plan) == FA_OK && plan.kernel == 0);   // non-causal: 64-key tiles
+    for (int32_t nq : {1, 2, 4, 8, 16, 32, 64, 128, 4096})       // every chunking of L = 4096 yields a legal tile
+        for (int32_t nk : {1, 8, 64, 128, 4096})
+            for (int dt : {FA_DTYPE_F16, FA_DTYPE_BF16, FA_DTYPE_F32})
+                for (int64_t D : {64, 128, 80}) {
+                    EXPECT(fa_plan(24, 4096, D, dt, nq, nk, 0.125f, 1, &plan) == FA_OK);
+                    EXPECT(plan.block_q >= 1 && plan.grid >= 1 && plan.waves >= 1 && plan.sched >= 1);
+                    if (plan.kernel == 0 || plan.kernel == 2) EXPECT(plan.block_q == 32 * plan.waves * plan.qb && (plan.block_q <= 4096 / nq || plan.block_q == 32));
+                }
+    // ---- debug options
+    int32_t v = -7;
+    EXPECT(fa_debug_set_option(nullptr, 1) == FA_ERR_NULL_POINTER);
+    EXPECT(fa_debug_set_option("bogus", 1) == FA_ERR_BAD_OPTION);
+    EXPECT(fa_debug_set_option("waves", 3) == FA_ERR_BAD_OPTION);
+    EXPECT(fa_debug_set_option("kernel", 'p') == FA_OK && fa_debug_get_option("kernel", &v) == FA_OK && v == 'p');
+    EXPECT(fa_plan(128, 2048, 64, FA_DTYPE_BF16, 8, 8, 1.0f, 1, &plan) == FA_OK && plan.kernel == 2 && plan.source == 2);
+    EXPECT(fa_debug_set_option("kernel", 0) == FA_OK);
+    EXPECT(fa_debug_get_option("kernel", nullptr) == FA_ERR_NULL_POINTER);
+    // ---- fa_fwd / fa_bwd argument checks (pointers are never dereferenced on the host; the launchers are stubs)
+    alignas(16) static char buf[64];
+    const int64_t st[3] = {128 * 64, 0, 64}, neg[3] = {-1, 0, 64}, odd[3] = {128 * 64, 0, 65};
+    void* p = buf;
+    EXPECT(fa_fwd(nullptr, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_NULL_POINTER);
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 128, 64, 1, 1, nullptr, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_NULL_POINTER);
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 3, 128, 64, 2, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_SHAPE);    // G % heads
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 6, 128, 64, 6, 4, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_SHAPE);    // heads % heads_kv
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 6, 128, 64, 6, 0, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_SHAPE);
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 128, 64, 1, 1, neg, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_STRIDE);
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, 9, 1.0f, 1, nullptr) == FA_ERR_BAD_DTYPE);
+    EXPECT(fa_fwd(buf + 1, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_MISALIGNED);
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 0.0f, 1, nullptr) == FA_ERR_BAD_SCALE);
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 2, nullptr) == FA_ERR_NOT_CAUSAL);
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 3, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_CHUNKS_Q);
+    const int64_t huge[3] = {1ll << 62, 0, 1ll << 62};
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1ll << 62, 1ll << 62, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_TOO_LARGE);
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 1ll << 30, 64, 1, 1, st, huge, huge, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_STRIDE);  // row offsets would overflow
+    const int launches0 = g_stub_launches;
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'd');
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 128, 64, 1, 1, odd, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'g');   // unaligned rows -> generic
+    EXPECT(fa_fwd(buf + 2, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'g');
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F32, 1.0f, 0, nullptr) == FA_OK && g_stub_last == 'f');
+    EXPECT(fa_fwd(p, p, p, p, nullptr, 1024, 4096, 64, 1, 1, st, st, st, st, 8, 8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'p');
+    EXPECT(fa_fwd_qkv_packed(nullptr, p, nullptr, 1, 8, 64, 1, 1, FA_DTYPE_BF16, nullptr) == FA_ERR_NULL_POINTER);
+    EXPECT(fa_fwd_qkv_packed(p, p, nullptr, 0, 8, 64, 1, 1, FA_DTYPE_BF16, nullptr) == FA_ERR_BAD_SHAPE);
+    EXPECT(fa_fwd_qkv_packed(p, p, nullptr, 1, 8, 64, 1, 1, 5, nullptr) == FA_ERR_BAD_DTYPE);
+    EXPECT(g_stub_launches == launches0 + 5);
+    int64_t st8[8][3];
+    for (auto& r : st8) { r[0] = 128 * 64; r[1] = 0; r[2] = 64; }
+    float fbuf[4];
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'B');
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_F32, 1.0f, 0, nullptr) == FA_OK && g_stub_last == 'b');
+    EXPECT(fa_bwd(p, p, p, p, p, nullptr, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_NULL_POINTER);
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, -2.0f, 1, nullptr) == FA_ERR_BAD_SCALE);
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, 1.0f, 3, nullptr) == FA_ERR_NOT_CAUSAL);
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 3, 128, 64, 2, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_SHAPE);
+    st8[3][1] = -5;
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_STRIDE);
+    // ---- thread-local error text; concurrent plan + option calls (ThreadSanitizer-style smoke under ASan/UBSan)
+    std::vector<std::thread> th;
+    for (int t = 0; t < 4; ++t)
+        th.emplace_back([t] {
+            fa_plan_t pl;
+            for (int i = 0; i < 2000; ++i) {
+                if (t == 0) fa_debug_set_option("sched", i % 5);
+                const int rc = fa_plan(8 + t, 1024, 64, FA_DTYPE_BF16, (i & 1) ? 3 : 1, 1, 1.0f, 1, &pl);
+                if (rc == FA_ERR_CHUNKS_Q && !std::strstr(fa_last_error(), "num_chunks_q=3")) std::abort();
+            }
+        });
+    for (auto& x : th) x.join();
+    fa_debug_set_option("sched", 0);
+    for (int code = 1; code >= -14; --code) EXPECT(fa_error_string(code) != nullptr && std::strlen(fa_error_string(code)) > 0);
+    std::printf(fails ? "FAILED (%d)\n" : "PASSED\n", fails);
+    return fails ? 1 : 0;
+}

@@ -53,6 +53,17 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
 
 
+def test_c_abi_under_address_and_ub_sanitizers(tmp_path):
+    """SURVEY 5 (sanitizers; the reference only has -Werror, Makefile:10): the C ABI's validation and plan-selection
+    code built host-only with -fsanitize=address,undefined against stub launchers, driven through every error path,
+    extreme sizes and concurrent callers (tests/cpp/test_capi_host.cpp).  CPU only - never on the GPU."""
+    exe = tmp_path / "test_capi_host_asan"
+    res = subprocess.run(["make", "-C", str(ROOT / "flash-attention-ipu_amd"), "sanitize", f"SAN_OUT={exe}"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "PASSED" in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "runtime error" not in res.stderr and "AddressSanitizer" not in res.stderr
+
+
 def test_c_abi_argument_validation(native):
     lib = native.load_native_library()
     shape = (ctypes.c_int64 * 4)(3, 8, 128, 64)
