@@ -375,14 +375,16 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     if (L > (1ll << 30) || G > (1ll << 30)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30");
     const void* const ptrs[8] = {q, k, v, out, dout, dq, dk, dv};
-    // MFMA kernels: 16-bit dtypes, head_dim 64/128, 16-byte aligned rows; everything else -> generic kernels
-    bool mfma = (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128);
+    // MFMA kernels: head_dim 64/128, 16-byte aligned rows - 16-bit dtypes (fa_bwd_kernels.hip) and fp32
+    // (fa_bwd_f32.hip, v_mfma_f32_32x32x2_f32); everything else -> generic kernels
+    bool mfma = (D == 64 || D == 128) && !(dtype == FA_DTYPE_F32 && options().f32_generic);
+    const int64_t row_align = 16 / elt_size(dtype);
     for (int i = 0; i < 8; ++i) {
         if (reinterpret_cast<uintptr_t>(ptrs[i]) % elt_size(dtype)) return fail(FA_ERR_MISALIGNED, "fa_bwd: tensor %d is not element aligned", i);
         if (reinterpret_cast<uintptr_t>(ptrs[i]) & 15) mfma = false;
         for (int j = 0; j < 3; ++j) {
             if (strides[i][j] < 0 || strides[i][j] > (1ll << 40)) return fail(FA_ERR_BAD_STRIDE, "strides must be in [0, 2^40] elements");
-            if (strides[i][j] % 8) mfma = false;
+            if (strides[i][j] % row_align) mfma = false;
         }
         if (strides[i][2] > (1ll << 32) || L * strides[i][2] >= (1ll << 31)) mfma = false;
     }
@@ -414,7 +416,9 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
     if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    hipError_t e = mfma ? fa::launch_bwd(p, dtype, (hipStream_t)stream) : fa::launch_bwd_generic(p, dtype, (hipStream_t)stream);
+    hipError_t e = !mfma                  ? fa::launch_bwd_generic(p, dtype, (hipStream_t)stream)
+                   : dtype == FA_DTYPE_F32 ? fa::launch_bwd_f32(p, (hipStream_t)stream)
+                                           : fa::launch_bwd(p, dtype, (hipStream_t)stream);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
 }

@@ -59,6 +59,7 @@ inline hipError_t launch1(const void* kernel, dim3 grid, dim3 block, size_t dyn_
 
 hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream);
 hipError_t launch_bwd_generic(const BwdParams& p, int dtype, hipStream_t stream);
+hipError_t launch_bwd_f32(const BwdParams& p, hipStream_t stream);   // fa_bwd_f32.hip: fp32, D in {64, 128}
 
 hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);

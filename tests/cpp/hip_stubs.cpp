@@ -14,6 +14,7 @@ extern "C" const char* hipGetErrorString(hipError_t) { return "stub"; }
 namespace fa {
 hipError_t launch_bwd(const BwdParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'B'; return hipSuccess; }
 hipError_t launch_bwd_generic(const BwdParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'b'; return hipSuccess; }
+hipError_t launch_bwd_f32(const BwdParams&, hipStream_t) { ++g_stub_launches; g_stub_last = 'F'; return hipSuccess; }
 hipError_t launch_fwd_tile(const FwdParams&, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 't'; return hipSuccess; }
 hipError_t launch_fwd_dma(const FwdParams&, int, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'd'; return hipSuccess; }
 hipError_t launch_fwd_generic(const FwdParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'g'; return hipSuccess; }

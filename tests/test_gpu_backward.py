@@ -122,7 +122,7 @@ def test_backward_is_deterministic_and_group_independent():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("G,L,D", [(4, 6, 2), (2, 33, 7), (2, 70, 24), (8, 256, 128), (2, 300, 80), (1, 1200, 32)])
-def test_generic_backward(dtype, G, L, D):
+def test_generic_backward(knobs, dtype, G, L, D):
     """Shapes/dtypes only the generic backward kernels serve, incl. the reference's fp32 C++ cases
     4x6x2 and 8x256x128 (t_cpp:273-287, bound 1e-4 there)."""
     import flash_attention_amd as fa
@@ -130,6 +130,7 @@ def test_generic_backward(dtype, G, L, D):
 
     if dtype != torch.float32 and D in (64, 128):
         pytest.skip("served by the MFMA kernels")
+    knobs.set("f32_generic", 1)      # fp32 at head_dim 64 / 128 has MFMA kernels of its own (test below)
     qkv = (frozen_randn(SEED + L + D, (3, G, L, D)) * (0.5 if D > 16 else 1.0)).to(dtype)
     dout = frozen_randn(SEED + 2, (G, L, D)).to(dtype)
     ref_out, ref_grad = _oracle_grads(qkv, dout, 1.0)
@@ -141,3 +142,37 @@ def test_generic_backward(dtype, G, L, D):
     else:
         for i, name in enumerate("qkv"):
             _close(x.grad[i], ref_grad[i], f"generic d{name} {dtype} {G}x{L}x{D}")
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("G,L,D", [(8, 256, 128), (3, 200, 64), (2, 33, 64), (1, 1000, 128), (2, 2048, 64)])
+def test_fp32_mfma_backward(knobs, G, L, D, causal):
+    """fp32 gradients at head_dim 64 / 128: the v_mfma_f32_32x32x2_f32 kernels (fa_bwd_f32.hip) against autograd
+    through the fp64 oracle with the reference's fp32 bound (max|delta| <= 1e-4, t_cpp:273-287, scaled by the
+    gradient's magnitude) and against the generic kernels they replace; causal and unmasked."""
+    import torch.nn.functional as F
+
+    import flash_attention_amd.auto  # noqa: F401
+    from oracle import dense_attention_lse, frozen_randn
+
+    q0, k0, v0 = (frozen_randn(SEED + L + D, (3, 1, G, L, D)) * 0.5)
+    g0 = frozen_randn(SEED + 3, (1, G, L, D))
+    scale = D ** -0.5
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q0, k0, v0))
+    ref, _ = dense_attention_lse(qr, kr, vr, scale=scale, causal=causal)
+    ref.backward(g0.double())
+
+    def run():
+        q, k, v = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
+        out = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
+        out.backward(g0.cuda())
+        return out.detach(), q.grad, k.grad, v.grad
+
+    got = run()
+    knobs.set("f32_generic", 1)
+    gen = run()
+    for name, a, b, want in zip(("out", "dq", "dk", "dv"), got, gen, (ref.detach(), qr.grad, kr.grad, vr.grad)):
+        bound = 1e-4 * max(1.0, want.abs().max().item())
+        assert torch.isfinite(a).all(), name
+        assert (a.cpu().double() - want).abs().max().item() <= bound, (name, (a.cpu().double() - want).abs().max().item(), bound)
+        assert (a - b).abs().max().item() <= 2 * bound, (name, "vs generic kernels")
