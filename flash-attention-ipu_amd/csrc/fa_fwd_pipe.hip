@@ -50,6 +50,13 @@
 #ifndef FA_PIPE_MFMASUM
 #define FA_PIPE_MFMASUM 1
 #endif
+// 1: a hand-scheduled step runs its PV MFMAs first (their V^T fragments were requested in the MIDDLE of the previous
+// step - V(i-1) has been published for two steps - and sit in registers across the step barrier) and its QK^T MFMAs
+// second (K(i+1) only becomes visible at the previous step's barrier; its rows are requested at the top of the step
+// and have the PV MFMAs to land).  No LDS operand latency is exposed at the top of a step.
+#ifndef FA_PIPE_PVFIRST
+#define FA_PIPE_PVFIRST 1
+#endif
 #if FA_PIPE_ABL == 1
 #define FA_PIPE_BARRIER() asm volatile("" ::: "memory")
 #else
@@ -278,17 +285,31 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // feeding QB MFMAs, each MFMA followed by its share of the softmax of S(I_): score pair p of block b (two
     // registers -> one packed dword of P) goes fma -> exp -> add, cvt, skewed over three groups so that nothing
     // waits for the transcendental unit; LDS operands are requested FA_PIPE_PF operands ahead.
+#define FA_OPND_IS_K(X_, NK_) (FA_PIPE_PVFIRST ? (X_) >= 2 * DT : (X_) < (NK_))
+#define FA_OPND_KIDX(X_, NK_) (FA_PIPE_PVFIRST ? (X_) - 2 * DT : (X_))
+#define FA_OPND_VIDX(X_, NK_) (FA_PIPE_PVFIRST ? (X_) : (X_) - (NK_))
 #define FA_OPND_LOAD(X_, NK_)                                                                      \
-        if constexpr ((X_) < (NK_)) {                                                              \
-            opnd[(X_)] = *(const vec8*)(kb_ + k_rd[(X_) < KS ? (X_) : 0]);                         \
+        if constexpr (FA_OPND_IS_K(X_, NK_)) {                                                     \
+            constexpr int kx_ = FA_OPND_KIDX(X_, NK_);                                             \
+            opnd[(X_)] = *(const vec8*)(kb_ + k_rd[kx_ < KS ? kx_ : 0]);                           \
         } else {                                                                                   \
-            constexpr int t_ = (X_) - (NK_);                                                       \
+            constexpr int t_ = FA_OPND_VIDX(X_, NK_);                                              \
             const unsigned char* vp = vb_ + (t_ % DT) * VBLK_B + (t_ / DT) * 1024 + v_rd;          \
             const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                              \
                 (i16x4 __attribute__((address_space(3)))*)(vp));                                   \
             const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                              \
                 (i16x4 __attribute__((address_space(3)))*)(vp + 512));                             \
             opnd[(X_)] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); \
+        }
+    // V^T fragment T_ (0 .. 2 DT - 1) of the V slot at VB_ -> pre[T_]
+#define FA_PRE_LOAD(T_, VB_)                                                                       \
+        {                                                                                          \
+            const unsigned char* vp = (VB_) + ((T_) % DT) * VBLK_B + ((T_) / DT) * 1024 + v_rd;    \
+            const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                              \
+                (i16x4 __attribute__((address_space(3)))*)(vp));                                   \
+            const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                              \
+                (i16x4 __attribute__((address_space(3)))*)(vp + 512));                             \
+            pre[(T_)] = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); \
         }
     // vector work item V_ (0 .. 8 QB - 1) = score pair V_ % 8 of block V_ / 8
     // MASK_ modes: 0 no mask; 1 causal mask on every block; 2 mask on block 0 only (two blocks: the step of block
@@ -344,10 +365,13 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         constexpr int PF_ = FA_PIPE_PF < NM ? FA_PIPE_PF : NM;                                     \
         const unsigned char* kb_ = smem + (KN_) * KH_B;                                            \
         const unsigned char* vb_ = smem_v + (VP_) * VH_B;                                          \
+        const unsigned char* vnext_ = smem_v + (((VP_) + 1) & NSM) * VH_B;                         \
         const int key0_ = (I_) * HK + 4 * h;                                                       \
-        (void)kb_; (void)key0_;                                                                    \
+        (void)kb_; (void)key0_; (void)vnext_;                                                      \
         vec8 opnd[NM];                                                                             \
-        fa_static_for<0, PF_>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; FA_OPND_LOAD(x_, NK) }); \
+        constexpr int NPRE = FA_PIPE_PVFIRST ? 2 * DT : 0;                                         \
+        fa_static_for<0, NPRE>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; opnd[x_] = pre[x_]; }); \
+        fa_static_for<NPRE, (NPRE > PF_ ? NPRE : PF_)>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; FA_OPND_LOAD(x_, NK) }); \
         float mc[QB], ls[QB];                                                                      \
         _Pragma("unroll") for (int b = 0; b < QB; ++b) { mc[b] = m[b] * c; ls[b] = 0.f; }          \
         FA_ITEM_FMA(SC_, 0, MASK_)                                                                 \
@@ -356,19 +380,24 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         __builtin_amdgcn_sched_barrier(0);                                                         \
         fa_static_for<0, NMF>([&](auto gi_) {                                                      \
             constexpr int n_ = decltype(gi_)::value, g_ = n_ / QB, b_ = n_ % QB;                   \
-            if constexpr (g_ < NK) {                                                               \
-                if constexpr (g_ == 0) {                                                           \
+            if constexpr (FA_OPND_IS_K(g_, NK)) {                                                  \
+                constexpr int kx_ = FA_OPND_KIDX(g_, NK);                                          \
+                if constexpr (kx_ == 0) {                                                          \
                     f32x16 z_;                                                                     \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) z_[e] = 0.f;                    \
-                    SN_[b_] = E::mfma(opnd[g_], qf[b_][g_ < KS ? g_ : 0], z_);                     \
+                    SN_[b_] = E::mfma(opnd[g_], qf[b_][kx_ < KS ? kx_ : 0], z_);                   \
                 } else {                                                                           \
-                    SN_[b_] = E::mfma(opnd[g_], qf[b_][g_ < KS ? g_ : 0], SN_[b_]);                \
+                    SN_[b_] = E::mfma(opnd[g_], qf[b_][kx_ < KS ? kx_ : 0], SN_[b_]);              \
                 }                                                                                  \
             } else {                                                                               \
-                constexpr int t_ = g_ - NK;                                                        \
+                constexpr int t_ = FA_OPND_VIDX(g_, NK);                                           \
                 o[b_][t_ % DT] = E::mfma(opnd[g_], PP_[b_][t_ / DT], o[b_][t_ % DT]);              \
             }                                                                                      \
-            if constexpr (b_ == QB - 1 && g_ + PF_ < NM) { FA_OPND_LOAD(g_ + PF_, NK) }            \
+            if constexpr (b_ == QB - 1 && g_ + PF_ < NM && g_ + PF_ >= NPRE) { FA_OPND_LOAD(g_ + PF_, NK) } \
+            /* the NEXT step's V^T fragments, requested once this step's have been consumed */     \
+            if constexpr (FA_PIPE_PVFIRST && (QK_) && b_ == QB - 1 && g_ >= NPRE && g_ < 2 * NPRE) { \
+                FA_PRE_LOAD(g_ - NPRE, vnext_)                                                     \
+            }                                                                                      \
             /* this MFMA's share of the vector work items */                                      \
             fa_static_for<(n_ * NV) / NMF, ((n_ + 1) * NV) / NMF>([&](auto vi_) {                  \
                 constexpr int v_ = decltype(vi_)::value;                                           \
@@ -431,6 +460,10 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             }                                                                                      \
             _Pragma("unroll") for (int b = 0; b < QB; ++b) l[b] += ls[b];                          \
             FA_PACK_H(PC_, SC_)                                                                    \
+            if (FA_PIPE_PVFIRST && !(SAFE_)) {   /* V(i) fragments for a hand-scheduled step i + 1 */  \
+                const unsigned char* vn_ = smem_v + (i_ & NSM) * VH_B;                             \
+                fa_static_for<0, 2 * DT>([&](auto ti_) { constexpr int t2_ = decltype(ti_)::value; FA_PRE_LOAD(t2_, vn_) }); \
+            }                                                                                      \
         }                                                                                          \
         FA_PUBLISH()                                                                               \
     }
@@ -482,6 +515,11 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 
     f32x16 sa[QB], sb[QB];
     vec8 pa[QB][2], pb[QB][2];
+    vec8 pre[2 * DT];          // the next hand-scheduled step's V^T fragments (FA_PIPE_PVFIRST)
+#pragma unroll
+    for (int t = 0; t < 2 * DT; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pre[t][j] = (T)0.f;
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
 #pragma unroll
@@ -526,6 +564,10 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #undef FA_RAGGED
 #undef FA_ROTATE
 #undef FA_OPND_LOAD
+#undef FA_OPND_IS_K
+#undef FA_OPND_KIDX
+#undef FA_OPND_VIDX
+#undef FA_PRE_LOAD
 #undef FA_ITEM_FMA
 #undef FA_ITEM_MASKED
 #undef FA_ITEM_DEAD

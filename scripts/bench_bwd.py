@@ -5,9 +5,12 @@ sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd")]
 import torch
 from flash_attention_amd._impl import _native
 CFG = {"cfg2": (128, 4096, 64), "d128": (64, 4096, 128), "short": (512, 1024, 64), "cfg5": (256, 8192, 64)}
-for name in sys.argv[1:] or ["cfg2"]:
+DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+for spec in sys.argv[1:] or ["cfg2"]:          # cfg2 | cfg2:f32 | d128:f16 ...
+    name, _, dtn = spec.partition(":")
     G, L, D = CFG[name]
-    dt = torch.bfloat16
+    dt = DT[dtn or "bf16"]
+    name = spec
     qkv = (torch.randn(3, G, L, D, device="cuda") * 0.5).to(dt)
     dout = torch.randn(G, L, D, device="cuda").to(dt)
     out = torch.empty(G, L, D, device="cuda", dtype=dt)
