@@ -142,15 +142,15 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         // ---- debug overrides
         const int fk = opt.kernel, fw = opt.waves, fq = opt.qb;
         if (fk || fw || fq || opt.sched > 0 || (dtype == FA_DTYPE_F16 && opt.skipmax >= 0)) source = 2;
-        if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && (waves > 4)) which = 'd'; }
+        if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
         if (fk == 't') { which = 't'; qb = 1; }
         else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
-        else if (fk == 'p' && pipe_ok && waves <= 4) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
+        else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
         if (fq == 1) qb = 1;
         if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
         // ---- constraints of the kernels
-        if (want32 && pipe_ok && which == 'd' && fk == 0) { which = 'p'; if (waves > 4) waves = 4; }
-        if (which == 'p' && (waves > 4 || !pipe_ok)) which = 'd';
+        if (want32 && pipe_ok && which == 'd' && fk == 0) { which = 'p'; if (waves > 4 && D != 128) waves = 4; }
+        if (which == 'p' && ((waves > 4 && D != 128) || !pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
         if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
         if (which == 't' && waves > 4) waves = 4;
         plan->kernel = which == 'p' ? 2 : 0;

@@ -634,6 +634,9 @@ static hipError_t launch_pipe_w(const FwdParams& p, int waves, int qb, hipStream
         }
     }
     hipError_t e;
+    if constexpr (D == 128) {   // 8 waves x 32 rows = 256-row workgroups: half the L2 -> LDS traffic per FLOP (one K / V piece per wave and step)
+        if (waves == 8) return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 8, 1>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    }
     switch (waves) {
         case 4: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
         case 2: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 2, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
@@ -642,7 +645,7 @@ static hipError_t launch_pipe_w(const FwdParams& p, int waves, int qb, hipStream
     return e;
 }
 
-// callers guarantee: D in {64, 128}, waves in {1, 2, 4}, skip-max arithmetic wanted (bf16, or f16 with p.skipmax);
+// callers guarantee: D in {64, 128}, waves in {1, 2, 4} (or 8 at D = 128), skip-max arithmetic wanted (bf16, or f16 with p.skipmax);
 // qb = 32-row query blocks per wave (2 only for D = 64 with 4 waves; the host sized p.nq_tiles for it)
 hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream) {
     if (dtype == 1) return p.D == 64 ? launch_pipe_w<__bf16, 64>(p, waves, qb, stream) : launch_pipe_w<__bf16, 128>(p, waves, qb, stream);

@@ -61,7 +61,7 @@ def candidates(G, L, D, skip, causal, scheds=True):
     bunches = sorted({b for b in (auto // 2, auto, auto * 2) if 1 <= b <= ng}) if scheds else [auto]
     out = []
     for kern, qb, w in itertools.product(("dma", "pipe"), (1, 2), (2, 4, 8)):
-        if kern == "pipe" and not (skip and causal and w <= 4):
+        if kern == "pipe" and not (skip and causal and (w <= 4 or D == 128)):
             continue
         if qb == 2 and (D != 64 or w != 4 or L < 256):
             continue

@@ -118,6 +118,23 @@ def test_every_mfma_kernel(knobs, kernel, qb, G, L, D):
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("G,L", [(2, 1000), (1, 4608), (3, 257)])
+def test_pipelined_kernel_8_wave_workgroups_head_dim_128(knobs, G, L):
+    """The pipelined kernel with 8 waves x 32 rows (256-row workgroups, head_dim 128 only): out and logsumexp."""
+    _, native, with_lse = _mods()
+    from oracle import frozen_randn
+
+    knobs.set("kernel", "pipe")
+    knobs.set("waves", 8)
+    p = native.plan(G, L, 128, torch.bfloat16, 1, 1)
+    assert (p.kernel, p.waves, p.block_q, p.block_kv) == (2, 8, 256, 32)
+    qkv = frozen_randn(SEED + 11 * L, (3, G, L, 128)).to(torch.bfloat16)
+    ref, ref_lse = _oracle(qkv)
+    out, lse = with_lse(qkv.cuda(), 1, 1)
+    _check(out, ref, torch.bfloat16, f"pipe 8 waves {G}x{L}x128")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("nq,nk", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 3), (3, 2), (3, 3)])
 def test_tiny_fp32_all_chunk_pairs(golden_dir, nq, nk):
     """t_cpp:245-251: fp32 G=4 L=6 D=2, every chunk pair; golden G3 from the reference CPU path."""
