@@ -36,7 +36,7 @@ int elt_size(int dtype) { return dtype == FA_DTYPE_F32 ? 4 : 2; }
 // either the old or the new value of one knob and never a torn one; fa_plan() and fa_fwd() go through the same
 // make_plan(), so a reported plan is the launched plan.
 struct Options {
-    std::atomic<int> kernel{0};     // 0 auto, 'd' | 'p' | 't'
+    std::atomic<int> kernel{0};     // 0 auto, 'd' | 'p' | 'x' | 't'
     std::atomic<int> qb{0};         // 0 auto, 1 | 2 query blocks per wave
     std::atomic<int> waves{0};      // 0 auto, 1 | 2 | 4 | 8
     std::atomic<int> sched{0};      // 0 auto, else groups per L2 bunch
@@ -47,7 +47,11 @@ struct Options {
 Options g_opt;
 std::once_flag g_opt_once;
 
-int parse_kernel(const char* v) { return (v && (v[0] == 't' || v[0] == 'd' || v[0] == 'p')) ? v[0] : 0; }
+int parse_kernel(const char* v) {   // dma | pipe | pipe16 | tile
+    if (!v) return 0;
+    if (strcmp(v, "pipe16") == 0 || v[0] == 'x') return 'x';
+    return (v[0] == 't' || v[0] == 'd' || v[0] == 'p') ? v[0] : 0;
+}
 
 const Options& options() {
     std::call_once(g_opt_once, [] {
@@ -87,6 +91,7 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 // The ONE selection function behind fa_plan() and fa_fwd().
 //   'd' fa_fwd_dma_kernel   64-key tiles, LDS-DMA staged (fa_fwd_dma.hip)
 //   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic, causal only
+//   'x' fa_fwd_pipe16_kernel the pipelined kernel on v_mfma_f32_16x16x32 (fa_fwd_pipe16.hip): head_dim 128, 4 waves, qb 1
 //   't' fa_fwd_tile_kernel  register-staged A/B baseline (debug override only)
 // qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
 // Order: debug overrides > measured table (fa_tuning_table.h) > built-in rules; the num_chunks_* bounds and the
@@ -134,7 +139,8 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
             for (const fa::TuneRow& r : fa::kTuneTable) {
                 if (r.D != D || r.skip != skip || r.causal != causal || L < r.L_lo || L > r.L_hi || wgs128 < r.wg_lo || wgs128 > r.wg_hi) continue;
                 if (32 * r.waves * r.qb > (cq > 32 ? cq : 32)) continue;   // the q chunk forbids the row's tile
-                if (r.kernel == 'p' && !pipe_ok) continue;
+                if ((r.kernel == 'p' || r.kernel == 'x') && !pipe_ok) continue;
+                if (r.kernel == 'x' && D != 128) continue;
                 which = r.kernel; waves = r.waves; qb = r.qb; sched = r.sched; source = 1;
                 break;
             }
@@ -145,23 +151,27 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
         if (fk == 't') { which = 't'; qb = 1; }
         else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
+        else if (fk == 'x' && pipe_ok && D == 128) { which = 'x'; waves = 4; qb = 1; }
         else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
         if (fq == 1) qb = 1;
         if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
         // ---- constraints of the kernels
         if (want32 && pipe_ok && which == 'd' && fk == 0) { which = 'p'; if (waves > 4 && D != 128) waves = 4; }
         if (which == 'p' && ((waves > 4 && D != 128) || !pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
+        if (which == 'x' && !(pipe_ok && D == 128)) which = 'd';
+        if (which == 'x') { waves = 4; qb = 1; }
         if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
         if (which == 't' && waves > 4) waves = 4;
-        plan->kernel = which == 'p' ? 2 : 0;
+        plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : 0;
         plan->waves = waves;
         plan->qb = qb;
         plan->block_q = 32 * waves * qb;
-        plan->block_kv = which == 'p' ? 32 : 64;
+        plan->block_kv = (which == 'p' || which == 'x') ? 32 : 64;
         plan->skipmax = skip;
         plan->source = source;
         plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
-        plan->lds_bytes = which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
+        plan->lds_bytes = which == 'x' ? 8 * 32 * D * 2 + 16
+                          : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
                                        : 2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64);
         // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
         // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
@@ -248,8 +258,8 @@ int fa_debug_set_option(const char* name, int32_t value) {
     for (const OptionName& o : kOptionNames) {
         if (strcmp(o.name, name) != 0) continue;
         if (value < o.lo || value > o.hi) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: %s=%d out of range [%d, %d]", name, value, o.lo, o.hi);
-        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 't'))
-            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p' or 't'");
+        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 't'))
+            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x' or 't'");
         if (o.field == &Options::waves && !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: waves must be 0, 1, 2, 4 or 8");
         (g_opt.*(o.field)).store(value);
@@ -356,6 +366,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     hipError_t e = sel.which == 'g'   ? fa::launch_fwd_generic(p, dtype, st)
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
+                   : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, st)
                    : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves, plan.qb, st)
                                       : fa::launch_fwd_tile(p, dtype, plan.waves, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

@@ -1,0 +1,470 @@
+// FlashAttention forward for MI355X (gfx950), head_dim 128: the software-pipelined kernel of fa_fwd_pipe.hip rebuilt
+// on v_mfma_f32_16x16x32 (read fa_fwd_pipe.hip first: same rings, LDS-DMA staging, step barrier, optimistic skip-max
+// arithmetic with an exact fallback pass, PV-first step order with the next step's V^T fragments requested mid-step).
+//
+// Why a second MFMA shape: at head_dim 128 the pipelined 32x32x16 kernel keeps the matrix pipe ~75 % busy and the device
+// answers by dropping to ~1.64 GHz (profiles/r02_cfg3) - it is power-bound - and on this chip the clock held under a
+// bf16 MFMA stream depends on the MFMA shape: 16x16x32 delivers 1.12-1.14x the FLOP/s of 32x32x16 at equal cycles with
+// operands read from LDS (MI355X_MICROARCH.md, DVFS give-back item 7; cdna_hip_programming.md rule 28).  The shape costs
+// issue slots (twice the MFMAs, each holding the issue port 8 cycles): 34 MFMAs x 8 + ~224 VALU cycles = ~500 issue
+// cycles per 32-key step against 544 matrix cycles at head_dim 128 - it fits; at head_dim 64 it would not (the 64-wide
+// kernel is issue-bound already), so this file exists for head_dim 128 only.
+//
+// Operand maps (lane l: n = l & 15, g = l >> 4):
+//   A[16 x 32]: A[row n][k = 8 g + j]      B[32 x 16]: B[k = 8 g + j][col n]      C/D[16 x 16]: [row 4 g + j][col n], j = 0..3
+//   S^T tile (kb, qh) = K(16 keys of block kb) Q^T(16 queries of half qh), summed over four 32-wide d slices:
+//     A = K[key 16 kb + pi(n)][32 ds + 8 g ..+7]  (one ds_read_b128),  B = Q[q_row0 + 16 qh + n][32 ds + 8 g ..+7]  (registers)
+//     -> lane holds S^T[key 16 kb + pi(4 g + j)][query 16 qh + n]:  a query on the lane, as in the 32x32 kernels.
+//     pi(r) = 8 ((r >> 2) & 1) + 4 (r >> 3) + (r & 3) renumbers the keys of a block so that the two lane groups of a
+//     half-wave own keys 8 apart (g = 0: 0-3, g = 1: 8-11, g = 2: 4-7, g = 3: 12-15): that makes the transposed V reads
+//     below bank-conflict free; any fixed renumbering is legal because the same keys meet again in the PV contraction.
+//   O^T tile (db, qh) += V^T(16 d of block db x 32 keys) P^T(32 keys x 16 queries of half qh):
+//     B = the lane's 8 probabilities of the step: j' = 0..3 from S^T tile (0, qh), 4..7 from tile (1, qh), i.e. contraction
+//     index k' = 8 g + j' <-> key 16 (j' >> 2) + pi(4 g + (j' & 3));  A = V[that key][16 db + n] = two ds_read_b64_tr_b16
+//     (4 keys x 16 columns each, transposed by the LDS hardware) from a plain row-major V image.
+//   row sums: one more MFMA per query half with an all-ones A: every lane receives the full 32-key sum of its query.
+// LDS images (32-key slots, 256-byte rows, both filled by LDS-DMA with per-lane source addresses):
+//   K: 16-byte chunk c of row r at chunk slot c ^ (r & 15)                      (conflict-free ds_read_b128 rows)
+//   V: chunk c of row r at slot c ^ (((r & 3) << 2) | ((r >> 2) & 3))           (conflict-free transposed reads)
+
+#include "fa_device.h"
+
+#ifndef FA_P16_PF
+#define FA_P16_PF 8          // hand-scheduled step: LDS operands are requested this many operands ahead
+#endif
+#ifndef FA_P16_NPRE
+#define FA_P16_NPRE 8        // V^T fragments of the next step requested mid-step and held across the step barrier
+#endif
+
+namespace fa {
+
+template <typename T>
+__device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
+    using E = Elt<T>;
+    using vec8 = typename E::vec8;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    constexpr int D = 128, NWAVES = 4, BQ = NWAVES * 32, HK = 32, ROWB = D * 2;
+    constexpr int SLOT_B = HK * ROWB;           // 8 KiB K slot = V slot
+    constexpr int PIECES = SLOT_B / 1024, PPW = PIECES / NWAVES;
+    constexpr int NDS = D / 32;                 // 32-wide d slices of the QK^T contraction
+    constexpr int NDB = D / 16;                 // 16-row d blocks of O^T
+    constexpr int NS = 4, NSM = NS - 1;         // ring slots
+    constexpr int NPRE = FA_P16_NPRE;           // V^T fragments of the next step held in registers across the step barrier
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NS * SLOT_B];   // K0..K3 V0..V3
+    unsigned char* const smem_v = smem + NS * SLOT_B;
+    __shared__ int flags[NWAVES];
+
+    const int b = blockIdx.x;
+    const int nq = p.nq_tiles;
+    int g, qi;
+    {
+        const int xcd = b & 7, slot = b >> 3;
+        const int ng = p.G8 >> 3;
+        const int per_bunch = p.sched * nq;
+        const int bunch = slot / per_bunch;
+        const int rem = slot - bunch * per_bunch;
+        const int g0 = bunch * p.sched;
+        const int bc = (ng - g0) < p.sched ? (ng - g0) : p.sched;
+        const int qd = rem / bc;
+        qi = nq - 1 - qd;
+        g = (g0 + (rem - qd * bc)) * 8 + xcd;
+    }
+    if (g >= p.G) return;
+
+    const int L = p.L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, gq = lane >> 4;
+    const int bb = g / p.H, hh = g - bb * p.H;
+    const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
+    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
+    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
+
+    const int q_row0 = qi * BQ + wave * 32;
+    const bool wave_active = q_row0 < L;
+    int qrow[2];                                 // this lane's query row in each 16-row half
+    vec8 qf[2][NDS];
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+        qrow[qh] = q_row0 + 16 * qh + n;
+        const int qr = qrow[qh] < L ? qrow[qh] : L - 1;
+        const T* qp = qg + (int64_t)qr * p.q_sl + 8 * gq;
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) qf[qh][ds] = *(const vec8*)(qp + 32 * ds);
+    }
+
+    // ---- LDS-DMA geometry: piece pc = wave + j NWAVES = rows 4 pc .. 4 pc + 3 of a slot; the lane's LDS destination is
+    // linear (row 4 pc + (lane >> 4), chunk slot lane & 15), its SOURCE chunk is the one the image stores in that slot
+    const unsigned k_slb = (unsigned)p.k_sl * 2, v_slb = (unsigned)p.v_sl * 2;
+    unsigned k_vo[PPW], v_vo[PPW];
+    int dst[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pc = wave + j * NWAVES;
+        const int row = 4 * pc + (lane >> 4), cp = lane & 15;
+        k_vo[j] = (unsigned)row * k_slb + ((cp ^ (row & 15)) << 4);
+        v_vo[j] = (unsigned)row * v_slb + ((cp ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+        dst[j] = pc * 1024;
+    }
+    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;
+    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
+    const unsigned smem_lds = lds_offset(smem);
+
+#define P16_DMA_K(J_, SLOT_)                                                                       \
+    {                                                                                              \
+        const unsigned ko_ = (unsigned)(J_) * HK * k_slb;                                          \
+        const i32x4 kr_ = make_raw_rsrc((const char*)kg + ko_, k_bytes - ko_);                     \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
+            lds_dma_b128(kr_, smem_lds + (SLOT_) * SLOT_B + dst[j], k_vo[j]);                      \
+    }
+#define P16_DMA_V(J_, SLOT_)                                                                       \
+    {                                                                                              \
+        const unsigned vo_ = (unsigned)(J_) * HK * v_slb;                                          \
+        const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
+            lds_dma_b128(vr_, smem_lds + (NS + (SLOT_)) * SLOT_B + dst[j], v_vo[j]);               \
+    }
+
+    // K fragment (kb, ds): row 16 kb + pi(n), chunk 4 ds + g
+    const int pin = 8 * ((n >> 2) & 1) + 4 * (n >> 3) + (n & 3);
+    int k_rd[2][NDS];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) k_rd[kb][ds] = (16 * kb + pin) * ROWB + (((4 * ds + gq) ^ pin) << 4);
+    // V^T fragment db: lane 4 q + pp of group g supplies row pi(4 g + q) (+16 for the second read), columns 16 db + 4 pp ..+3
+    const int vq = (lane & 15) >> 2, vpp = lane & 3;
+    const int vrow = 8 * (gq & 1) + 4 * (gq >> 1) + vq;
+    const int vsw = ((vrow & 3) << 2) | ((vrow >> 2) & 3);
+    int v_rd[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) v_rd[db] = vrow * ROWB + (((2 * db + (vpp >> 1)) ^ vsw) << 4) + 8 * (vpp & 1);
+    const int keyg = 8 * (gq & 1) + 4 * (gq >> 1);         // key of accumulator register j of S^T tile (kb, .): 16 kb + keyg + j
+
+    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    const int nh_wg = (kv_end + HK - 1) / HK;              // steps the workgroup streams
+    const int nh_w = wave_active ? q_row0 / HK + 1 : 0;    // steps this wave computes; the last one is its diagonal step
+
+    f32x4 o[NDB][2];
+    f32x4 lsum[2];
+    float m[2];
+    const vec8 ones = __builtin_bit_cast(vec8, u32x4{E::one_bits * 0x10001u, E::one_bits * 0x10001u, E::one_bits * 0x10001u, E::one_bits * 0x10001u});
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#define P16_RESET()                                                                                \
+    _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) {                                             \
+        m[qh] = -INFINITY;                                                                         \
+        lsum[qh] = zero4;                                                                          \
+        _Pragma("unroll") for (int db = 0; db < NDB; ++db) o[db][qh] = zero4;                      \
+    }
+    P16_RESET()
+    const float c = p.scale_log2;
+
+#define P16_KFRAG(KB_, DS_, SLOT_) (*(const vec8*)(smem + (SLOT_) * SLOT_B + k_rd[KB_][DS_]))
+#define P16_VFRAG(OUT_, DB_, VB_)                                                                  \
+    {                                                                                              \
+        const unsigned char* vp = (VB_) + v_rd[DB_];                                               \
+        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(vp)); \
+        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(vp + 16 * ROWB)); \
+        OUT_ = __builtin_bit_cast(vec8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));  \
+    }
+    // ---- compiler-scheduled pieces (first step, drain, idle steps, the exact fallback pass)
+#define P16_QK(S_, SLOT_)                                                                          \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                             \
+        _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) S_[kb][qh] = zero4;                       \
+        _Pragma("unroll") for (int ds = 0; ds < NDS; ++ds) {                                       \
+            const vec8 kf_ = P16_KFRAG(kb, ds, SLOT_);                                             \
+            _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) S_[kb][qh] = E::mfma16(kf_, qf[qh][ds], S_[kb][qh]); \
+        }                                                                                          \
+    }
+#define P16_PV(P_, SLOT_)                                                                          \
+    _Pragma("unroll") for (int db = 0; db < NDB; ++db) {                                           \
+        vec8 vf_;                                                                                  \
+        P16_VFRAG(vf_, db, smem_v + (SLOT_) * SLOT_B)                                              \
+        _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) o[db][qh] = E::mfma16(vf_, P_[qh], o[db][qh]); \
+    }
+#define P16_MASK(S_, I_)                                                                           \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                               \
+        _Pragma("unroll") for (int qh = 0; qh < 2; ++qh)                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+                if ((I_) * HK + 16 * kb + keyg + j > qrow[qh]) S_[kb][qh][j] = -INFINITY;
+    // exact row max of the step (a query's 32 scores sit in the 4 lanes n, n+16, n+32, n+48); raise m (rescaling O and the
+    // row sums) wherever it is exceeded
+#define P16_MAXR(S_)                                                                               \
+    _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) {                                             \
+        float mx = max2(max2(S_[0][qh][0], S_[0][qh][1]), max2(S_[0][qh][2], S_[0][qh][3]));       \
+        mx = max3(mx, max2(S_[1][qh][0], S_[1][qh][1]), max2(S_[1][qh][2], S_[1][qh][3]));         \
+        mx = max2(mx, __shfl_xor(mx, 16, 64));                                                     \
+        mx = max2(mx, __shfl_xor(mx, 32, 64));                                                     \
+        if (__builtin_amdgcn_ballot_w64((mx - m[qh]) * c > 0.0f) != 0) {                           \
+            const float m_new = max2(m[qh], mx);                                                   \
+            const float alpha = fast_exp2((m[qh] - m_new) * c);                                    \
+            m[qh] = m_new;                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) lsum[qh][j] *= alpha;                    \
+            _Pragma("unroll") for (int db = 0; db < NDB; ++db)                                     \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) o[db][qh][j] *= alpha;               \
+        }                                                                                          \
+    }
+    // P = 2^(c S - c m), packed as the B fragment of the PV product (j' = 0..3 from key block 0, 4..7 from block 1), row sums
+#define P16_SM_PACK(PC_, S_)                                                                       \
+    _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) {                                             \
+        const float mc = m[qh] * c;                                                                \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+                PC_[qh][4 * kb + j] = (T)fast_exp2(__builtin_fmaf(S_[kb][qh][j], c, -mc));         \
+        lsum[qh] = E::mfma16(ones, PC_[qh], lsum[qh]);                                             \
+    }
+    // every step: issue the DMA for K(i+3), V(i+2); compute; publish (everything issued before this step has landed)
+#define P16_ISSUE(I_, KSLOT_, VSLOT_)                                                              \
+        const bool dk_ = (I_) + NS - 1 < nh_wg, dv_ = (I_) + NS - 2 < nh_wg;                       \
+        if (dk_) P16_DMA_K((I_) + NS - 1, KSLOT_)                                                  \
+        if (dv_) P16_DMA_V((I_) + NS - 2, VSLOT_)
+#define P16_PUBLISH()                                                                              \
+        if (dk_ && dv_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NS - 3)) : "memory");  \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        __syncthreads();
+#define P16_PRE(VB_)                                                                               \
+        fa_static_for<0, NPRE>([&](auto ti_) { constexpr int t2_ = decltype(ti_)::value; P16_VFRAG(pre[t2_], t2_, VB_) });
+#define P16_GENERIC(I_, SC_, SN_, PP_, PC_, SAFE_)                                                 \
+    {                                                                                              \
+        const int i_ = (I_);                                                                       \
+        P16_ISSUE(i_, (i_ + NS - 1) & NSM, (i_ + NS - 2) & NSM)                                    \
+        if (i_ + 1 < nh_w) P16_QK(SN_, (i_ + 1) & NSM)                                             \
+        if (i_ >= 1 && i_ <= nh_w) P16_PV(PP_, (i_ + NS - 1) & NSM)                                \
+        if (i_ < nh_w) {                                                                           \
+            if (i_ == nh_w - 1) P16_MASK(SC_, i_)                                                  \
+            if (i_ == 0 || (SAFE_)) P16_MAXR(SC_)                                                  \
+            P16_SM_PACK(PC_, SC_)                                                                  \
+            if (!(SAFE_)) P16_PRE(smem_v + (i_ & NSM) * SLOT_B)   /* V(i) fragments for a hand-scheduled step i + 1 */ \
+        }                                                                                          \
+        P16_PUBLISH()                                                                              \
+    }
+    // ---- hand-scheduled step.  32 (or 16 on a wave's last step) MFMAs in a fixed order: PV first (operands x = 0..7 =
+    // V^T fragments of V(i-1), the first NPRE of them held in `pre` since the middle of the previous step), then QK^T
+    // (operands x = 8..15 = K(i+1) fragments (kb, ds), requested at the top of the step); every operand feeds the two query
+    // halves.  The softmax of S(i) is cut into 8 items (2 scores -> one dword of P) and spread one sub-operation per MFMA
+    // gap: [2 fma] [exp] [exp] [cvt (+ row-sum MFMA when a half's fragment is complete)] - at most 8 VALU issue cycles
+    // beside a 16-cycle MFMA.  Frozen with sched_barrier(0).
+#define P16_ITEM_FMA(SC_, V_, MASK_)                                                               \
+        {                                                                                          \
+            constexpr int qh_ = (V_) >> 2, kb_ = ((V_) >> 1) & 1, e_ = 2 * ((V_) & 1);             \
+            if constexpr (MASK_) {                                                                 \
+                const int key_ = key0_ + 16 * kb_ + e_;                                            \
+                if (key_ > qrow[qh_]) SC_[kb_][qh_][e_] = -INFINITY;                               \
+                if (key_ + 1 > qrow[qh_]) SC_[kb_][qh_][e_ + 1] = -INFINITY;                       \
+            }                                                                                      \
+            SC_[kb_][qh_][e_] = __builtin_fmaf(SC_[kb_][qh_][e_], c, -mc[qh_]);                    \
+            SC_[kb_][qh_][e_ + 1] = __builtin_fmaf(SC_[kb_][qh_][e_ + 1], c, -mc[qh_]);            \
+        }
+#define P16_ITEM_EXP(SC_, V_, EL_)                                                                 \
+        {                                                                                          \
+            constexpr int qh_ = (V_) >> 2, kb_ = ((V_) >> 1) & 1, e_ = 2 * ((V_) & 1) + (EL_);     \
+            SC_[kb_][qh_][e_] = fast_exp2(SC_[kb_][qh_][e_]);                                      \
+        }
+#define P16_ITEM_CVT(SC_, PC_, V_)                                                                 \
+        {                                                                                          \
+            constexpr int qh_ = (V_) >> 2, kb_ = ((V_) >> 1) & 1, e_ = 2 * ((V_) & 1);             \
+            PC_[qh_][4 * kb_ + e_] = (T)SC_[kb_][qh_][e_];                                         \
+            PC_[qh_][4 * kb_ + e_ + 1] = (T)SC_[kb_][qh_][e_ + 1];                                 \
+            if constexpr (((V_) & 3) == 3) lsum[qh_] = E::mfma16(ones, PC_[qh_], lsum[qh_]);       \
+        }
+#define P16_OPND_LOAD(X_)                                                                          \
+        if constexpr ((X_) < NDB) {                                                                \
+            P16_VFRAG(opnd[(X_)], (X_), vb_)                                                       \
+        } else {                                                                                   \
+            opnd[(X_)] = *(const vec8*)(kb_ + k_rd[((X_) - NDB) / NDS][((X_) - NDB) % NDS]);       \
+        }
+#define P16_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_)                            \
+    {                                                                                              \
+        P16_ISSUE(I_, KI_, VI_)                                                                    \
+        constexpr int NM = NDB + ((QK_) ? 2 * NDS : 0), NMF = 2 * NM, NV = 8, GAP = NMF / NV;      \
+        constexpr int PF_ = FA_P16_PF < NM ? FA_P16_PF : NM;                                       \
+        const unsigned char* kb_ = smem + (KN_) * SLOT_B;                                          \
+        const unsigned char* vb_ = smem_v + (VP_) * SLOT_B;                                        \
+        const unsigned char* vnext_ = smem_v + (((VP_) + 1) & NSM) * SLOT_B;                       \
+        const int key0_ = (I_) * HK + keyg;                                                        \
+        (void)kb_; (void)key0_; (void)vnext_;                                                      \
+        vec8 opnd[NM];                                                                             \
+        fa_static_for<0, NPRE>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; opnd[x_] = pre[x_]; }); \
+        fa_static_for<NPRE, (NPRE > PF_ ? NPRE : PF_)>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; P16_OPND_LOAD(x_) }); \
+        float mc[2];                                                                               \
+        _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) mc[qh] = m[qh] * c;                       \
+        P16_ITEM_FMA(SC_, 0, MASK_)                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        fa_static_for<0, NMF>([&](auto gi_) {                                                      \
+            constexpr int n_ = decltype(gi_)::value, g_ = n_ / 2, qh_ = n_ % 2;                    \
+            if constexpr (g_ < NDB) {                                                              \
+                o[g_][qh_] = E::mfma16(opnd[g_], PP_[qh_], o[g_][qh_]);                            \
+            } else {                                                                               \
+                constexpr int kbx_ = (g_ - NDB) / NDS, ds_ = (g_ - NDB) % NDS;                     \
+                if constexpr (ds_ == 0) SN_[kbx_][qh_] = E::mfma16(opnd[g_], qf[qh_][ds_], zero4); \
+                else SN_[kbx_][qh_] = E::mfma16(opnd[g_], qf[qh_][ds_], SN_[kbx_][qh_]);           \
+            }                                                                                      \
+            if constexpr (qh_ == 1 && g_ + PF_ < NM && g_ + PF_ >= NPRE) { P16_OPND_LOAD(g_ + PF_) } \
+            /* the NEXT step's first V^T fragments, requested once this step's held ones have been consumed */ \
+            if constexpr ((QK_) && qh_ == 1 && g_ >= NPRE && g_ < 2 * NPRE) { P16_VFRAG(pre[g_ - NPRE], g_ - NPRE, vnext_) } \
+            /* this gap's share of the softmax of S(i) */                                          \
+            constexpr int w_ = n_ / GAP, ph_ = n_ % GAP;                                           \
+            if constexpr (GAP == 4) {                                                              \
+                if constexpr (ph_ == 0 && w_ + 1 < NV) { P16_ITEM_FMA(SC_, w_ + 1, MASK_) }        \
+                if constexpr (ph_ == 1) { P16_ITEM_EXP(SC_, w_, 0) }                               \
+                if constexpr (ph_ == 2) { P16_ITEM_EXP(SC_, w_, 1) }                               \
+                if constexpr (ph_ == 3) { P16_ITEM_CVT(SC_, PC_, w_) }                             \
+            } else {                                                                               \
+                if constexpr (ph_ == 0) { if constexpr (w_ + 1 < NV) { P16_ITEM_FMA(SC_, w_ + 1, MASK_) } P16_ITEM_EXP(SC_, w_, 0) } \
+                if constexpr (ph_ == 1) { P16_ITEM_EXP(SC_, w_, 1) P16_ITEM_CVT(SC_, PC_, w_) }    \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        });                                                                                        \
+        /* pin this step's vector work to this step */                                             \
+        asm volatile("" : "+v"(PC_[0]), "+v"(PC_[1]), "+v"(lsum[0]), "+v"(lsum[1]));               \
+        P16_PUBLISH()                                                                              \
+    }
+#define P16_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                     \
+    P16_FAST(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, false, true)
+#define P16_ROTATE()                                                                               \
+    _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) {                                             \
+        sa[0][qh] = sb[0][qh];                                                                     \
+        sa[1][qh] = sb[1][qh];                                                                     \
+        pb[qh] = pa[qh];                                                                           \
+    }
+#define P16_RAGGED(I_, MASK_, QK_)                                                                 \
+    P16_FAST(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, MASK_, QK_)
+    // one pass over the kv steps of this workgroup.  S(i) lives in sa for even i and in sb for odd i; P(i) in pa / pb
+    // likewise.  Groups of four steady steps start at i = 1.
+#define P16_RUN(SAFE_)                                                                             \
+    {                                                                                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < NS - 1; ++j_) {       /* K(0..NS-2), V(0..NS-3) */    \
+            if (j_ < nh_wg) P16_DMA_K(j_, j_)                                                      \
+            if (j_ < NS - 2 && j_ < nh_wg) P16_DMA_V(j_, j_)                                       \
+        }                                                                                          \
+        lds_dma_wait_all();                                                                        \
+        __syncthreads();                                                                           \
+        if (nh_w >= 1) P16_QK(sa, 0)                                                               \
+        P16_GENERIC(0, sa, sb, pb, pa, SAFE_)                                                      \
+        int i = 1;                                                                                 \
+        if (!(SAFE_)) {                                                                            \
+            for (; i + NS - 1 + 1 < nh_w; i += NS) {   /* steps i .. i+NS-1 carry no mask */         \
+                fa_static_for<0, NS>([&](auto ki_) {                                               \
+                    constexpr int k_ = decltype(ki_)::value, R_ = (1 + k_) % NS;                   \
+                    if constexpr (k_ % 2 == 0) P16_STEADY(i + k_, R_, sb, sa, pa, pb)              \
+                    else P16_STEADY(i + k_, R_, sa, sb, pb, pa)                                    \
+                });                                                                                \
+            }                                                                                      \
+        }                                                                                          \
+        P16_ROTATE()                                           /* i is odd: S(i) sb -> sa, P(i-1) pa -> pb */ \
+        if (!(SAFE_)) {                                                                            \
+            for (; i + 1 < nh_w; ++i) {                        /* steps the groups left over */    \
+                P16_RAGGED(i, false, true)                                                         \
+                P16_ROTATE()                                                                       \
+            }                                                                                      \
+            if (i < nh_w) {                                    /* the wave's last (diagonal) step */ \
+                P16_RAGGED(i, true, false)                                                         \
+                P16_ROTATE()                                                                       \
+                ++i;                                                                               \
+            }                                                                                      \
+        }                                                                                          \
+        for (; i <= nh_wg; ++i) {                              /* drain, idle (and the exact pass) */ \
+            P16_GENERIC(i, sa, sb, pb, pa, SAFE_)                                                  \
+            P16_ROTATE()                                                                           \
+        }                                                                                          \
+    }
+
+    f32x4 sa[2][2], sb[2][2];
+    vec8 pa[2], pb[2];
+    vec8 pre[NPRE];
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+        sa[0][qh] = zero4; sa[1][qh] = zero4; sb[0][qh] = zero4; sb[1][qh] = zero4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pa[qh][j] = (T)0.f; pb[qh][j] = (T)0.f; }
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) asm volatile("" : "+v"(qf[qh][ds]));   // Q loads issued
+    }
+#pragma unroll
+    for (int t = 0; t < NPRE; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pre[t][j] = (T)0.f;
+
+    P16_RUN(false)
+    // optimistic pass: an overflowed P made a row sum inf / NaN for good - one check per pass, all waves must agree
+    bool bad = false;
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) bad |= wave_active && sum_left_safe_range(lsum[qh][0]);
+    flags[wave] = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
+    __syncthreads();
+    int any_bad = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) any_bad |= flags[w];
+    if (any_bad) {
+        __syncthreads();
+        P16_RESET()
+        P16_RUN(true)
+    }
+#undef P16_DMA_K
+#undef P16_DMA_V
+#undef P16_RESET
+#undef P16_KFRAG
+#undef P16_VFRAG
+#undef P16_QK
+#undef P16_PV
+#undef P16_MASK
+#undef P16_MAXR
+#undef P16_SM_PACK
+#undef P16_ISSUE
+#undef P16_PUBLISH
+#undef P16_PRE
+#undef P16_GENERIC
+#undef P16_ITEM_FMA
+#undef P16_ITEM_EXP
+#undef P16_ITEM_CVT
+#undef P16_OPND_LOAD
+#undef P16_FAST
+#undef P16_STEADY
+#undef P16_ROTATE
+#undef P16_RAGGED
+#undef P16_RUN
+
+    // ---- epilogue: O /= l through LDS (the K ring is free now), whole-row stores.  A lane holds, per d block, 4 consecutive
+    // d of ONE row: 8 bytes at byte 32 db + 8 g of that row; the 16-byte chunk index is XORed with the row so that the 16
+    // rows of a half land in different banks.
+    if (!wave_active) return;
+    unsigned char* slab = smem + wave * (32 * ROWB);
+    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+        const float lt = lsum[qh][0];
+        const float inv = __builtin_amdgcn_rcpf(lt);
+        const int rr = 16 * qh + n;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            vec4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][qh][j] * inv);
+            const int ch = 2 * db + (gq >> 1);
+            *(vec4*)(slab + rr * ROWB + ((ch ^ (rr & 15)) << 4) + 8 * (gq & 1)) = w;
+        }
+        if (p.lse != nullptr && gq == 0 && qrow[qh] < L) p.lse[(int64_t)g * L + qrow[qh]] = m[qh] * p.scale + __logf(lt);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {           // 4 rows x 16 chunks per instruction
+        const int rr = 4 * i + (lane >> 4), ch = lane & 15;
+        const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & 15)) << 4));
+        const int orow = q_row0 + rr;
+        if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void fa_fwd_pipe16_kernel(const FwdParams p) {
+    fa_fwd_pipe16_body<T>(p);
+}
+
+// callers guarantee: D = 128, causal, skip-max arithmetic wanted (bf16, or f16 with p.skipmax), p.nq_tiles = ceil(L / 128)
+hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, hipStream_t stream) {
+    const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
+    if (dtype == 1) return launch1((const void*)(fa_fwd_pipe16_kernel<__bf16>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    return launch1((const void*)(fa_fwd_pipe16_kernel<_Float16>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+}
+
+}  // namespace fa

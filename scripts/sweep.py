@@ -51,7 +51,7 @@ def setknobs(lib, rest):
         if kv:
             k, val = kv.split("=")
             name = {"K": "kernel", "W": "waves", "S": "sched", "Q": "qb"}[k]
-            want[name] = ord(val[0]) if name == "kernel" else int(val)
+            want[name] = (ord("x") if val in ("pipe16", "x") else ord(val[0])) if name == "kernel" else int(val)
     for name, val in want.items():
         assert lib.fa_debug_set_option(name.encode(), val) == 0, (name, val)
 

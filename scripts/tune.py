@@ -71,6 +71,9 @@ def candidates(G, L, D, skip, causal, scheds=True):
             continue
         for b in bunches:
             out.append({"kernel": kern, "qb": qb, "waves": w, "sched": b})
+    if D == 128 and skip and causal:      # the pipelined kernel on 16x16x32 MFMAs (one tile shape: 4 waves x 32 rows)
+        for b in bunches:
+            out.append({"kernel": "pipe16", "qb": 1, "waves": 4, "sched": b})
     return out, auto
 
 
@@ -134,7 +137,7 @@ def emit(args):
                 if same_tile_auto and med[same_tile_auto[0]] <= med[best] * 1.01:
                     best, sched = same_tile_auto[0], 0
                 c = cands[best]
-                rows.append((D, skip, causal, L_lo, L_hi, wg, c["kernel"][0], c["waves"], c["qb"], sched, L, G,
+                rows.append((D, skip, causal, L_lo, L_hi, wg, {"dma": "d", "pipe": "p", "pipe16": "x"}[c["kernel"]], c["waves"], c["qb"], sched, L, G,
                              shape.flops / med[best] / 1e9))
                 log.append(f"D={D} skip={skip} causal={causal} L={L} G={G} wg128={wg}: {c} sched->{sched}  "
                            f"{shape.flops / med[best] / 1e9:.0f} TFLOP/s (runner-up {sorted(med.values())[1] / med[best]:.3f}x time)")

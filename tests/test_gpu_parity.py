@@ -135,6 +135,51 @@ def test_pipelined_kernel_8_wave_workgroups_head_dim_128(knobs, G, L):
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 128 ** -0.5), (torch.float16, 128 ** -0.5)])
+@pytest.mark.parametrize("G,L", [(2, 32), (3, 100), (2, 257), (2, 1000), (1, 4608), (9, 600)])
+def test_pipelined_kernel_on_16x16x32_mfma_head_dim_128(knobs, dtype, scale, G, L):
+    """fa_fwd_pipe16_kernel (the pipelined kernel rebuilt on v_mfma_f32_16x16x32, head_dim 128): out and logsumexp
+    against the oracle for ragged / short / long sequences - every path of its step machinery (generic first step
+    only, left-over steps, groups of four, diagonal step, drain) - in bf16 and 1/sqrt(D)-scaled f16."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    knobs.set("kernel", "pipe16")
+    p = native.plan(G, L, 128, dtype, 1, 1, softmax_scale=scale)
+    assert (p.kernel, p.waves, p.block_q, p.block_kv) == (4, 4, 128, 32)
+    x = frozen_randn(SEED + 13 * L + G, (3, G, L, 128)).to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale)
+    q, k, v = x.cuda()
+    out = torch.empty_like(q)
+    lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+    st = (L * 128, 0, 128)
+    native.fwd_strided(q, k, v, out, lse, G, L, 128, 1, st, st, st, st, 1, 1, scale)
+    _check(out, ref, dtype, f"pipe16 {dtype} scale={scale:.3g} {G}x{L}x128")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
+def test_pipe16_growing_logits_force_the_exact_pass(knobs, step):
+    """The optimistic pass of fa_fwd_pipe16_kernel must detect a P that left the safe range (inf / NaN row sum) and
+    redo the workgroup through its exact pass (cdna guide rule 26: force the rare branch)."""
+    _, native, with_lse = _mods()
+    from oracle import frozen_randn
+
+    knobs.set("kernel", "pipe16")
+    G, L, D = 2, 1024, 128
+    x = frozen_randn(SEED + 56, (3, G, L, D)) * 0.05
+    u = torch.zeros(D)
+    u[:4] = 1.0
+    tile = torch.arange(L) // 64
+    x[0] += u
+    x[1] += u[None, None, :] * (step / 4.0) * tile[None, :, None]
+    x = x.to(torch.bfloat16)
+    ref, ref_lse = _oracle(x)
+    out, lse = with_lse(x.cuda(), 1, 1)
+    _check(out, ref, torch.bfloat16, f"pipe16 growing logits step={step}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
+
+
 @pytest.mark.parametrize("nq,nk", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 3), (3, 2), (3, 3)])
 def test_tiny_fp32_all_chunk_pairs(golden_dir, nq, nk):
     """t_cpp:245-251: fp32 G=4 L=6 D=2, every chunk pair; golden G3 from the reference CPU path."""

@@ -133,7 +133,7 @@ def test_measured_tuning_table_is_consulted_and_bounded_by_the_chunks(native):
             continue
         dt = torch.bfloat16 if skip == "1" else torch.float16
         p = native.plan(G, L, D, dt, 1, 1, causal=causal == "1")
-        assert p.source == 1 and (p.kernel, p.waves, p.qb) == (2 if kern == "p" else 0, waves, qb), (D, skip, causal, L, G)
+        assert p.source == 1 and (p.kernel, p.waves, p.qb) == ({"p": 2, "x": 4, "d": 0}[kern], waves, qb), (D, skip, causal, L, G)
         with native.debug_options(table=0):
             assert native.plan(G, L, D, dt, 1, 1, causal=causal == "1").source == 0
         checked += 1
