@@ -310,7 +310,7 @@ def main():
     if rehearse:
         local_rank = 0
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no fallback)")
+        raise SystemExit(f"bench.py needs a GPU (the HIP path has no fallback) [rank {rank} of {world}]")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

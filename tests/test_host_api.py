@@ -108,7 +108,7 @@ def test_debug_options_are_explicit_and_not_read_from_the_environment_per_call(n
     assert lib.fa_debug_get_option(b"kernel", ctypes.byref(val)) == 0 and val.value == 0
     assert lib.fa_debug_set_option(b"no_such_knob", 1) == -12
     assert lib.fa_debug_set_option(b"waves", 3) == -12
-    assert lib.fa_debug_set_option(b"kernel", ord("x")) == -12
+    assert lib.fa_debug_set_option(b"kernel", ord("z")) == -12
 
 
 def test_measured_tuning_table_is_consulted_and_bounded_by_the_chunks(native):
