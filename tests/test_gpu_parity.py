@@ -418,7 +418,7 @@ def test_long_context_config3_full_groups_vs_oracle_rows():
 
     G, L, D = 16, 32768, 128
     plan = native.plan(G, L, D, torch.bfloat16, 16, 16)
-    assert plan.kernel in (0, 2) and plan.block_q in (128, 256)              # an MFMA kernel (rules: 8-wave 64-key tiles)
+    assert plan.kernel in (0, 2, 4) and plan.block_q in (128, 256)           # an MFMA kernel (rules: 8-wave 64-key tiles)
     gen = torch.Generator(device="cuda").manual_seed(3)
     qkv = torch.randn(3, G, L, D, device="cuda", generator=gen).to(torch.bfloat16)
     out, lse = with_lse(qkv, 16, 16)
