@@ -122,6 +122,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
         dsum = half_swap_sum(acc);
         if (h == 0 && qrow < L) p.dsum[(int64_t)g * L + qrow] = dsum;
     }
+    const float ndsum = -dsum;
     const float c = p.scale_log2;
 
     // LDS-DMA geometry (pieces pc = wave + j*NWAVES of each image)
@@ -179,7 +180,8 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             const unsigned char* kb_ = smem + (BUF_) * IMG_B;                                      \
             const unsigned char* vb_ = smem_v + (BUF_) * IMG_B;                                    \
             f32x16 s0, s1, t0, t1;                                                                 \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; t0[e] = 0.f; t1[e] = 0.f; } \
+            /* the accumulators of dP^T start at -Dsum: the MFMA chain delivers dP^T - Dsum (no v_sub per element) */ \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; t0[e] = ndsum; t1[e] = ndsum; } \
             _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                    \
                 s0 = E::mfma(*(const vec8*)(kb_ + a_rd[ks]), qf[ks], s0);                          \
                 s1 = E::mfma(*(const vec8*)(kb_ + 2048 + a_rd[ks]), qf[ks], s1);                   \
@@ -195,8 +197,8 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             }                                                                                      \
             /* dS^T = P^T o (dP^T - Dsum), P^T = 2^(S^T c - lse2): the row constants are lane scalars */ \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                       \
-                s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -lse2)) * (t0[e] - dsum);               \
-                s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -lse2)) * (t1[e] - dsum);               \
+                s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -lse2)) * t0[e];                        \
+                s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -lse2)) * t1[e];                        \
             }                                                                                      \
             vec8 dsf[4];                                                                           \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
@@ -329,7 +331,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         }                                                                                          \
     }
     const unsigned smem_lds = lds_offset(smem);
-    // row constants of q tile I_: threads 0..63 fetch lse*log2e, 64..127 fetch Dsum; rows past L get
+    // row constants of q tile I_: threads 0..63 fetch lse*log2e, 64..127 fetch -Dsum; rows past L get
     // lse2 = +inf (P = 0) and Dsum = 0
     const float* __restrict__ lse_g = p.lse + (int64_t)g * L;
     const float* __restrict__ dsum_g = p.dsum + (int64_t)g * L;
@@ -338,7 +340,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         const int rr_ = (I_) * BQ + (tid & 63);                                                    \
         rc_stage = (tid < 64) ? INFINITY : 0.f;                                                    \
         if (tid < 64 && rr_ < L) rc_stage = lse_g[rr_] * LOG2E;                                    \
-        if (tid >= 64 && tid < 128 && rr_ < L) rc_stage = dsum_g[rr_];                             \
+        if (tid >= 64 && tid < 128 && rr_ < L) rc_stage = -dsum_g[rr_];   /* negated: see the dP accumulators */ \
     }
 #define FA_ROWC_STORE(BUF_) \
     if (tid < 128) rowc[(BUF_) * 128 + tid] = rc_stage;
@@ -371,7 +373,16 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
             const float* rc_ = rowc + (BUF_) * 128;                                                \
             f32x16 s0, s1, t0, t1;                                                                 \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; t0[e] = 0.f; t1[e] = 0.f; } \
+            /* the accumulators of dP start at -Dsum[q] (rowc holds the negated sums; the row constants vary along the \
+               registers): the MFMA chain delivers dP - Dsum, no v_sub per element */              \
+            _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                     \
+                const f32x4 da = *(const f32x4*)(rc_ + 64 + 8 * gq + 4 * h);                       \
+                const f32x4 db = *(const f32x4*)(rc_ + 96 + 8 * gq + 4 * h);                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
+                    s0[4 * gq + j] = 0.f; s1[4 * gq + j] = 0.f;                                    \
+                    t0[4 * gq + j] = da[j]; t1[4 * gq + j] = db[j];                                \
+                }                                                                                  \
+            }                                                                                      \
             /* S = Q K^T and dP = dO V^T, key on the lane, query rows in the registers */          \
             _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                    \
                 s0 = E::mfma(*(const vec8*)(qb_ + a_rd[ks]), kf[ks], s0);                          \
@@ -390,14 +401,12 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                     \
                 const f32x4 la = *(const f32x4*)(rc_ + 8 * gq + 4 * h);                            \
                 const f32x4 lb = *(const f32x4*)(rc_ + 32 + 8 * gq + 4 * h);                       \
-                const f32x4 da = *(const f32x4*)(rc_ + 64 + 8 * gq + 4 * h);                       \
-                const f32x4 db = *(const f32x4*)(rc_ + 96 + 8 * gq + 4 * h);                       \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
                     const int e = 4 * gq + j;                                                      \
                     s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -la[j]));                           \
                     s1[e] = fast_exp2(__builtin_fmaf(s1[e], c, -lb[j]));                           \
-                    t0[e] = s0[e] * (t0[e] - da[j]);                                               \
-                    t1[e] = s1[e] * (t1[e] - db[j]);                                               \
+                    t0[e] = s0[e] * t0[e];                                                         \
+                    t1[e] = s1[e] * t1[e];                                                         \
                 }                                                                                  \
             }                                                                                      \
             vec8 pf[4], dsf[4];                                                                    \

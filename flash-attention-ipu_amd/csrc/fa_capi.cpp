@@ -151,7 +151,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
         if (fk == 't') { which = 't'; qb = 1; }
         else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
-        else if (fk == 'x' && pipe_ok && D == 128) { which = 'x'; waves = 4; qb = 1; }
+        else if (fk == 'x' && pipe_ok && D == 128) { which = 'x'; waves = fw == 8 ? 8 : 4; qb = 1; }
         else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
         if (fq == 1) qb = 1;
         if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
@@ -159,7 +159,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (want32 && pipe_ok && which == 'd' && fk == 0) { which = 'p'; if (waves > 4 && D != 128) waves = 4; }
         if (which == 'p' && ((waves > 4 && D != 128) || !pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
         if (which == 'x' && !(pipe_ok && D == 128)) which = 'd';
-        if (which == 'x') { waves = 4; qb = 1; }
+        if (which == 'x') { waves = waves == 8 ? 8 : 4; qb = 1; }
         if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
         if (which == 't' && waves > 4) waves = 4;
         plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : 0;
@@ -366,7 +366,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     hipError_t e = sel.which == 'g'   ? fa::launch_fwd_generic(p, dtype, st)
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
-                   : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, st)
+                   : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, st)
                    : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves, plan.qb, st)
                                       : fa::launch_fwd_tile(p, dtype, plan.waves, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

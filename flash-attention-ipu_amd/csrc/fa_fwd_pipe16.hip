@@ -32,18 +32,22 @@
 #ifndef FA_P16_PF
 #define FA_P16_PF 8          // hand-scheduled step: LDS operands are requested this many operands ahead
 #endif
+// timing-only ablations (wrong results): -DFA_P16_ABL=1 no per-step barrier, 2 no per-step DMA
+#ifndef FA_P16_ABL
+#define FA_P16_ABL 0
+#endif
 #ifndef FA_P16_NPRE
 #define FA_P16_NPRE 8        // V^T fragments of the next step requested mid-step and held across the step barrier
 #endif
 
 namespace fa {
 
-template <typename T>
+template <typename T, int NWAVES>
 __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
-    constexpr int D = 128, NWAVES = 4, BQ = NWAVES * 32, HK = 32, ROWB = D * 2;
+    constexpr int D = 128, BQ = NWAVES * 32, HK = 32, ROWB = D * 2;
     constexpr int SLOT_B = HK * ROWB;           // 8 KiB K slot = V slot
     constexpr int PIECES = SLOT_B / 1024, PPW = PIECES / NWAVES;
     constexpr int NDS = D / 32;                 // 32-wide d slices of the QK^T contraction
@@ -217,12 +221,12 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     // every step: issue the DMA for K(i+3), V(i+2); compute; publish (everything issued before this step has landed)
 #define P16_ISSUE(I_, KSLOT_, VSLOT_)                                                              \
         const bool dk_ = (I_) + NS - 1 < nh_wg, dv_ = (I_) + NS - 2 < nh_wg;                       \
-        if (dk_) P16_DMA_K((I_) + NS - 1, KSLOT_)                                                  \
-        if (dv_) P16_DMA_V((I_) + NS - 2, VSLOT_)
+        if (dk_ && FA_P16_ABL != 2) P16_DMA_K((I_) + NS - 1, KSLOT_)                               \
+        if (dv_ && FA_P16_ABL != 2) P16_DMA_V((I_) + NS - 2, VSLOT_)
 #define P16_PUBLISH()                                                                              \
         if (dk_ && dv_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NS - 3)) : "memory");  \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
-        __syncthreads();
+        if (FA_P16_ABL != 1) __syncthreads();
 #define P16_PRE(VB_)                                                                               \
         fa_static_for<0, NPRE>([&](auto ti_) { constexpr int t2_ = decltype(ti_)::value; P16_VFRAG(pre[t2_], t2_, VB_) });
 #define P16_GENERIC(I_, SC_, SN_, PP_, PC_, SAFE_)                                                 \
@@ -455,16 +459,21 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void fa_fwd_pipe16_kernel(const FwdParams p) {
-    fa_fwd_pipe16_body<T>(p);
+template <typename T, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_pipe16_kernel(const FwdParams p) {
+    fa_fwd_pipe16_body<T, NWAVES>(p);
 }
 
-// callers guarantee: D = 128, causal, skip-max arithmetic wanted (bf16, or f16 with p.skipmax), p.nq_tiles = ceil(L / 128)
-hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, hipStream_t stream) {
-    const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
-    if (dtype == 1) return launch1((const void*)(fa_fwd_pipe16_kernel<__bf16>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    return launch1((const void*)(fa_fwd_pipe16_kernel<_Float16>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+// callers guarantee: D = 128, causal, skip-max arithmetic wanted (bf16, or f16 with p.skipmax), waves in {4, 8},
+// p.nq_tiles = ceil(L / (32 waves))
+hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
+    const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles));
+    if (waves == 8) {   // 256-row workgroups: half the K/V LDS-DMA pieces per wave and step, half the L2 -> LDS traffic per FLOP
+        if (dtype == 1) return launch1((const void*)(fa_fwd_pipe16_kernel<__bf16, 8>), grid, dim3(512), 0, stream, p);
+        return launch1((const void*)(fa_fwd_pipe16_kernel<_Float16, 8>), grid, dim3(512), 0, stream, p);
+    }
+    if (dtype == 1) return launch1((const void*)(fa_fwd_pipe16_kernel<__bf16, 4>), grid, dim3(256), 0, stream, p);
+    return launch1((const void*)(fa_fwd_pipe16_kernel<_Float16, 4>), grid, dim3(256), 0, stream, p);
 }
 
 }  // namespace fa

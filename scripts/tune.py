@@ -72,8 +72,9 @@ def candidates(G, L, D, skip, causal, scheds=True):
         for b in bunches:
             out.append({"kernel": kern, "qb": qb, "waves": w, "sched": b})
     if D == 128 and skip and causal:      # the pipelined kernel on 16x16x32 MFMAs (one tile shape: 4 waves x 32 rows)
-        for b in bunches:
-            out.append({"kernel": "pipe16", "qb": 1, "waves": 4, "sched": b})
+        for w in (4, 8):
+            for b in bunches:
+                out.append({"kernel": "pipe16", "qb": 1, "waves": w, "sched": b})
     return out, auto
 
 

@@ -135,9 +135,10 @@ def test_pipelined_kernel_8_wave_workgroups_head_dim_128(knobs, G, L):
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 128 ** -0.5), (torch.float16, 128 ** -0.5)])
 @pytest.mark.parametrize("G,L", [(2, 32), (3, 100), (2, 257), (2, 1000), (1, 4608), (9, 600)])
-def test_pipelined_kernel_on_16x16x32_mfma_head_dim_128(knobs, dtype, scale, G, L):
+def test_pipelined_kernel_on_16x16x32_mfma_head_dim_128(knobs, dtype, scale, G, L, waves):
     """fa_fwd_pipe16_kernel (the pipelined kernel rebuilt on v_mfma_f32_16x16x32, head_dim 128): out and logsumexp
     against the oracle for ragged / short / long sequences - every path of its step machinery (generic first step
     only, left-over steps, groups of four, diagonal step, drain) - in bf16 and 1/sqrt(D)-scaled f16."""
@@ -145,8 +146,9 @@ def test_pipelined_kernel_on_16x16x32_mfma_head_dim_128(knobs, dtype, scale, G, 
     from oracle import frozen_randn
 
     knobs.set("kernel", "pipe16")
+    knobs.set("waves", waves)
     p = native.plan(G, L, 128, dtype, 1, 1, softmax_scale=scale)
-    assert (p.kernel, p.waves, p.block_q, p.block_kv) == (4, 4, 128, 32)
+    assert (p.kernel, p.waves, p.block_q, p.block_kv) == (4, waves, 32 * waves, 32)
     x = frozen_randn(SEED + 13 * L + G, (3, G, L, 128)).to(dtype)
     ref, ref_lse = _oracle(x, scale=scale)
     q, k, v = x.cuda()
