@@ -54,6 +54,8 @@ def fuzz(cases, seed, log=print):
       for kern in ("dma", "pipe"):
           for qb in (1, 2):
               variants.append({"kernel": kern, "qb": qb, "waves": rng.choice([1, 2, 4, 4, 8]), "sched": rng.choice([1, 2, 8])})
+      if D == 128:      # the pipelined kernel on 16x16x32 MFMAs (head_dim 128 only), 4- and 8-wave workgroups
+          variants.append({"kernel": "pipe16", "waves": rng.choice([4, 8]), "sched": rng.choice([1, 2, 8])})
       ulp = 2.0 ** -6 if dt == torch.bfloat16 else 2.0 ** -9
       ref = None
       if L <= 700:
@@ -65,8 +67,11 @@ def fuzz(cases, seed, log=print):
           # output error scales with |V| (P carries 8 / 11 bits); with FUZZ_AMP > 1 the softmax is nearly one-hot and
           # 16-bit P underflow shows as a few more ulps in every kernel: twice the slack there
           vs = max(1.0, amp) * (2.0 if amp > 1.0 else 1.0)
+          # (the MFMA kernels normalise by the sum of the 16-bit-rounded P - the weights the PV product uses -, the
+          # register-staged baseline by the exact sum, and P is rounded relative to different reference maxima: two
+          # correct kernels sit up to 2^-8 (bf16) of |V| apart per dominant key, each within the oracle tolerance)
           tol = vs * 1e-2 * (1 if dt == torch.bfloat16 else 0.1) + ulp * (2.0 if amp > 1.0 else 1.0) * base.float().abs()
-          ok = bool(torch.isfinite(out).all()) and bool((d <= tol).all()) and bool(((lse - base_lse).abs() <= 2e-3 + 1e-4 * base_lse.abs()).all())
+          ok = bool(torch.isfinite(out).all()) and bool((d <= tol).all()) and bool(((lse - base_lse).abs() <= (6e-3 if dt == torch.bfloat16 else 2e-3) + 1e-4 * base_lse.abs()).all())   # (bf16: |dLSE| <= 2^-8, see above)
           if ref is not None:
               e = (out.reshape(B * H, L, D).cpu().double() - ref).abs()
               ok = ok and bool((e <= max(1.0, amp) * 1e-2 + 1e-2 * ref.abs()).all())
