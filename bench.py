@@ -387,13 +387,29 @@ def main():
     step(0)                      # first call pays one-off host costs (library load, op registration)
     drain()
     torch.cuda.synchronize()
-    t_ramp = time.perf_counter()
-    i_ramp = 0
-    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:   # untimed: bring the chip to its sustained clock
-        step(i_ramp)
-        i_ramp += 1
-        if i_ramp % 16 == 0:
-            torch.cuda.synchronize()
+    # untimed ramp: bring the chip to its sustained clock.  Every rank must issue the SAME number of steps (each step
+    # carries a collective), so with N > 1 the count is agreed first: 3 steps are timed, the slowest rank's time decides.
+    if world > 1:
+        t_est = time.perf_counter()
+        for i in range(3):
+            step(i)
+        drain()
+        torch.cuda.synchronize()
+        est = torch.tensor([(time.perf_counter() - t_est) / 3 * 1e3], dtype=torch.float64, device="cpu" if use_gloo else dev)
+        dist.all_reduce(est, op=dist.ReduceOp.MAX)
+        n_ramp = int(min(2000, max(1, args.ramp_ms / max(est.item(), 1e-3))))
+        for i in range(n_ramp):
+            step(i)
+            if (i + 1) % 16 == 0:
+                torch.cuda.synchronize()
+    else:
+        t_ramp = time.perf_counter()
+        i_ramp = 0
+        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            step(i_ramp)
+            i_ramp += 1
+            if i_ramp % 16 == 0:
+                torch.cuda.synchronize()
     drain()
     torch.cuda.synchronize()
     for i in range(args.warmup):
