@@ -5,6 +5,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd")]
 import torch
 import flash_attention_amd as fa
+from flash_attention_amd._impl import _native
 from oracle import dense_causal_attention_lse, frozen_randn
 
 def run(tag, qkv, nq=1, nk=1):
@@ -15,11 +16,11 @@ def run(tag, qkv, nq=1, nk=1):
     rows_bad = bad.any(-1).nonzero()
     print(f"{tag:40s} max|d|={err.max().item():.3e} bad={int(bad.sum())}/{bad.numel()} first_bad_rows={rows_bad[:6].tolist()}", flush=True)
 
-for kern in os.environ.get("DEBUG_KERNELS", "tile").split(","):
-    os.environ["FA_AMD_KERNEL"] = kern
+for kern in os.environ.get("DEBUG_KERNELS", "tile").split(","):      # dma | pipe | pipe16 | tile
     for dt in (torch.bfloat16, torch.float16):
         for waves in ("1", "2", "4", "8"):
-            os.environ["FA_AMD_WAVES"] = waves
+            _native.set_debug_option("kernel", kern)      # (knobs are process options now, not per-call environment reads)
+            _native.set_debug_option("waves", int(waves))
             for (G, L, D) in [(1, 32, 64), (1, 64, 64), (1, 128, 64), (2, 320, 64), (3, 1000, 64), (1, 128, 128), (2, 320, 128), (2, 777, 128)]:
                 x = frozen_randn(7 + L + D, (3, G, L, D)).to(dt)
                 run(f"{kern} {dt} w={waves} randn {G}x{L}x{D}", x)
