@@ -344,7 +344,7 @@ def main():
     record = [False]
 
     if strong:
-        sg = SlabGather(G, L, D, dtype, dev if not use_gloo else dev, slabs=args.slabs, mode=args.gather, gather=do_gather and not use_gloo)
+        sg = SlabGather(G, L, D, dtype, dev, slabs=args.slabs, mode=args.gather, gather=do_gather and not use_gloo)
 
         def step(i):
             if record[0]:

@@ -132,22 +132,37 @@ def set_debug_option(name: str, value) -> None:
         _raise(rc)
 
 
+def get_debug_option(name: str) -> int:
+    lib = load_native_library()
+    val = ctypes.c_int32(0)
+    rc = lib.fa_debug_get_option(name.encode(), ctypes.byref(val))
+    if rc != 0:
+        _raise(rc)
+    return val.value
+
+
 class debug_options:
-    """Context manager for tests and tuning tools: force knobs of the tile plan, restore "auto" on exit.
+    """Context manager for tests and tuning tools: force knobs of the tile plan; on exit every knob is back at the value
+    it had on entry (contexts nest).  Knobs not named keep their current value.
 
         with _native.debug_options(kernel="pipe", qb=2, waves=4): ...
     """
 
     def __init__(self, **knobs):
+        unknown = set(knobs) - set(_OPTION_AUTO)
+        if unknown:
+            raise ValueError(f"unknown debug option(s) {sorted(unknown)}; known: {sorted(_OPTION_AUTO)}")
         self.knobs = {k: v for k, v in knobs.items() if v is not None}
+        self.saved = {}
 
     def __enter__(self):
-        for k in _OPTION_AUTO:
-            set_debug_option(k, self.knobs.get(k, _OPTION_AUTO[k]))
+        self.saved = {k: get_debug_option(k) for k in self.knobs}
+        for k, v in self.knobs.items():
+            set_debug_option(k, v)
         return self
 
     def __exit__(self, *exc):
-        for k, v in _OPTION_AUTO.items():
+        for k, v in self.saved.items():
             set_debug_option(k, v)
         return False
 
