@@ -171,12 +171,44 @@ def _strides3(arr):
     return (ctypes.c_int64 * 3)(*arr)
 
 
+_I64x3 = ctypes.c_int64 * 3
+_I64x24 = ctypes.c_int64 * 24
+_P_I64x3 = ctypes.POINTER(ctypes.c_int64 * 3)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+class _on_device_of:
+    """`with _on_device_of(t) as stream:` - the raw HIP stream PyTorch is enqueueing on for t's device, switching the
+    current device only when it is not t's (the common single-device case costs two C calls, not a context manager
+    and a Stream object: the Python side of a launch is ~10 us, which matters for small attention calls)."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t: torch.Tensor):
+        self.idx = t.device.index
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if self.idx is not None and cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+        idx = cur if self.idx is None else self.idx
+        if _raw_stream is not None:
+            return _raw_stream(idx)
+        return torch.cuda.current_stream(idx).cuda_stream
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def fwd_packed(qkv: torch.Tensor, out: torch.Tensor, lse, num_chunks_q: int, num_chunks_kv: int):
     """qkv: contiguous CUDA [3,G,L,D]; out: contiguous [G,L,D]; lse: None or fp32 [G,L]."""
     lib = load_native_library()
     _, G, L, D = qkv.shape
-    with torch.cuda.device(qkv.device):
-        stream = torch.cuda.current_stream().cuda_stream
+    with _on_device_of(qkv) as stream:
         rc = lib.fa_fwd_qkv_packed(qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
                                    G, L, D, num_chunks_q, num_chunks_kv, FA_DTYPE[qkv.dtype], stream)
     if rc != 0:
@@ -187,8 +219,7 @@ def fwd_strided(q, k, v, out, lse, G, L, D, heads, qs, ks, vs, os_, num_chunks_q
                 causal: bool = True, heads_kv=None):
     """Strided three-view forward: see fa_fwd in include/flash_attention_amd.h."""
     lib = load_native_library()
-    with torch.cuda.device(q.device):
-        stream = torch.cuda.current_stream().cuda_stream
+    with _on_device_of(q) as stream:
         rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                         lse.data_ptr() if lse is not None else None, G, L, D, heads,
                         heads if heads_kv is None else heads_kv,
@@ -208,16 +239,15 @@ def group_strides(t: torch.Tensor, heads: int):
 def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale, causal: bool = True):
     """Backward through the C ABI (fa_bwd).  Tensors are [G,L,D] or [B,H,L,D] views with unit inner stride."""
     lib = load_native_library()
-    tensors = (q, k, v, out, dout, dq, dk, dv)
-    arr = ((ctypes.c_int64 * 3) * 8)()
-    for i, t in enumerate(tensors):
-        for j, sv in enumerate(group_strides(t, heads)):
-            arr[i][j] = sv
+    if q.ndim == 3:
+        flat = [x for t in (q, k, v, out, dout, dq, dk, dv) for x in (t.stride(0), 0, t.stride(1))]
+    else:
+        flat = [x for t in (q, k, v, out, dout, dq, dk, dv) for x in (t.stride(0), t.stride(1), t.stride(2))]
+    arr = _I64x24(*flat)        # laid out exactly as int64_t[8][3]
     dsum = torch.empty((G, L), dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
-        stream = torch.cuda.current_stream().cuda_stream
+    with _on_device_of(q) as stream:
         rc = lib.fa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                        dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(), G, L, D, heads, arr,
-                        FA_DTYPE[q.dtype], float(scale), int(bool(causal)), stream)
+                        dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(), G, L, D, heads,
+                        ctypes.cast(arr, _P_I64x3), FA_DTYPE[q.dtype], float(scale), int(bool(causal)), stream)
     if rc != 0:
         _raise(rc)

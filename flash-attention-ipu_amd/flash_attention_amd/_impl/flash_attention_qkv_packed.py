@@ -40,8 +40,8 @@ def flash_attention_qkv_packed(qkv: torch.Tensor, num_chunks_q: int, num_chunks_
     if qkv.is_cuda:
         if qkv.dtype not in _native.FA_DTYPE:
             raise TypeError(f"flash_attention_qkv_packed: unsupported dtype {qkv.dtype} on GPU")
-        # one opaque custom op (HIP forward; HIP backward through its registered autograd formula)
-        return ops.fwd_qkv_packed(qkv, int(num_chunks_q), int(num_chunks_kv))[0]
+        # HIP forward; HIP backward through autograd (an opaque torch.library custom op under torch.compile)
+        return ops.attention_qkv_packed(qkv, int(num_chunks_q), int(num_chunks_kv))
 
     # CPU tensors: the op's CPU branch (fa.py:47-53) - dense attention with an additive -10000 mask.
     q, k, v = qkv

@@ -84,13 +84,13 @@ def _scaled_dot_product_attention_amd(
         if not needs_grad and query.ndim == 4 and query.numel() > 0:
             # inference on [B, H, L, D] views (e.g. slices of a fused [B, T, 3C] projection): no copies at all;
             # grouped-query K/V heads are resolved inside the kernel
-            return ops.fwd_bhld(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+            return ops.attention_bhld(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal)
         if gqa:   # training with grouped K/V heads: expand them (autograd sums the head gradients back)
             rep = query.shape[1] // key.shape[1]
             key = key.repeat_interleave(rep, dim=1)
             value = value.repeat_interleave(rep, dim=1)
-        out, _ = ops.fwd(query.reshape(-1, L, D), key.reshape(-1, L, D), value.reshape(-1, L, D),
-                         softmax_scale, num_chunks_q, num_chunks_kv, causal)
+        out = ops.attention(query.reshape(-1, L, D), key.reshape(-1, L, D), value.reshape(-1, L, D),
+                            softmax_scale, num_chunks_q, num_chunks_kv, causal)
         return out.view(*batch_shape, L, D)
 
     return orig_fn(query, key, value, attn_mask, dropout_p, is_causal, **extra)

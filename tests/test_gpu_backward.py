@@ -176,3 +176,29 @@ def test_fp32_mfma_backward(knobs, G, L, D, causal):
         assert torch.isfinite(a).all(), name
         assert (a.cpu().double() - want).abs().max().item() <= bound, (name, (a.cpu().double() - want).abs().max().item(), bound)
         assert (a - b).abs().max().item() <= 2 * bound, (name, "vs generic kernels")
+
+
+def test_eager_fast_path_and_custom_ops_agree_bitwise():
+    """Eager calls run plain autograd.Functions, torch.compile traces the torch.library custom ops; both call the same
+    implementations, so outputs and gradients must be identical bit for bit (packed op and three-operand op)."""
+    from flash_attention_amd._impl import ops
+    from oracle import frozen_randn
+
+    qkv = (frozen_randn(SEED + 90, (3, 3, 300, 64)) * 0.5).to(torch.bfloat16).cuda()
+    dout = frozen_randn(SEED + 91, (3, 300, 64)).to(torch.bfloat16).cuda()
+
+    def grads(fn):
+        x = qkv.clone().requires_grad_(True)
+        out = fn(x)
+        out.backward(dout)
+        return out.detach(), x.grad
+
+    o1, g1 = grads(lambda x: ops.attention_qkv_packed(x, 1, 1))
+    o2, g2 = grads(lambda x: ops.fwd_qkv_packed(x, 1, 1)[0])
+    assert torch.equal(o1, o2) and torch.equal(g1, g2)
+    for causal in (True, False):
+        o3, g3 = grads(lambda x: ops.attention(x[0], x[1], x[2], 0.125, 1, 1, causal))
+        o4, g4 = grads(lambda x: ops.fwd(x[0], x[1], x[2], 0.125, 1, 1, causal)[0])
+        assert torch.equal(o3, o4) and torch.equal(g3, g4)
+    q4 = qkv[0].view(1, 3, 300, 64)
+    assert torch.equal(ops.attention_bhld(q4, q4, q4, 0.125, 1, 1, True), ops.fwd_bhld(q4, q4, q4, 0.125, 1, 1, True))
