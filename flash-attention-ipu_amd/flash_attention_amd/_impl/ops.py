@@ -93,10 +93,13 @@ def _fwd_impl(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal):
     return out, lse
 
 
-def _bwd_impl(q, k, v, out, dout, lse, softmax_scale, causal):
+def _bwd_impl(q, k, v, out, dout, lse, softmax_scale, causal, one_buffer=False):
     q, k, v, out, dout = (_rows(t) for t in (q, k, v, out, dout))
     G, L, D = q.shape
-    dq, dk, dv = torch.empty((3, G, L, D), dtype=q.dtype, device=q.device).unbind(0)   # one allocation, three views
+    if one_buffer:   # eager path: one allocation, three views (a custom op's returns must not share storage)
+        dq, dk, dv = torch.empty((3, G, L, D), dtype=q.dtype, device=q.device).unbind(0)
+    else:
+        dq, dk, dv = (torch.empty((G, L, D), dtype=q.dtype, device=q.device) for _ in range(3))
     if dq.numel() > 0:
         _native.bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, 1, softmax_scale, causal)
     return dq, dk, dv
@@ -192,7 +195,7 @@ class _AttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = _bwd_impl(q, k, v, out, dout, lse, ctx.softmax_scale, ctx.causal)
+        dq, dk, dv = _bwd_impl(q, k, v, out, dout, lse, ctx.softmax_scale, ctx.causal, one_buffer=True)
         return dq, dk, dv, None, None, None, None
 
 
