@@ -90,7 +90,7 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 
 // The ONE selection function behind fa_plan() and fa_fwd().
 //   'd' fa_fwd_dma_kernel   64-key tiles, LDS-DMA staged (fa_fwd_dma.hip)
-//   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic, causal only
+//   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic only
 //   'x' fa_fwd_pipe16_kernel the pipelined kernel on v_mfma_f32_16x16x32 (fa_fwd_pipe16.hip): head_dim 128, 4 waves, qb 1
 //   't' fa_fwd_tile_kernel  register-staged A/B baseline (debug override only)
 // qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
@@ -125,7 +125,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         const int64_t cq = plan->chunk_q < L ? plan->chunk_q : L;
         const int64_t ck = plan->chunk_kv < L ? plan->chunk_kv : L;
         const int wmax = waves_for_chunk(cq);            // the q chunk bounds the workgroup's rows
-        const bool pipe_ok = skip && causal;              // (the pipelined kernel: skip-max arithmetic, causal order)
+        const bool pipe_ok = skip != 0;                   // (the pipelined kernels implement the skip-max arithmetic only)
         const bool want32 = ck < 64;                      // a kv chunk below 64 keys is served by 32-key steps
         char which = 'd';
         int waves = wmax, qb = 1, sched = 0, source = 0;

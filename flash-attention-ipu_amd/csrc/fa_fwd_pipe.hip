@@ -65,7 +65,7 @@
 
 namespace fa {
 
-template <typename T, int D, int NWAVES, int QB>
+template <typename T, int D, int NWAVES, int QB, bool CAUSAL>
 __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -174,11 +174,17 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     }
     const int v_rd = (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
-    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    // CAUSAL = false (no mask): every wave computes every step, and only keys past L are masked - the same step
+    // machinery with FA_KLIM (the last key a row may see) = L - 1 instead of the row index, no dead block in the last step.
+    // A template parameter, not a run-time flag: a run-time branch around the last step costs the causal kernel its
+    // register allocation (256 VGPRs + scratch instead of 222).
+    constexpr bool causal = CAUSAL;
+#define FA_KLIM(B_) (CAUSAL ? qrow + 32 * (B_) : L - 1)
+    const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
     const int nh_wg = (kv_end + HK - 1) / HK;                 // steps the workgroup streams
     // steps this wave computes: block b's diagonal step is q_row0/32 + b, so the last QB steps carry a mask
     // (a block whose rows all lie before a step's keys gets P = 0 there)
-    const int nh_w = wave_active ? q_row0 / HK + QB : 0;
+    const int nh_w = wave_active ? (causal ? q_row0 / HK + QB : nh_wg) : 0;
 
     f32x16 o[QB][DT];
     float m[QB], l[QB];
@@ -232,7 +238,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                           \
             const int key = (J_) * HK + (e & 3) + 8 * (e >> 2) + 4 * h;                            \
-            if (key > qrow + 32 * b) S_[b][e] = -INFINITY;                                         \
+            if (key > FA_KLIM(b)) S_[b][e] = -INFINITY;                                            \
         }                                                                                          \
     }
     // exact row max of the step; raise m (rescaling O and l) wherever it is exceeded.  (A fully masked block -
@@ -322,8 +328,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             constexpr int b_ = (V_) / 8, e_ = 2 * ((V_) % 8);                                      \
             if constexpr (FA_ITEM_MASKED(MASK_, b_)) {   /* key of element e: (e & 3) + 8 (e >> 2) + 4 h in the step */ \
                 const int key_ = key0_ + (e_ & 3) + 8 * (e_ >> 2);                                 \
-                if (key_ > qrow + 32 * b_) SC_[b_][e_] = -INFINITY;                                \
-                if (key_ + 1 > qrow + 32 * b_) SC_[b_][e_ + 1] = -INFINITY;                        \
+                if (key_ > FA_KLIM(b_)) SC_[b_][e_] = -INFINITY;                                   \
+                if (key_ + 1 > FA_KLIM(b_)) SC_[b_][e_ + 1] = -INFINITY;                           \
             }                                                                                      \
             if constexpr (!FA_ITEM_DEAD(MASK_, b_)) {                                              \
                 SC_[b_][e_] = __builtin_fmaf(SC_[b_][e_], c, -mc[b_]);                             \
@@ -502,7 +508,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 ++i;                                                                               \
             }                                                                                      \
             if (i < nh_w) {                                    /* the wave's last step */          \
-                FA_RAGGED(i, (QB == 2 ? 3 : 1), false)                                             \
+                if constexpr (CAUSAL) { FA_RAGGED(i, (QB == 2 ? 3 : 1), false) }   /* (block 0 lies wholly before this step's keys) */ \
+                else { FA_RAGGED(i, 1, false) }                                    /* unmasked attention: only keys past L are masked */ \
                 FA_ROTATE()                                                                        \
                 ++i;                                                                               \
             }                                                                                      \
@@ -557,6 +564,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         }
         FA_RUN(true)
     }
+#undef FA_KLIM
 #undef FA_ISSUE
 #undef FA_PUBLISH
 #undef FA_STEADY
@@ -618,31 +626,36 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 }
 
 // (two query blocks per wave: hold the register allocator to 2 waves per SIMD = 256 registers)
-template <typename T, int D, int NWAVES, int QB>
+template <typename T, int D, int NWAVES, int QB, bool CAUSAL>
 __global__ __launch_bounds__(NWAVES * 64, QB == 2 ? 2 : 1) void fa_fwd_pipe_kernel(const FwdParams p) {
-    fa_fwd_pipe_body<T, D, NWAVES, QB>(p);
+    fa_fwd_pipe_body<T, D, NWAVES, QB, CAUSAL>(p);
 }
 
-template <typename T, int D>
-static hipError_t launch_pipe_w(const FwdParams& p, int waves, int qb, hipStream_t stream) {
+template <typename T, int D, bool CAUSAL>
+static hipError_t launch_pipe_c(const FwdParams& p, int waves, int qb, hipStream_t stream) {
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
     if (qb == 2) {
         if constexpr (D == 64) {
-            return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+            return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         } else {
             return hipErrorInvalidValue;
         }
     }
     hipError_t e;
     if constexpr (D == 128) {   // 8 waves x 32 rows = 256-row workgroups: half the L2 -> LDS traffic per FLOP (one K / V piece per wave and step)
-        if (waves == 8) return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 8, 1>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+        if (waves == 8) return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 8, 1, CAUSAL>), dim3((unsigned)grid), dim3(512), 0, stream, p);
     }
     switch (waves) {
-        case 4: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 2: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 2, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
-        default: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 1, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
+        case 4: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 1, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 2, 1, CAUSAL>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
+        default: e = launch1((const void*)(fa_fwd_pipe_kernel<T, D, 1, 1, CAUSAL>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
     }
     return e;
+}
+
+template <typename T, int D>
+static hipError_t launch_pipe_w(const FwdParams& p, int waves, int qb, hipStream_t stream) {
+    return p.causal ? launch_pipe_c<T, D, true>(p, waves, qb, stream) : launch_pipe_c<T, D, false>(p, waves, qb, stream);
 }
 
 // callers guarantee: D in {64, 128}, waves in {1, 2, 4} (or 8 at D = 128), skip-max arithmetic wanted (bf16, or f16 with p.skipmax);

@@ -42,7 +42,7 @@
 
 namespace fa {
 
-template <typename T, int NWAVES>
+template <typename T, int NWAVES, bool CAUSAL>
 __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -146,9 +146,11 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     for (int db = 0; db < NDB; ++db) v_rd[db] = vrow * ROWB + (((2 * db + (vpp >> 1)) ^ vsw) << 4) + 8 * (vpp & 1);
     const int keyg = 8 * (gq & 1) + 4 * (gq >> 1);         // key of accumulator register j of S^T tile (kb, .): 16 kb + keyg + j
 
-    const int kv_end = (qi + 1) * BQ < L ? (qi + 1) * BQ : L;
+    constexpr bool causal = CAUSAL;                        // false: no mask - every wave computes every step, keys past L are masked
+    const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
     const int nh_wg = (kv_end + HK - 1) / HK;              // steps the workgroup streams
-    const int nh_w = wave_active ? q_row0 / HK + 1 : 0;    // steps this wave computes; the last one is its diagonal step
+    const int nh_w = wave_active ? (causal ? q_row0 / HK + 1 : nh_wg) : 0;   // steps this wave computes; the last one carries the mask
+#define P16_KLIM(QH_) (CAUSAL ? qrow[QH_] : L - 1)        /* the last key a row may see */
 
     f32x4 o[NDB][2];
     f32x4 lsum[2];
@@ -191,7 +193,7 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                               \
         _Pragma("unroll") for (int qh = 0; qh < 2; ++qh)                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
-                if ((I_) * HK + 16 * kb + keyg + j > qrow[qh]) S_[kb][qh][j] = -INFINITY;
+                if ((I_) * HK + 16 * kb + keyg + j > P16_KLIM(qh)) S_[kb][qh][j] = -INFINITY;
     // exact row max of the step (a query's 32 scores sit in the 4 lanes n, n+16, n+32, n+48); raise m (rescaling O and the
     // row sums) wherever it is exceeded
 #define P16_MAXR(S_)                                                                               \
@@ -254,8 +256,8 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
             constexpr int qh_ = (V_) >> 2, kb_ = ((V_) >> 1) & 1, e_ = 2 * ((V_) & 1);             \
             if constexpr (MASK_) {                                                                 \
                 const int key_ = key0_ + 16 * kb_ + e_;                                            \
-                if (key_ > qrow[qh_]) SC_[kb_][qh_][e_] = -INFINITY;                               \
-                if (key_ + 1 > qrow[qh_]) SC_[kb_][qh_][e_ + 1] = -INFINITY;                       \
+                if (key_ > P16_KLIM(qh_)) SC_[kb_][qh_][e_] = -INFINITY;                           \
+                if (key_ + 1 > P16_KLIM(qh_)) SC_[kb_][qh_][e_ + 1] = -INFINITY;                   \
             }                                                                                      \
             SC_[kb_][qh_][e_] = __builtin_fmaf(SC_[kb_][qh_][e_], c, -mc[qh_]);                    \
             SC_[kb_][qh_][e_ + 1] = __builtin_fmaf(SC_[kb_][qh_][e_ + 1], c, -mc[qh_]);            \
@@ -405,6 +407,7 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
         P16_RESET()
         P16_RUN(true)
     }
+#undef P16_KLIM
 #undef P16_DMA_K
 #undef P16_DMA_V
 #undef P16_RESET
@@ -459,21 +462,24 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     }
 }
 
-template <typename T, int NWAVES>
+template <typename T, int NWAVES, bool CAUSAL>
 __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_pipe16_kernel(const FwdParams p) {
-    fa_fwd_pipe16_body<T, NWAVES>(p);
+    fa_fwd_pipe16_body<T, NWAVES, CAUSAL>(p);
 }
 
-// callers guarantee: D = 128, causal, skip-max arithmetic wanted (bf16, or f16 with p.skipmax), waves in {4, 8},
+// callers guarantee: D = 128, skip-max arithmetic wanted (bf16, or f16 with p.skipmax), waves in {4, 8},
 // p.nq_tiles = ceil(L / (32 waves))
-hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
+template <typename T, bool CAUSAL>
+static hipError_t launch_pipe16_c(const FwdParams& p, int waves, hipStream_t stream) {
     const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles));
-    if (waves == 8) {   // 256-row workgroups: half the K/V LDS-DMA pieces per wave and step, half the L2 -> LDS traffic per FLOP
-        if (dtype == 1) return launch1((const void*)(fa_fwd_pipe16_kernel<__bf16, 8>), grid, dim3(512), 0, stream, p);
-        return launch1((const void*)(fa_fwd_pipe16_kernel<_Float16, 8>), grid, dim3(512), 0, stream, p);
-    }
-    if (dtype == 1) return launch1((const void*)(fa_fwd_pipe16_kernel<__bf16, 4>), grid, dim3(256), 0, stream, p);
-    return launch1((const void*)(fa_fwd_pipe16_kernel<_Float16, 4>), grid, dim3(256), 0, stream, p);
+    // 8 waves = 256-row workgroups: half the K/V LDS-DMA pieces per wave and step, half the L2 -> LDS traffic per FLOP
+    if (waves == 8) return launch1((const void*)(fa_fwd_pipe16_kernel<T, 8, CAUSAL>), grid, dim3(512), 0, stream, p);
+    return launch1((const void*)(fa_fwd_pipe16_kernel<T, 4, CAUSAL>), grid, dim3(256), 0, stream, p);
+}
+
+hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
+    if (dtype == 1) return p.causal ? launch_pipe16_c<__bf16, true>(p, waves, stream) : launch_pipe16_c<__bf16, false>(p, waves, stream);
+    return p.causal ? launch_pipe16_c<_Float16, true>(p, waves, stream) : launch_pipe16_c<_Float16, false>(p, waves, stream);
 }
 
 }  // namespace fa

@@ -61,7 +61,7 @@ def candidates(G, L, D, skip, causal, scheds=True):
     bunches = sorted({b for b in (auto // 2, auto, auto * 2) if 1 <= b <= ng}) if scheds else [auto]
     out = []
     for kern, qb, w in itertools.product(("dma", "pipe"), (1, 2), (2, 4, 8)):
-        if kern == "pipe" and not (skip and causal and (w <= 4 or D == 128)):
+        if kern == "pipe" and not (skip and (w <= 4 or D == 128)):
             continue
         if qb == 2 and (D != 64 or w != 4 or L < 256):
             continue
@@ -71,7 +71,7 @@ def candidates(G, L, D, skip, causal, scheds=True):
             continue
         for b in bunches:
             out.append({"kernel": kern, "qb": qb, "waves": w, "sched": b})
-    if D == 128 and skip and causal:      # the pipelined kernel on 16x16x32 MFMAs (one tile shape: 4 waves x 32 rows)
+    if D == 128 and skip:                 # the pipelined kernel on 16x16x32 MFMAs (4 or 8 waves x 32 rows)
         for w in (4, 8):
             for b in bunches:
                 out.append({"kernel": "pipe16", "qb": 1, "waves": w, "sched": b})

@@ -53,10 +53,11 @@ def test_noncausal_forward_vs_oracle(dtype, B, H, L, D):
     torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
-@pytest.mark.parametrize("kernel,qb,waves", [("dma", 1, 4), ("dma", 2, 4), ("dma", 1, 8), ("dma", 1, 1), ("tile", 1, 4), ("pipe", 2, 4)])
+@pytest.mark.parametrize("kernel,qb,waves", [("dma", 1, 4), ("dma", 2, 4), ("dma", 1, 8), ("dma", 1, 1), ("tile", 1, 4),
+                                             ("pipe", 2, 4), ("pipe", 1, 4), ("pipe", 1, 2)])
 def test_noncausal_every_kernel_variant(knobs, kernel, qb, waves):
-    """is_causal=False through every MFMA kernel that serves it (a forced 'pipe' falls back to the 64-key-tile
-    kernel: the pipelined order is causal by construction), ragged L, unscaled bf16 logits."""
+    """is_causal=False through every MFMA kernel (the mask mode is a template parameter of the pipelined kernels: no
+    dead block in the last step, only keys past L masked), ragged L, unscaled bf16 logits."""
     from oracle import dense_attention_lse, frozen_randn
 
     knobs.set("kernel", kernel)
@@ -68,6 +69,24 @@ def test_noncausal_every_kernel_variant(knobs, kernel, qb, waves):
     q, k, v = x.cuda()
     out, lse = _fwd(q, k, v, 1.0, False)
     _check(out, ref, torch.bfloat16, f"non-causal kernel={kernel} qb={qb} waves={waves}")
+    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("kernel,waves", [("pipe", 4), ("pipe", 8), ("pipe16", 4), ("pipe16", 8), ("dma", 8)])
+@pytest.mark.parametrize("L", [600, 4100])
+def test_noncausal_head_dim_128_pipelined_kernels(knobs, kernel, waves, L):
+    """Unmasked attention at head_dim 128 through the pipelined kernels (32x32x16 and 16x16x32 MFMA shapes)."""
+    from oracle import dense_attention_lse, frozen_randn
+
+    knobs.set("kernel", kernel)
+    knobs.set("waves", waves)
+    B, H, D = 1, 2, 128
+    x = frozen_randn(SEED + 6 + L, (3, B, H, L, D)).to(torch.bfloat16)
+    scale = D ** -0.5
+    ref, ref_lse = dense_attention_lse(x[0], x[1], x[2], scale=scale, causal=False)
+    q, k, v = x.cuda()
+    out, lse = _fwd(q, k, v, scale, False)
+    _check(out, ref, torch.bfloat16, f"non-causal D=128 kernel={kernel} waves={waves} L={L}")
     torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 

@@ -179,9 +179,10 @@ def _check_builtin_rules(native):
     p = native.plan(8, 2048, 64, torch.float16, 8, 64)         # unscaled f16 keeps the per-tile max: 64-key tiles
     assert (p.chunk_kv, p.block_kv, p.skipmax) == (32, 64, 0)
     assert native.plan(8, 2048, 64, torch.float16, 8, 64, softmax_scale=0.125).block_kv == 32
-    # the non-causal forward (a widening) runs the 64-key-tile kernel
+    # the non-causal forward (a widening) goes through the same kernels (mask mode is a template parameter)
     p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8, causal=False)
-    assert (p.kernel, p.block_q, p.block_kv) == (0, 128, 64)
+    assert (p.kernel, p.block_q, p.block_kv) == (2, 256, 32)
+    assert native.plan(128, 2048, 64, torch.bfloat16, 8, 8, causal=False).kernel == 0
     assert native.plan(4, 4096, 64, torch.float16, 128, 64).block_q == 32    # 32-row chunks honoured
     assert native.plan(5, 200, 64, torch.bfloat16, 1, 1).grid == 8 * 2       # G padded to the 8 XCDs
     assert native.plan(4, 6, 2, torch.float32, 3, 3).kernel == 1             # generic kernel
