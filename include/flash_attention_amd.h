@@ -63,7 +63,7 @@ enum {
     FA_ERR_MISALIGNED = -6,         /* MFMA path needs 16-byte aligned rows */
     FA_ERR_NOT_CAUSAL = -7,         /* causal must be 0 or 1 (the reference path is causal only, sdpa.py:29-32;
                                        causal = 0 is a widening) */
-    FA_ERR_LAUNCH = -8,             /* hipGetLastError() after the launch */
+    FA_ERR_LAUNCH = -8,             /* the launch itself failed (hipLaunchKernel's own return value) */
     FA_ERR_BAD_STRIDE = -9,
     FA_ERR_TOO_LARGE = -10,         /* grid or offsets exceed what the kernel indexes */
     FA_ERR_BAD_SCALE = -11,         /* softmax_scale must be finite and > 0 */
@@ -85,8 +85,8 @@ typedef struct fa_plan_t {
     int64_t lds_bytes;   /* LDS per workgroup */
     int32_t qb;          /* 32-row query blocks per wave (block_q = 32 * waves * qb) */
     int32_t sched;       /* groups per XCD bunch of the block -> (group, q tile) map */
-    int32_t skipmax;     /* 1 = reference max fixed on a wave's first tile + overflow-triggered redo (bf16 always;
-                            f16 when softmax_scale <= 0.25), 0 = per-tile row max with lazy rescale */
+    int32_t skipmax;     /* 1 = reference max fixed on a wave's first tile, optimistic pass + exact fallback pass
+                            (bf16 always; f16 when softmax_scale <= 0.25), 0 = per-tile row max with lazy rescale */
     int32_t source;      /* 0 = built-in rules, 1 = a row of the measured tuning table (fa_tuning_table.h),
                             2 = a debug override was in force (fa_debug_set_option / FA_AMD_* at load) */
 } fa_plan_t;
