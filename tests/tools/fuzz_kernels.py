@@ -102,6 +102,33 @@ def fuzz(cases, seed, log=print):
       if not ok:
           bad += 1
           log(f"MISMATCH fp32 case {case}: B={B} H={H} L={L} D={D} scale={scale:.3g} max|d|={(out - base).abs().max().item():.3e}")
+  # backward: random shapes / dtypes / mask modes / scales through autograd of the override's training path against
+  # autograd through the fp64 oracle (MFMA kernels for 16-bit and fp32 at head_dim 64 / 128, generic kernels otherwise)
+  from flash_attention_amd._impl import ops
+  for case in range(max(2, cases // 6)):
+      D = rng.choice([64, 64, 128, 128, 24, 80])
+      L = rng.choice([rng.randint(1, 130), rng.randint(1, 420)])
+      G = rng.randint(1, 6)
+      dt = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+      scale = rng.choice([1.0, D ** -0.5])
+      causal = rng.random() < 0.7
+      torch.manual_seed(20_000 + case)
+      x = (torch.randn(3, G, L, D) * 0.6).to(dt)
+      g = torch.randn(G, L, D).to(dt)
+      xr = x.double().requires_grad_(True)
+      ref, _ = dense_attention_lse(xr[0][None], xr[1][None], xr[2][None], scale=scale, causal=causal)
+      ref[0].backward(g.double())
+      xc = x.cuda().requires_grad_(True)
+      out = ops.attention(xc[0], xc[1], xc[2], scale, 1, 1, causal)
+      out.backward(g.cuda())
+      torch.cuda.synchronize()
+      tol = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2, torch.float32: 1e-5}[dt]
+      gr, want = xc.grad.cpu().double(), xr.grad
+      floor = tol * max(1e-3, want.abs().max().item())
+      ok = bool(torch.isfinite(gr).all()) and bool(((gr - want).abs() <= floor + 2e-2 * want.abs()).all())
+      if not ok:
+          bad += 1
+          log(f"MISMATCH backward case {case}: G={G} L={L} D={D} {dt} scale={scale:.3g} causal={causal} max|d|={(gr - want).abs().max().item():.3e} (ref max {want.abs().max().item():.2f})")
   return bad, len(variants)
 
 
