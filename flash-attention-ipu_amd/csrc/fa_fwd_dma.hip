@@ -67,6 +67,14 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         g = (g0 + (rem - qd * bc)) * 8 + xcd;
     }
     if (g >= p.G) return;
+#ifdef FA_STAMPS   /* measurement build only (scripts/phase_times.py): phase time stamps overwrite the LSE rows */
+    const unsigned long long st0_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st1_ = 0, st2_ = 0;
+#define FA_STAMP(V_) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); V_ = __builtin_amdgcn_s_memtime(); }
+#else
+#define FA_STAMP(V_) {}
+#endif
 
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -118,12 +126,17 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         const unsigned ko_ = (unsigned)(T_) * BK * k_slb, vo_ = (unsigned)(T_) * BK * v_slb;       \
         const i32x4 kr_ = make_raw_rsrc((const char*)kg + ko_, k_bytes - ko_);                     \
         const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
+        if (FA_DMA_ABL != 2) {                                                                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
             lds_dma_b128(kr_, smem_lds + (BUF_) * KTILE_B + k_dst[j], k_vo[j]);                    \
             lds_dma_b128(vr_, smem_lds + 2 * KTILE_B + (BUF_) * VTILE_B + v_dst[j], v_vo[j]);      \
         }                                                                                          \
+        }                                                                                          \
     }
     // publish a DMA'd tile: drain this wave's DMA, then the workgroup barrier
+#ifndef FA_DMA_ABL
+#define FA_DMA_ABL 0    /* timing-only ablations (wrong results): 2 no K/V DMA, 3 no softmax, 4 no PV, 5 no QK, 6 no O stores */
+#endif
 #if defined(FA_DMA_ABL_NOBAR)   /* timing-only ablation: wrong results */
 #define FA_TILE_BARRIER() { lds_dma_wait_all(); }
 #else
@@ -259,14 +272,20 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         const int kv0 = (T_) * BK;                                                                 \
         if (wave_active && kv0 <= wave_kv_last) {                                                  \
             f32x16 s0[QB], s1[QB];                                                                 \
-            FA_QK(BUF_)                                                                            \
+            if (FA_DMA_ABL != 5) { FA_QK(BUF_) } else {                                            \
+                _Pragma("unroll") for (int b = 0; b < QB; ++b)                                     \
+                    _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[b][e] = o[b][0][e]; s1[b][e] = o[b][1][e]; } \
+            }                                                                                      \
             if ((MODE_) == 0) {                                                                    \
                 if (kv0 == 0) FA_MAX_RESCALE(0.0f)       /* first tile: m = -inf -> exact max */    \
             } else {                                                                               \
                 FA_MAX_RESCALE(RESCALE_THR)                                                        \
             }                                                                                      \
-            FA_SOFTMAX()                                                                           \
-            FA_PV(BUF_)                                                                            \
+            if (FA_DMA_ABL != 3) FA_SOFTMAX()                                                      \
+            if (FA_DMA_ABL != 4) { FA_PV(BUF_) } else {                                            \
+                _Pragma("unroll") for (int b = 0; b < QB; ++b)                                     \
+                    _Pragma("unroll") for (int e = 0; e < 16; ++e) { o[b][0][e] += s0[b][e]; o[b][1][e] += s1[b][e]; } \
+            }                                                                                      \
         }                                                                                          \
     }
     // one pass over the workgroup's kv tiles (the kv loop is unrolled by two: LDS addresses are base + immediate)
@@ -274,6 +293,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     {                                                                                              \
         FA_DMA_TILE(0, 0)                                                                          \
         FA_TILE_BARRIER()                                                                          \
+        FA_STAMP(st1_)                                                                             \
         for (int t = 0; t < n_tiles; t += 2) {                                                     \
             if (t + 1 < n_tiles) FA_DMA_TILE(t + 1, 1)                                             \
             FA_COMPUTE(t, 0, MODE_)                                                                \
@@ -322,6 +342,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #undef FA_SOFTMAX
 #undef FA_PV
 
+    FA_STAMP(st2_)
     // ---- epilogue: O /= l, staged through LDS so that every store instruction writes whole rows.
     // (A lane owns 8-byte pieces of ONE row at a 16-byte pitch; stored directly, one instruction touches
     // 32 rows x 2 pieces.)  The K buffers are free after the last barrier; each wave uses a private
@@ -354,9 +375,28 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             const int rr = i * RPI + lane / CPR, ch = lane % CPR;
             const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
             const int orow = q_row0 + 32 * b + rr;
-            if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
+            if (orow < L && (FA_DMA_ABL != 6 || val.x == 0x12345u)) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
         }
     }
+#ifdef FA_STAMPS
+    {
+        unsigned long long st3_;
+        FA_STAMP(st3_)
+        if (p.lse != nullptr && lane == 0 && BQ >= 64 && qi * BQ + BQ <= L) {
+            unsigned long long* sp = (unsigned long long*)(p.lse + (int64_t)g * L + qi * BQ) + wave * (BQ / 2 / NWAVES);
+            sp[0] = st0_; sp[1] = st1_; sp[2] = st2_; sp[3] = st3_;
+            sp[10] = rt0_; sp[11] = __builtin_amdgcn_s_memrealtime();
+            if (BQ / 2 / NWAVES >= 8) {
+                unsigned hwid;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                sp[4] = ((unsigned long long)xcc << 32) | hwid;
+                sp[5] = (unsigned long long)n_tiles;
+            }
+        }
+    }
+#endif
 }
 
 template <typename T, int D, int NWAVES, bool SKIP, int QB>

@@ -107,6 +107,14 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         g = (g0 + (rem - qd * bc)) * 8 + xcd;
     }
     if (g >= p.G) return;
+#ifdef FA_STAMPS   /* measurement build only (scripts/phase_times.py): phase time stamps overwrite the LSE rows */
+    const unsigned long long st0_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st1_ = 0, st2_ = 0, sta_ = 0, stb_ = 0, stc_ = 0;
+#define FA_STAMP(V_) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); V_ = __builtin_amdgcn_s_memtime(); }
+#else
+#define FA_STAMP(V_) {}
+#endif
 
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -484,8 +492,10 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         }                                                                                          \
         lds_dma_wait_all();                                                                        \
         __syncthreads();                                                                           \
+        if (!(SAFE_)) FA_STAMP(st1_)                                                               \
         if (nh_w >= 1) FA_QK_H(sa, 0)                                                              \
         FA_GENERIC(0, sa, sb, pb, pa, SAFE_)                                                       \
+        if (!(SAFE_)) FA_STAMP(sta_)                                                               \
         int i = 1;                                                                                 \
         if (!(SAFE_)) {                                                                            \
             for (; i + NS - 1 + QB < nh_w; i += NS) {  /* steps i .. i+NS-1 carry no mask */        \
@@ -497,6 +507,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             }                                                                                      \
         }                                                                                          \
         FA_ROTATE()                                            /* i is odd: S(i) sb -> sa, P(i-1) pa -> pb */ \
+        if (!(SAFE_)) FA_STAMP(stb_)                                                               \
         if (!(SAFE_)) {                                                                            \
             for (; i + QB < nh_w; ++i) {                       /* steps the groups left over */    \
                 FA_RAGGED(i, 0, true)                                                              \
@@ -514,6 +525,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 ++i;                                                                               \
             }                                                                                      \
         }                                                                                          \
+        if (!(SAFE_)) FA_STAMP(stc_)                                                               \
         for (; i <= nh_wg; ++i) {                              /* drain, idle (and the safe pass) */ \
             FA_GENERIC(i, sa, sb, pb, pa, SAFE_)                                                   \
             FA_ROTATE()                                                                            \
@@ -592,6 +604,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #undef FA_SM_H
 #undef FA_PACK_H
 
+    FA_STAMP(st2_)
     // ---- epilogue: O /= l through LDS, whole-row stores (as fa_fwd_dma_kernel; the K ring is free now)
     if (!wave_active) return;
     unsigned char* slab = smem + wave * (32 * ROWB);
@@ -623,6 +636,25 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
         }
     }
+#ifdef FA_STAMPS
+    {
+        unsigned long long st3_;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FA_STAMP(st3_)
+        if (p.lse != nullptr && lane == 0 && BQ / 2 / NWAVES >= 8 && qi * BQ + BQ <= L) {
+            unsigned long long* sp = (unsigned long long*)(p.lse + (int64_t)g * L + qi * BQ) + wave * (BQ / 2 / NWAVES);
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            sp[0] = st0_; sp[1] = st1_; sp[2] = st2_; sp[3] = st3_;
+            sp[10] = rt0_; sp[11] = __builtin_amdgcn_s_memrealtime();
+            sp[4] = ((unsigned long long)xcc << 32) | hwid;
+            sp[5] = (unsigned long long)nh_wg;
+            sp[6] = sta_; sp[7] = stb_;
+            if (BQ / 2 / NWAVES >= 16) sp[8] = stc_;
+        }
+    }
+#endif
 }
 
 // (two query blocks per wave: hold the register allocator to 2 waves per SIMD = 256 registers)
