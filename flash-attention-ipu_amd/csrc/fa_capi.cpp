@@ -91,7 +91,8 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 // The ONE selection function behind fa_plan() and fa_fwd().
 //   'd' fa_fwd_dma_kernel   64-key tiles, LDS-DMA staged (fa_fwd_dma.hip)
 //   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic only
-//   'x' fa_fwd_pipe16_kernel the pipelined kernel on v_mfma_f32_16x16x32 (fa_fwd_pipe16.hip): head_dim 128, 4 waves, qb 1
+//   'x' fa_fwd_pipe16_kernel the pipelined kernel on v_mfma_f32_16x16x32 (fa_fwd_pipe16.hip): head_dim 128 with 4 | 8 waves and qb 1,
+//       head_dim 64 with 4 waves and qb 1 | 2
 //   't' fa_fwd_tile_kernel  register-staged A/B baseline (debug override only)
 // qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
 // Order: debug overrides > measured table (fa_tuning_table.h) > built-in rules; the num_chunks_* bounds and the
@@ -140,7 +141,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
                 if (r.D != D || r.skip != skip || r.causal != causal || L < r.L_lo || L > r.L_hi || wgs128 < r.wg_lo || wgs128 > r.wg_hi) continue;
                 if (32 * r.waves * r.qb > (cq > 32 ? cq : 32)) continue;   // the q chunk forbids the row's tile
                 if ((r.kernel == 'p' || r.kernel == 'x') && !pipe_ok) continue;
-                if (r.kernel == 'x' && D != 128) continue;
+                if (r.kernel == 'x' && D == 64 && r.waves != 4) continue;
                 which = r.kernel; waves = r.waves; qb = r.qb; sched = r.sched; source = 1;
                 break;
             }
@@ -151,15 +152,16 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
         if (fk == 't') { which = 't'; qb = 1; }
         else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
-        else if (fk == 'x' && pipe_ok && D == 128) { which = 'x'; waves = fw == 8 ? 8 : 4; qb = 1; }
+        else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && D == 128) ? 8 : 4; if (!fq) qb = 1; }
         else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
         if (fq == 1) qb = 1;
         if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
+        if (fq == 2 && fk == 'x' && D == 64) qb = 2;        // (a forced variant ignores the chunk bound, as the forced kernel does)
         // ---- constraints of the kernels
         if (want32 && pipe_ok && which == 'd' && fk == 0) { which = 'p'; if (waves > 4 && D != 128) waves = 4; }
         if (which == 'p' && ((waves > 4 && D != 128) || !pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
-        if (which == 'x' && !(pipe_ok && D == 128)) which = 'd';
-        if (which == 'x') { waves = waves == 8 ? 8 : 4; qb = 1; }
+        if (which == 'x' && !pipe_ok) which = 'd';
+        if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
         if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
         if (which == 't' && waves > 4) waves = 4;
         plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : 0;
@@ -366,7 +368,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     hipError_t e = sel.which == 'g'   ? fa::launch_fwd_generic(p, dtype, st)
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
-                   : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, st)
+                   : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves, plan.qb, st)
                                       : fa::launch_fwd_tile(p, dtype, plan.waves, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

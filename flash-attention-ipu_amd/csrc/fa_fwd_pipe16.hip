@@ -1,14 +1,16 @@
-// FlashAttention forward for MI355X (gfx950), head_dim 128: the software-pipelined kernel of fa_fwd_pipe.hip rebuilt
-// on v_mfma_f32_16x16x32 (read fa_fwd_pipe.hip first: same rings, LDS-DMA staging, step barrier, optimistic skip-max
+// FlashAttention forward for MI355X (gfx950): the software-pipelined kernel of fa_fwd_pipe.hip rebuilt on
+// v_mfma_f32_16x16x32 (read fa_fwd_pipe.hip first: same rings, LDS-DMA staging, step barrier, optimistic skip-max
 // arithmetic with an exact fallback pass, PV-first step order with the next step's V^T fragments requested mid-step).
 //
-// Why a second MFMA shape: at head_dim 128 the pipelined 32x32x16 kernel keeps the matrix pipe ~75 % busy and the device
-// answers by dropping to ~1.64 GHz (profiles/r02_cfg3) - it is power-bound - and on this chip the clock held under a
-// bf16 MFMA stream depends on the MFMA shape: 16x16x32 delivers 1.12-1.14x the FLOP/s of 32x32x16 at equal cycles with
-// operands read from LDS (MI355X_MICROARCH.md, DVFS give-back item 7; cdna_hip_programming.md rule 28).  The shape costs
-// issue slots (twice the MFMAs, each holding the issue port 8 cycles): 34 MFMAs x 8 + ~224 VALU cycles = ~500 issue
-// cycles per 32-key step against 544 matrix cycles at head_dim 128 - it fits; at head_dim 64 it would not (the 64-wide
-// kernel is issue-bound already), so this file exists for head_dim 128 only.
+// Why a second MFMA shape: the forward is power-bound - the in-kernel clock under the pipelined 32x32x16 kernels is
+// 1.4-1.65 GHz of 2.4 (scripts/phase_times.py, profiles/r02_cfg3) - and on this chip the clock held under a bf16 MFMA
+// stream depends on the MFMA shape: 16x16x32 delivers 1.12-1.14x the FLOP/s of 32x32x16 at equal cycles with operands
+// read from LDS (MI355X_MICROARCH.md, DVFS give-back item 7; cdna_hip_programming.md rule 28).  The shape costs issue
+// slots (twice the MFMAs, each holding the issue port 8 cycles):
+//   head_dim 128, 32 rows per wave: 34 MFMAs x 8 + ~224 VALU cycles = ~500 issue cycles per 32-key step against 544
+//     matrix cycles - it fits, and pays: +4.4 % over the 32x32x16 pipelined kernel;
+//   head_dim 64, 64 rows per wave (NQH = 4): 36 x 8 + ~456 = ~750 against 576 - issue-bound, and the clock gain only
+//     just covers it: +0.8 % at L = 4096, +1.9 % at L = 32768, -5 % at L = 1024: a tuner candidate.
 //
 // Operand maps (lane l: n = l & 15, g = l >> 4):
 //   A[16 x 32]: A[row n][k = 8 g + j]      B[32 x 16]: B[k = 8 g + j][col n]      C/D[16 x 16]: [row 4 g + j][col n], j = 0..3
@@ -23,9 +25,10 @@
 //     index k' = 8 g + j' <-> key 16 (j' >> 2) + pi(4 g + (j' & 3));  A = V[that key][16 db + n] = two ds_read_b64_tr_b16
 //     (4 keys x 16 columns each, transposed by the LDS hardware) from a plain row-major V image.
 //   row sums: one more MFMA per query half with an all-ones A: every lane receives the full 32-key sum of its query.
-// LDS images (32-key slots, 256-byte rows, both filled by LDS-DMA with per-lane source addresses):
-//   K: 16-byte chunk c of row r at chunk slot c ^ (r & 15)                      (conflict-free ds_read_b128 rows)
-//   V: chunk c of row r at slot c ^ (((r & 3) << 2) | ((r >> 2) & 3))           (conflict-free transposed reads)
+// LDS images (32-key slots of 2 D-byte rows, both filled by LDS-DMA with per-lane source addresses); head_dim 128 | 64:
+//   K: 16-byte chunk c of row r at chunk slot c ^ (r & 15) | c ^ ((r >> 1) & 7)          (conflict-free ds_read_b128 rows)
+//   V: chunk c of row r at slot c ^ (((r & 3) << 2) | ((r >> 2) & 3)) | c ^ (2 ((r >> 1) & 1) + 4 ((r >> 3) & 1))
+//      (conflict-free transposed reads: the 8 rows a half-wave touches, 32 bytes each, cover the 64 banks once)
 
 #include "fa_device.h"
 
@@ -42,18 +45,27 @@
 
 namespace fa {
 
-template <typename T, int NWAVES, bool CAUSAL>
+// D = head_dim (64 | 128), NQH = 16-row query blocks per wave (2 | 4: every K / V^T fragment read feeds NQH MFMAs)
+template <typename T, int D, int NWAVES, int NQH, bool CAUSAL>
 __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
-    constexpr int D = 128, BQ = NWAVES * 32, HK = 32, ROWB = D * 2;
-    constexpr int SLOT_B = HK * ROWB;           // 8 KiB K slot = V slot
+    constexpr int RW = 16 * NQH;                // query rows per wave
+    constexpr int BQ = NWAVES * RW, HK = 32, ROWB = D * 2;
+    constexpr int SLOT_B = HK * ROWB;           // K slot = V slot (8 KiB at head_dim 128, 4 KiB at 64)
     constexpr int PIECES = SLOT_B / 1024, PPW = PIECES / NWAVES;
+    constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
+    constexpr int RPP = 1024 / ROWB;            // rows per 1-KiB DMA piece
+    constexpr int NDIAG = RW / HK;              // a wave's last NDIAG steps carry the causal mask
+    static_assert(PPW >= 1 && PIECES % NWAVES == 0, "pieces must split evenly over the waves");
     constexpr int NDS = D / 32;                 // 32-wide d slices of the QK^T contraction
     constexpr int NDB = D / 16;                 // 16-row d blocks of O^T
     constexpr int NS = 4, NSM = NS - 1;         // ring slots
-    constexpr int NPRE = FA_P16_NPRE;           // V^T fragments of the next step held in registers across the step barrier
+    constexpr int NPRE = FA_P16_NPRE < NDB ? FA_P16_NPRE : NDB;   // V^T fragments of the next step held in registers across the step barrier
+    // image swizzles: the 16-byte chunk c of row r sits at chunk slot c ^ kswz(r) (K) / c ^ vswz(r) (V)
+    auto kswz = [](int r) { return D == 128 ? (r & 15) : ((r >> 1) & 7); };
+    auto vswz = [](int r) { return D == 128 ? (((r & 3) << 2) | ((r >> 2) & 3)) : ((((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2)); };
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NS * SLOT_B];   // K0..K3 V0..V3
     unsigned char* const smem_v = smem + NS * SLOT_B;
@@ -85,12 +97,12 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
     const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
-    const int q_row0 = qi * BQ + wave * 32;
+    const int q_row0 = qi * BQ + wave * RW;
     const bool wave_active = q_row0 < L;
-    int qrow[2];                                 // this lane's query row in each 16-row half
-    vec8 qf[2][NDS];
+    int qrow[NQH];                               // this lane's query row in each 16-row block
+    vec8 qf[NQH][NDS];
 #pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {
+    for (int qh = 0; qh < NQH; ++qh) {
         qrow[qh] = q_row0 + 16 * qh + n;
         const int qr = qrow[qh] < L ? qrow[qh] : L - 1;
         const T* qp = qg + (int64_t)qr * p.q_sl + 8 * gq;
@@ -106,9 +118,9 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int pc = wave + j * NWAVES;
-        const int row = 4 * pc + (lane >> 4), cp = lane & 15;
-        k_vo[j] = (unsigned)row * k_slb + ((cp ^ (row & 15)) << 4);
-        v_vo[j] = (unsigned)row * v_slb + ((cp ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+        const int row = RPP * pc + lane / CPR, cp = lane % CPR;
+        k_vo[j] = (unsigned)row * k_slb + ((cp ^ kswz(row)) << 4);
+        v_vo[j] = (unsigned)row * v_slb + ((cp ^ vswz(row)) << 4);
         dst[j] = pc * 1024;
     }
     const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;
@@ -136,11 +148,11 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) k_rd[kb][ds] = (16 * kb + pin) * ROWB + (((4 * ds + gq) ^ pin) << 4);
+        for (int ds = 0; ds < NDS; ++ds) k_rd[kb][ds] = (16 * kb + pin) * ROWB + (((4 * ds + gq) ^ kswz(pin)) << 4);
     // V^T fragment db: lane 4 q + pp of group g supplies row pi(4 g + q) (+16 for the second read), columns 16 db + 4 pp ..+3
     const int vq = (lane & 15) >> 2, vpp = lane & 3;
     const int vrow = 8 * (gq & 1) + 4 * (gq >> 1) + vq;
-    const int vsw = ((vrow & 3) << 2) | ((vrow >> 2) & 3);
+    const int vsw = vswz(vrow);                  // (= vswz(vrow + 16): the second read of a fragment)
     int v_rd[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db) v_rd[db] = vrow * ROWB + (((2 * db + (vpp >> 1)) ^ vsw) << 4) + 8 * (vpp & 1);
@@ -149,16 +161,16 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     constexpr bool causal = CAUSAL;                        // false: no mask - every wave computes every step, keys past L are masked
     const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
     const int nh_wg = (kv_end + HK - 1) / HK;              // steps the workgroup streams
-    const int nh_w = wave_active ? (causal ? q_row0 / HK + 1 : nh_wg) : 0;   // steps this wave computes; the last one carries the mask
+    const int nh_w = wave_active ? (causal ? q_row0 / HK + NDIAG : nh_wg) : 0;   // steps this wave computes; the last NDIAG carry the mask
 #define P16_KLIM(QH_) (CAUSAL ? qrow[QH_] : L - 1)        /* the last key a row may see */
 
-    f32x4 o[NDB][2];
-    f32x4 lsum[2];
-    float m[2];
+    f32x4 o[NDB][NQH];
+    f32x4 lsum[NQH];
+    float m[NQH];
     const vec8 ones = __builtin_bit_cast(vec8, u32x4{E::one_bits * 0x10001u, E::one_bits * 0x10001u, E::one_bits * 0x10001u, E::one_bits * 0x10001u});
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #define P16_RESET()                                                                                \
-    _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) {                                             \
+    _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh) {                                             \
         m[qh] = -INFINITY;                                                                         \
         lsum[qh] = zero4;                                                                          \
         _Pragma("unroll") for (int db = 0; db < NDB; ++db) o[db][qh] = zero4;                      \
@@ -177,27 +189,27 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     // ---- compiler-scheduled pieces (first step, drain, idle steps, the exact fallback pass)
 #define P16_QK(S_, SLOT_)                                                                          \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                             \
-        _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) S_[kb][qh] = zero4;                       \
+        _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh) S_[kb][qh] = zero4;                       \
         _Pragma("unroll") for (int ds = 0; ds < NDS; ++ds) {                                       \
             const vec8 kf_ = P16_KFRAG(kb, ds, SLOT_);                                             \
-            _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) S_[kb][qh] = E::mfma16(kf_, qf[qh][ds], S_[kb][qh]); \
+            _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh) S_[kb][qh] = E::mfma16(kf_, qf[qh][ds], S_[kb][qh]); \
         }                                                                                          \
     }
 #define P16_PV(P_, SLOT_)                                                                          \
     _Pragma("unroll") for (int db = 0; db < NDB; ++db) {                                           \
         vec8 vf_;                                                                                  \
         P16_VFRAG(vf_, db, smem_v + (SLOT_) * SLOT_B)                                              \
-        _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) o[db][qh] = E::mfma16(vf_, P_[qh], o[db][qh]); \
+        _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh) o[db][qh] = E::mfma16(vf_, P_[qh], o[db][qh]); \
     }
 #define P16_MASK(S_, I_)                                                                           \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                               \
-        _Pragma("unroll") for (int qh = 0; qh < 2; ++qh)                                           \
+        _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh)                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
                 if ((I_) * HK + 16 * kb + keyg + j > P16_KLIM(qh)) S_[kb][qh][j] = -INFINITY;
     // exact row max of the step (a query's 32 scores sit in the 4 lanes n, n+16, n+32, n+48); raise m (rescaling O and the
     // row sums) wherever it is exceeded
 #define P16_MAXR(S_)                                                                               \
-    _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) {                                             \
+    _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh) {                                             \
         float mx = max2(max2(S_[0][qh][0], S_[0][qh][1]), max2(S_[0][qh][2], S_[0][qh][3]));       \
         mx = max3(mx, max2(S_[1][qh][0], S_[1][qh][1]), max2(S_[1][qh][2], S_[1][qh][3]));         \
         mx = max2(mx, __shfl_xor(mx, 16, 64));                                                     \
@@ -213,7 +225,7 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     }
     // P = 2^(c S - c m), packed as the B fragment of the PV product (j' = 0..3 from key block 0, 4..7 from block 1), row sums
 #define P16_SM_PACK(PC_, S_)                                                                       \
-    _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) {                                             \
+    _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh) {                                             \
         const float mc = m[qh] * c;                                                                \
         _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
@@ -238,7 +250,7 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
         if (i_ + 1 < nh_w) P16_QK(SN_, (i_ + 1) & NSM)                                             \
         if (i_ >= 1 && i_ <= nh_w) P16_PV(PP_, (i_ + NS - 1) & NSM)                                \
         if (i_ < nh_w) {                                                                           \
-            if (i_ == nh_w - 1) P16_MASK(SC_, i_)                                                  \
+            if (i_ >= nh_w - NDIAG) P16_MASK(SC_, i_)                                              \
             if (i_ == 0 || (SAFE_)) P16_MAXR(SC_)                                                  \
             P16_SM_PACK(PC_, SC_)                                                                  \
             if (!(SAFE_)) P16_PRE(smem_v + (i_ & NSM) * SLOT_B)   /* V(i) fragments for a hand-scheduled step i + 1 */ \
@@ -283,7 +295,8 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
 #define P16_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_)                            \
     {                                                                                              \
         P16_ISSUE(I_, KI_, VI_)                                                                    \
-        constexpr int NM = NDB + ((QK_) ? 2 * NDS : 0), NMF = 2 * NM, NV = 8, GAP = NMF / NV;      \
+        constexpr int NM = NDB + ((QK_) ? 2 * NDS : 0), NMF = NQH * NM, NV = 4 * NQH, GAP = NMF / NV;  \
+        static_assert(GAP == 1 || GAP == 2 || GAP == 4, "softmax items per MFMA gap");             \
         constexpr int PF_ = FA_P16_PF < NM ? FA_P16_PF : NM;                                       \
         const unsigned char* kb_ = smem + (KN_) * SLOT_B;                                          \
         const unsigned char* vb_ = smem_v + (VP_) * SLOT_B;                                        \
@@ -293,12 +306,12 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
         vec8 opnd[NM];                                                                             \
         fa_static_for<0, NPRE>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; opnd[x_] = pre[x_]; }); \
         fa_static_for<NPRE, (NPRE > PF_ ? NPRE : PF_)>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; P16_OPND_LOAD(x_) }); \
-        float mc[2];                                                                               \
-        _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) mc[qh] = m[qh] * c;                       \
+        float mc[NQH];                                                                             \
+        _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh) mc[qh] = m[qh] * c;                     \
         P16_ITEM_FMA(SC_, 0, MASK_)                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         fa_static_for<0, NMF>([&](auto gi_) {                                                      \
-            constexpr int n_ = decltype(gi_)::value, g_ = n_ / 2, qh_ = n_ % 2;                    \
+            constexpr int n_ = decltype(gi_)::value, g_ = n_ / NQH, qh_ = n_ % NQH;                \
             if constexpr (g_ < NDB) {                                                              \
                 o[g_][qh_] = E::mfma16(opnd[g_], PP_[qh_], o[g_][qh_]);                            \
             } else {                                                                               \
@@ -306,9 +319,9 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
                 if constexpr (ds_ == 0) SN_[kbx_][qh_] = E::mfma16(opnd[g_], qf[qh_][ds_], zero4); \
                 else SN_[kbx_][qh_] = E::mfma16(opnd[g_], qf[qh_][ds_], SN_[kbx_][qh_]);           \
             }                                                                                      \
-            if constexpr (qh_ == 1 && g_ + PF_ < NM && g_ + PF_ >= NPRE) { P16_OPND_LOAD(g_ + PF_) } \
+            if constexpr (qh_ == NQH - 1 && g_ + PF_ < NM && g_ + PF_ >= NPRE) { P16_OPND_LOAD(g_ + PF_) } \
             /* the NEXT step's first V^T fragments, requested once this step's held ones have been consumed */ \
-            if constexpr ((QK_) && qh_ == 1 && g_ >= NPRE && g_ < 2 * NPRE) { P16_VFRAG(pre[g_ - NPRE], g_ - NPRE, vnext_) } \
+            if constexpr ((QK_) && qh_ == NQH - 1 && g_ >= NPRE && g_ < 2 * NPRE) { P16_VFRAG(pre[g_ - NPRE], g_ - NPRE, vnext_) } \
             /* this gap's share of the softmax of S(i) */                                          \
             constexpr int w_ = n_ / GAP, ph_ = n_ % GAP;                                           \
             if constexpr (GAP == 4) {                                                              \
@@ -316,20 +329,23 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
                 if constexpr (ph_ == 1) { P16_ITEM_EXP(SC_, w_, 0) }                               \
                 if constexpr (ph_ == 2) { P16_ITEM_EXP(SC_, w_, 1) }                               \
                 if constexpr (ph_ == 3) { P16_ITEM_CVT(SC_, PC_, w_) }                             \
-            } else {                                                                               \
+            } else if constexpr (GAP == 2) {                                                       \
                 if constexpr (ph_ == 0) { if constexpr (w_ + 1 < NV) { P16_ITEM_FMA(SC_, w_ + 1, MASK_) } P16_ITEM_EXP(SC_, w_, 0) } \
                 if constexpr (ph_ == 1) { P16_ITEM_EXP(SC_, w_, 1) P16_ITEM_CVT(SC_, PC_, w_) }    \
+            } else {                                                                               \
+                if constexpr (w_ + 1 < NV) { P16_ITEM_FMA(SC_, w_ + 1, MASK_) }                    \
+                P16_ITEM_EXP(SC_, w_, 0) P16_ITEM_EXP(SC_, w_, 1) P16_ITEM_CVT(SC_, PC_, w_)       \
             }                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         });                                                                                        \
         /* pin this step's vector work to this step */                                             \
-        asm volatile("" : "+v"(PC_[0]), "+v"(PC_[1]), "+v"(lsum[0]), "+v"(lsum[1]));               \
+        _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh) asm volatile("" : "+v"(PC_[qh]), "+v"(lsum[qh])); \
         P16_PUBLISH()                                                                              \
     }
 #define P16_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                     \
     P16_FAST(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, false, true)
 #define P16_ROTATE()                                                                               \
-    _Pragma("unroll") for (int qh = 0; qh < 2; ++qh) {                                             \
+    _Pragma("unroll") for (int qh = 0; qh < NQH; ++qh) {                                             \
         sa[0][qh] = sb[0][qh];                                                                     \
         sa[1][qh] = sb[1][qh];                                                                     \
         pb[qh] = pa[qh];                                                                           \
@@ -350,7 +366,7 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
         P16_GENERIC(0, sa, sb, pb, pa, SAFE_)                                                      \
         int i = 1;                                                                                 \
         if (!(SAFE_)) {                                                                            \
-            for (; i + NS - 1 + 1 < nh_w; i += NS) {   /* steps i .. i+NS-1 carry no mask */         \
+            for (; i + NS - 1 + NDIAG < nh_w; i += NS) {   /* steps i .. i+NS-1 carry no mask */     \
                 fa_static_for<0, NS>([&](auto ki_) {                                               \
                     constexpr int k_ = decltype(ki_)::value, R_ = (1 + k_) % NS;                   \
                     if constexpr (k_ % 2 == 0) P16_STEADY(i + k_, R_, sb, sa, pa, pb)              \
@@ -360,9 +376,14 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
         }                                                                                          \
         P16_ROTATE()                                           /* i is odd: S(i) sb -> sa, P(i-1) pa -> pb */ \
         if (!(SAFE_)) {                                                                            \
-            for (; i + 1 < nh_w; ++i) {                        /* steps the groups left over */    \
+            for (; i + NDIAG < nh_w; ++i) {                    /* steps the groups left over */    \
                 P16_RAGGED(i, false, true)                                                         \
                 P16_ROTATE()                                                                       \
+            }                                                                                      \
+            if (NDIAG == 2 && i + 1 < nh_w) {                  /* the first diagonal step of a 64-row wave */ \
+                P16_RAGGED(i, true, true)                                                          \
+                P16_ROTATE()                                                                       \
+                ++i;                                                                               \
             }                                                                                      \
             if (i < nh_w) {                                    /* the wave's last (diagonal) step */ \
                 P16_RAGGED(i, true, false)                                                         \
@@ -376,11 +397,11 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
         }                                                                                          \
     }
 
-    f32x4 sa[2][2], sb[2][2];
-    vec8 pa[2], pb[2];
+    f32x4 sa[2][NQH], sb[2][NQH];
+    vec8 pa[NQH], pb[NQH];
     vec8 pre[NPRE];
 #pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {
+    for (int qh = 0; qh < NQH; ++qh) {
         sa[0][qh] = zero4; sa[1][qh] = zero4; sb[0][qh] = zero4; sb[1][qh] = zero4;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { pa[qh][j] = (T)0.f; pb[qh][j] = (T)0.f; }
@@ -396,7 +417,7 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     // optimistic pass: an overflowed P made a row sum inf / NaN for good - one check per pass, all waves must agree
     bool bad = false;
 #pragma unroll
-    for (int qh = 0; qh < 2; ++qh) bad |= wave_active && sum_left_safe_range(lsum[qh][0]);
+    for (int qh = 0; qh < NQH; ++qh) bad |= wave_active && sum_left_safe_range(lsum[qh][0]);
     flags[wave] = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
     __syncthreads();
     int any_bad = 0;
@@ -436,10 +457,10 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     // d of ONE row: 8 bytes at byte 32 db + 8 g of that row; the 16-byte chunk index is XORed with the row so that the 16
     // rows of a half land in different banks.
     if (!wave_active) return;
-    unsigned char* slab = smem + wave * (32 * ROWB);
+    unsigned char* slab = smem + wave * (RW * ROWB);
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
 #pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {
+    for (int qh = 0; qh < NQH; ++qh) {
         const float lt = lsum[qh][0];
         const float inv = __builtin_amdgcn_rcpf(lt);
         const int rr = 16 * qh + n;
@@ -449,37 +470,42 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][qh][j] * inv);
             const int ch = 2 * db + (gq >> 1);
-            *(vec4*)(slab + rr * ROWB + ((ch ^ (rr & 15)) << 4) + 8 * (gq & 1)) = w;
+            *(vec4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4) + 8 * (gq & 1)) = w;
         }
         if (p.lse != nullptr && gq == 0 && qrow[qh] < L) p.lse[(int64_t)g * L + qrow[qh]] = m[qh] * p.scale + __logf(lt);
     }
+    constexpr int RPI = 64 / CPR;           // rows per store instruction (4 x 16 chunks at head_dim 128, 8 x 8 at 64)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {           // 4 rows x 16 chunks per instruction
-        const int rr = 4 * i + (lane >> 4), ch = lane & 15;
-        const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & 15)) << 4));
+    for (int i = 0; i < RW / RPI; ++i) {
+        const int rr = RPI * i + lane / CPR, ch = lane % CPR;
+        const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
         const int orow = q_row0 + rr;
         if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
     }
 }
 
-template <typename T, int NWAVES, bool CAUSAL>
+template <typename T, int D, int NWAVES, int NQH, bool CAUSAL>
 __global__ __launch_bounds__(NWAVES * 64, 2) void fa_fwd_pipe16_kernel(const FwdParams p) {
-    fa_fwd_pipe16_body<T, NWAVES, CAUSAL>(p);
+    fa_fwd_pipe16_body<T, D, NWAVES, NQH, CAUSAL>(p);
 }
 
 // callers guarantee: D = 128, skip-max arithmetic wanted (bf16, or f16 with p.skipmax), waves in {4, 8},
 // p.nq_tiles = ceil(L / (32 waves))
 template <typename T, bool CAUSAL>
-static hipError_t launch_pipe16_c(const FwdParams& p, int waves, hipStream_t stream) {
+static hipError_t launch_pipe16_c(const FwdParams& p, int waves, int qb, hipStream_t stream) {
     const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles));
     // 8 waves = 256-row workgroups: half the K/V LDS-DMA pieces per wave and step, half the L2 -> LDS traffic per FLOP
-    if (waves == 8) return launch1((const void*)(fa_fwd_pipe16_kernel<T, 8, CAUSAL>), grid, dim3(512), 0, stream, p);
-    return launch1((const void*)(fa_fwd_pipe16_kernel<T, 4, CAUSAL>), grid, dim3(256), 0, stream, p);
+    if (p.D == 64) {   // 4 waves; qb = 32-row query blocks per wave (the host sized p.nq_tiles for it)
+        if (qb == 2) return launch1((const void*)(fa_fwd_pipe16_kernel<T, 64, 4, 4, CAUSAL>), grid, dim3(256), 0, stream, p);
+        return launch1((const void*)(fa_fwd_pipe16_kernel<T, 64, 4, 2, CAUSAL>), grid, dim3(256), 0, stream, p);
+    }
+    if (waves == 8) return launch1((const void*)(fa_fwd_pipe16_kernel<T, 128, 8, 2, CAUSAL>), grid, dim3(512), 0, stream, p);
+    return launch1((const void*)(fa_fwd_pipe16_kernel<T, 128, 4, 2, CAUSAL>), grid, dim3(256), 0, stream, p);
 }
 
-hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, hipStream_t stream) {
-    if (dtype == 1) return p.causal ? launch_pipe16_c<__bf16, true>(p, waves, stream) : launch_pipe16_c<__bf16, false>(p, waves, stream);
-    return p.causal ? launch_pipe16_c<_Float16, true>(p, waves, stream) : launch_pipe16_c<_Float16, false>(p, waves, stream);
+hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream) {
+    if (dtype == 1) return p.causal ? launch_pipe16_c<__bf16, true>(p, waves, qb, stream) : launch_pipe16_c<__bf16, false>(p, waves, qb, stream);
+    return p.causal ? launch_pipe16_c<_Float16, true>(p, waves, qb, stream) : launch_pipe16_c<_Float16, false>(p, waves, qb, stream);
 }
 
 }  // namespace fa

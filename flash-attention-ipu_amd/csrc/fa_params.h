@@ -67,7 +67,7 @@ hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream)
 hipError_t launch_fwd_f32(const FwdParams& p, hipStream_t stream);   // fa_fwd_f32.hip
 
 hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);   // fa_fwd_pipe.hip
-hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, hipStream_t stream);         // fa_fwd_pipe16.hip (D = 128)
+hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream); // fa_fwd_pipe16.hip
 double probe_mfma_peak(int dtype, int iters, int random_data);
 hipError_t launch_clock_sampler(unsigned long long* out, int spins, hipStream_t stream);   // fa_probe.hip
 

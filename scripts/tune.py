@@ -75,6 +75,10 @@ def candidates(G, L, D, skip, causal, scheds=True):
         for w in (4, 8):
             for b in bunches:
                 out.append({"kernel": "pipe16", "qb": 1, "waves": w, "sched": b})
+    if D == 64 and skip and L >= 256:     # ... at head_dim 64: 4 waves x 32 or 64 rows
+        for qb in (1, 2):
+            for b in bunches:
+                out.append({"kernel": "pipe16", "qb": qb, "waves": 4, "sched": b})
     return out, auto
 
 

@@ -160,15 +160,41 @@ def test_pipelined_kernel_on_16x16x32_mfma_head_dim_128(knobs, dtype, scale, G, 
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("qb", [1, 2])
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 64 ** -0.5), (torch.float16, 64 ** -0.5)])
+@pytest.mark.parametrize("G,L", [(2, 32), (3, 100), (2, 257), (2, 1000), (1, 4608), (9, 600), (2, 2049)])
+def test_pipelined_kernel_on_16x16x32_mfma_head_dim_64(knobs, dtype, scale, G, L, qb):
+    """fa_fwd_pipe16_kernel at head_dim 64 (32 or 64 query rows per wave: one or two diagonal steps per wave): out and
+    logsumexp against the oracle over every path of the step machinery."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    knobs.set("kernel", "pipe16")
+    knobs.set("qb", qb)
+    p = native.plan(G, L, 64, dtype, 1, 1, softmax_scale=scale)
+    assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (4, 4, qb, 128 * qb, 32)
+    x = frozen_randn(SEED + 17 * L + G, (3, G, L, 64)).to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale)
+    q, k, v = x.cuda()
+    out = torch.empty_like(q)
+    lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+    st = (L * 64, 0, 64)
+    native.fwd_strided(q, k, v, out, lse, G, L, 64, 1, st, st, st, st, 1, 1, scale)
+    _check(out, ref, dtype, f"pipe16 {dtype} scale={scale:.3g} qb={qb} {G}x{L}x64")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
-def test_pipe16_growing_logits_force_the_exact_pass(knobs, step):
+@pytest.mark.parametrize("D,qb", [(128, 1), (64, 1), (64, 2)])
+def test_pipe16_growing_logits_force_the_exact_pass(knobs, step, D, qb):
     """The optimistic pass of fa_fwd_pipe16_kernel must detect a P that left the safe range (inf / NaN row sum) and
     redo the workgroup through its exact pass (cdna guide rule 26: force the rare branch)."""
     _, native, with_lse = _mods()
     from oracle import frozen_randn
 
     knobs.set("kernel", "pipe16")
-    G, L, D = 2, 1024, 128
+    knobs.set("qb", qb)
+    G, L = 2, 1024
     x = frozen_randn(SEED + 56, (3, G, L, D)) * 0.05
     u = torch.zeros(D)
     u[:4] = 1.0
@@ -178,7 +204,7 @@ def test_pipe16_growing_logits_force_the_exact_pass(knobs, step):
     x = x.to(torch.bfloat16)
     ref, ref_lse = _oracle(x)
     out, lse = with_lse(x.cuda(), 1, 1)
-    _check(out, ref, torch.bfloat16, f"pipe16 growing logits step={step}")
+    _check(out, ref, torch.bfloat16, f"pipe16 growing logits step={step} D={D} qb={qb}")
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
 
 

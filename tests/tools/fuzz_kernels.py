@@ -54,8 +54,10 @@ def fuzz(cases, seed, log=print):
       for kern in ("dma", "pipe"):
           for qb in (1, 2):
               variants.append({"kernel": kern, "qb": qb, "waves": rng.choice([1, 2, 4, 4, 8]), "sched": rng.choice([1, 2, 8])})
-      if D == 128:      # the pipelined kernel on 16x16x32 MFMAs (head_dim 128 only), 4- and 8-wave workgroups
+      if D == 128:      # the pipelined kernel on 16x16x32 MFMAs: 4- and 8-wave workgroups at head_dim 128,
           variants.append({"kernel": "pipe16", "waves": rng.choice([4, 8]), "sched": rng.choice([1, 2, 8])})
+      else:             # 32 or 64 query rows per wave at head_dim 64
+          variants.append({"kernel": "pipe16", "waves": 4, "qb": rng.choice([1, 2]), "sched": rng.choice([1, 2, 8])})
       ulp = 2.0 ** -6 if dt == torch.bfloat16 else 2.0 ** -9
       ref = None
       if L <= 700:
