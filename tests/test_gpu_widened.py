@@ -114,7 +114,7 @@ def test_grouped_query_long_sequence_pipelined_kernel():
     from oracle import dense_attention_lse
 
     B, H, Hkv, L, D = 4, 16, 4, 4096, 64
-    assert _native.plan(B * H, L, D, torch.bfloat16, 8, 8, softmax_scale=D ** -0.5).kernel == 2
+    assert _native.plan(B * H, L, D, torch.bfloat16, 8, 8, softmax_scale=D ** -0.5).kernel in (2, 4)   # (pipe | pipe16: the measured table decides)
     gen = torch.Generator(device="cuda").manual_seed(3)
     q = torch.randn(B, H, L, D, device="cuda", generator=gen).to(torch.bfloat16)
     k = torch.randn(B, Hkv, L, D, device="cuda", generator=gen).to(torch.bfloat16)

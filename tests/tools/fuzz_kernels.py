@@ -33,6 +33,7 @@ def run(q, k, v, heads, scale, knobs, causal=True):
 def fuzz(cases, seed, log=print):
   rng = random.Random(seed)
   bad = 0
+  only = os.environ.get("FUZZ_ONLY")
   for case in range(cases):
       D = rng.choice([64, 64, 128])
       L = rng.choice([rng.randint(1, 300), rng.randint(1, 1500), rng.randint(1500, 5000)])
@@ -49,7 +50,6 @@ def fuzz(cases, seed, log=print):
       else:
           q = (torch.randn(B, H, L, D, device="cuda") * amp).to(dt)
           k, v = ((torch.randn(B, Hkv, L, D, device="cuda") * amp).to(dt) for _ in range(2))
-      base, base_lse = run(q, k, v, H, scale, {"kernel": "tile"}, causal)
       variants = [{}]
       for kern in ("dma", "pipe"):
           for qb in (1, 2):
@@ -58,6 +58,9 @@ def fuzz(cases, seed, log=print):
           variants.append({"kernel": "pipe16", "waves": rng.choice([4, 8]), "sched": rng.choice([1, 2, 8])})
       else:             # 32 or 64 query rows per wave at head_dim 64
           variants.append({"kernel": "pipe16", "waves": 4, "qb": rng.choice([1, 2]), "sched": rng.choice([1, 2, 8])})
+      if only is not None and case != int(only):
+          continue
+      base, base_lse = run(q, k, v, H, scale, {"kernel": "tile"}, causal)
       ulp = 2.0 ** -6 if dt == torch.bfloat16 else 2.0 ** -9
       ref = None
       if L <= 700:
@@ -73,13 +76,25 @@ def fuzz(cases, seed, log=print):
           # register-staged baseline by the exact sum, and P is rounded relative to different reference maxima: two
           # correct kernels sit up to 2^-8 (bf16) of |V| apart per dominant key, each within the oracle tolerance)
           tol = vs * 1e-2 * (1 if dt == torch.bfloat16 else 0.1) + ulp * (2.0 if amp > 1.0 else 1.0) * base.float().abs()
-          ok = bool(torch.isfinite(out).all()) and bool((d <= tol).all()) and bool(((lse - base_lse).abs() <= (6e-3 if dt == torch.bfloat16 else 2e-3) + 1e-4 * base_lse.abs()).all())   # (bf16: |dLSE| <= 2^-8, see above)
-          if ref is not None:
+          finite = bool(torch.isfinite(out).all())
+          ok = finite and bool((d <= tol).all()) and bool(((lse - base_lse).abs() <= (6e-3 if dt == torch.bfloat16 else 2e-3) + 1e-4 * base_lse.abs()).all())   # (bf16: |dLSE| <= 2^-8, see above)
+          if not ok and ref is None and finite:
+              # two correct kernels may sit further apart than this cheap cross-check allows (near-one-hot rows: P is rounded
+              # relative to different reference maxima): then the oracle decides, whatever the sequence length
+              ref, ref_lse = dense_attention_lse(q.cpu(), k.cpu(), v.cpu(), scale=scale, causal=causal)
+              ref = ref.reshape(B * H, L, D)
+              eb = (base.reshape(B * H, L, D).cpu().double() - ref).abs()
+              log(f"case {case}: a variant differs from the baseline kernel by {d.max().item():.3e}; the baseline sits {eb.max().item():.3e} from the oracle")
+          if ref is not None and finite:      # the oracle is the authority wherever it was computed
               e = (out.reshape(B * H, L, D).cpu().double() - ref).abs()
-              ok = ok and bool((e <= max(1.0, amp) * 1e-2 + 1e-2 * ref.abs()).all())
+              el = (lse.cpu().double() - ref_lse.reshape(B * H, L)).abs()
+              ok = bool((e <= max(1.0, amp) * 1e-2 + 1e-2 * ref.abs()).all()) and bool((el <= (6e-3 if dt == torch.bfloat16 else 2e-3) + 1e-4 * ref_lse.reshape(B * H, L).abs()).all())
           if not ok:
               bad += 1
-              log(f"MISMATCH case {case}: B={B} H={H} Hkv={Hkv} L={L} D={D} {dt} scale={scale:.3g} causal={causal} knobs={env} max|d|={d.max().item():.3e}")
+              excess = (d - tol).max().item()
+              dl = (lse - base_lse).abs()
+              log(f"MISMATCH case {case}: B={B} H={H} Hkv={Hkv} L={L} D={D} {dt} scale={scale:.3g} amp={amp} causal={causal} knobs={env} max|d|={d.max().item():.3e} "
+                  f"max(d - tol)={excess:.3e} max|dLSE|={dl.max().item():.3e} (base LSE there {base_lse.flatten()[dl.argmax()].item():.3f}) finite={bool(torch.isfinite(out).all())}")
       if case % 20 == 0:
           log(f"case {case}: B={B} H={H} L={L} D={D} {dt} ok so far, bad={bad}")
   # fp32 inputs: the fp32 MFMA kernel against the generic kernel (FA_AMD_F32=generic) and the oracle
