@@ -43,6 +43,7 @@ struct Options {
     std::atomic<int> skipmax{-1};   // -1 auto, 0 | 1
     std::atomic<int> f32_generic{0};
     std::atomic<int> table{1};      // 1 = consult the measured tuning table (fa_tuning_table.h), 0 = built-in rules only
+    std::atomic<int> split{0};      // 0 auto, 1 | 2 | 4 kv split groups per workgroup (fa_fwd_dma.hip)
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -59,6 +60,7 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_QB")) g_opt.qb = atoi(e);
         if (const char* e = getenv("FA_AMD_WAVES")) g_opt.waves = atoi(e);
         if (const char* e = getenv("FA_AMD_SCHED")) g_opt.sched = atoi(e);
+        if (const char* e = getenv("FA_AMD_SPLIT")) g_opt.split = atoi(e);
         if (const char* e = getenv("FA_AMD_SKIPMAX")) { if (*e) g_opt.skipmax = atoi(e); }
         if (const char* e = getenv("FA_AMD_F32")) g_opt.f32_generic = e[0] == 'g';
         if (const char* e = getenv("FA_AMD_TABLE")) { if (*e) g_opt.table = atoi(e); }
@@ -95,11 +97,14 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 //       head_dim 64 with 4 waves and qb 1 | 2
 //   't' fa_fwd_tile_kernel  register-staged A/B baseline (debug override only)
 // qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
+// split = kv split groups of a 'd' workgroup (4 waves x 32 rows each, all on the same 128 query rows; fa_fwd_dma.hip): for
+// grids with fewer workgroups than the chip has slots, where the kv loop of the longest q tile is the launch's critical path.
 // Order: debug overrides > measured table (fa_tuning_table.h) > built-in rules; the num_chunks_* bounds and the
 // kernels' own constraints are enforced on whatever was picked.
 struct Selection {
     fa_plan_t plan;
     char which;      // 'd' | 'p' | 't' | 'g' generic | 'f' fp32 MFMA
+    int split;       // kv split groups per workgroup ('d' only; plan.waves counts all of the workgroup's waves)
 };
 
 int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, float scale, int32_t causal,
@@ -114,6 +119,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     const Options& opt = options();
     fa_plan_t* plan = &sel->plan;
     memset(plan, 0, sizeof(*plan));
+    sel->split = 1;
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
     const int64_t g8 = (G + 7) / 8 * 8;
@@ -129,11 +135,14 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         const bool pipe_ok = skip != 0;                   // (the pipelined kernels implement the skip-max arithmetic only)
         const bool want32 = ck < 64;                      // a kv chunk below 64 keys is served by 32-key steps
         char which = 'd';
-        int waves = wmax, qb = 1, sched = 0, source = 0;
+        int waves = wmax, qb = 1, sched = 0, source = 0, split = 1;
         // ---- built-in rules (round-1 measurements)
         const int64_t wgs256 = g8 * ((L + 255) / 256);
         if (D == 64 && pipe_ok && waves == 4 && cq >= 256 && L >= 4096 && wgs256 >= 1024) { which = 'p'; qb = 2; }
         if (D == 128 && skip && waves == 4 && cq >= 256 && L >= 4096 && wgs256 >= 512) waves = 8;
+        // a grid of at most 512 128-row workgroups leaves CUs idle or at one workgroup each: split every q tile's kv loop over
+        // 2 | 4 wave groups of the same workgroup (measured: G=8 L=4096 394 -> 514, G=8 L=8192 754 -> 883, G=4 L=8192 D=128 458 -> 512)
+        if (waves == 4 && cq >= 128 && L >= 1024 && g8 * ((L + 127) / 128) <= 512) split = (D == 64 && L >= 2048) ? 4 : 2;
         // ---- measured table
         if (opt.table) {
             const int64_t wgs128 = g8 * ((L + 127) / 128);
@@ -143,12 +152,14 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
                 if ((r.kernel == 'p' || r.kernel == 'x') && !pipe_ok) continue;
                 if (r.kernel == 'x' && D == 64 && r.waves != 4) continue;
                 which = r.kernel; waves = r.waves; qb = r.qb; sched = r.sched; source = 1;
+                split = r.split > 1 ? r.split : 1;
                 break;
             }
         }
         // ---- debug overrides
-        const int fk = opt.kernel, fw = opt.waves, fq = opt.qb;
-        if (fk || fw || fq || opt.sched > 0 || (dtype == FA_DTYPE_F16 && opt.skipmax >= 0)) source = 2;
+        const int fk = opt.kernel, fw = opt.waves, fq = opt.qb, fs = opt.split;
+        if (fk || fw || fq || fs || opt.sched > 0 || (dtype == FA_DTYPE_F16 && opt.skipmax >= 0)) source = 2;
+        if (fk || fw || fq) split = 1;                     // (a forced tile drops the table's split unless split is forced too)
         if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
         if (fk == 't') { which = 't'; qb = 1; }
         else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
@@ -157,15 +168,18 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (fq == 1) qb = 1;
         if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
         if (fq == 2 && fk == 'x' && D == 64) qb = 2;        // (a forced variant ignores the chunk bound, as the forced kernel does)
+        if (fs == 1) split = 1;
+        if (fs > 1 && (fk == 0 || fk == 'd')) { which = 'd'; waves = 4; qb = 1; split = fs; }
         // ---- constraints of the kernels
-        if (want32 && pipe_ok && which == 'd' && fk == 0) { which = 'p'; if (waves > 4 && D != 128) waves = 4; }
+        if (want32 && pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
         if (which == 'p' && ((waves > 4 && D != 128) || !pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
         if (which == 'x' && !pipe_ok) which = 'd';
         if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
         if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
         if (which == 't' && waves > 4) waves = 4;
+        if (split > 1 && !(which == 'd' && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
         plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : 0;
-        plan->waves = waves;
+        plan->waves = waves * split;
         plan->qb = qb;
         plan->block_q = 32 * waves * qb;
         plan->block_kv = (which == 'p' || which == 'x') ? 32 : 64;
@@ -174,7 +188,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
         plan->lds_bytes = which == 'x' ? 8 * 32 * D * 2 + 16
                           : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
-                                       : 2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64);
+                                       : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
         // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
         // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
         {
@@ -187,6 +201,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
             plan->sched = (int32_t)bunch;
         }
         sel->which = which;
+        sel->split = split;
     } else if (f32_ok) {
         plan->kernel = 3;
         plan->waves = 4;
@@ -224,7 +239,7 @@ struct OptionName { const char* name; std::atomic<int> Options::*field; int lo, 
 const OptionName kOptionNames[] = {
     {"kernel", &Options::kernel, 0, 127}, {"qb", &Options::qb, 0, 2}, {"waves", &Options::waves, 0, 8},
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
-    {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1},
+    {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
 };
 
 }  // namespace
@@ -264,6 +279,7 @@ int fa_debug_set_option(const char* name, int32_t value) {
             return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x' or 't'");
         if (o.field == &Options::waves && !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: waves must be 0, 1, 2, 4 or 8");
+        if (o.field == &Options::split && value == 3) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: split must be 0, 1, 2 or 4");
         (g_opt.*(o.field)).store(value);
         return FA_OK;
     }
@@ -369,7 +385,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, plan.qb, st)
-                   : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves, plan.qb, st)
+                   : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves / sel.split, plan.qb, sel.split, st)
                                       : fa::launch_fwd_tile(p, dtype, plan.waves, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;

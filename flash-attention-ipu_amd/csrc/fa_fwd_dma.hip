@@ -29,7 +29,13 @@ namespace fa {
 
 // (the body lives in a __device__ function: the buffer/LDS-DMA builtins do not exist for the host pass,
 // and a __global__ template that names them loses its host-side launch stub)
-template <typename T, int D, int NWAVES, bool SKIP, int QB>
+//
+// SPLIT > 1 (split-KV inside the workgroup, for grids that cannot fill the chip): SPLIT groups of NWAVES waves own the SAME
+// query rows; group s streams the kv tiles s, s + SPLIT, ... through LDS buffers of its own, in lock step with the others
+// (one workgroup barrier per tile round), and the groups' (m, l, O) are merged through LDS before the epilogue - the kv
+// loop of a q tile, the critical path of a launch with fewer workgroups than slots, shrinks SPLIT-fold with no second
+// kernel and no partial results in HBM.
+template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT>
 __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -47,9 +53,9 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     constexpr int DT = D / 32;
     static_assert(PIECES % NWAVES == 0 && PPW >= 1, "pieces must split evenly over the waves");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KTILE_B + 2 * VTILE_B];  // K0 K1 V0 V1
-    unsigned char* const smem_v = smem + 2 * KTILE_B;
-    __shared__ int flags[NWAVES];
+    constexpr int GROUP_B = 2 * KTILE_B + 2 * VTILE_B;                                      // K0 K1 V0 V1 of one group
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[SPLIT * GROUP_B];
+    __shared__ int flags[NWAVES * SPLIT];
 
     const int b = blockIdx.x;
     const int nq = p.nq_tiles;
@@ -78,7 +84,11 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base -> M0)
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base -> M0)
+    const int ws = SPLIT == 1 ? 0 : wave_all / NWAVES;               // kv split group of this wave
+    const int wave = SPLIT == 1 ? wave_all : wave_all - ws * NWAVES; // its row block inside the group
+    unsigned char* const smem = smem_all + ws * GROUP_B;
+    unsigned char* const smem_v = smem + 2 * KTILE_B;
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.H, hh = g - bb * p.H;
     const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
@@ -270,14 +280,14 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #define FA_COMPUTE(T_, BUF_, MODE_)                                                                \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
-        if (wave_active && kv0 <= wave_kv_last) {                                                  \
+        if (wave_active && (SPLIT == 1 || (T_) < n_tiles) && kv0 <= wave_kv_last) {                \
             f32x16 s0[QB], s1[QB];                                                                 \
             if (FA_DMA_ABL != 5) { FA_QK(BUF_) } else {                                            \
                 _Pragma("unroll") for (int b = 0; b < QB; ++b)                                     \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[b][e] = o[b][0][e]; s1[b][e] = o[b][1][e]; } \
             }                                                                                      \
             if ((MODE_) == 0) {                                                                    \
-                if (kv0 == 0) FA_MAX_RESCALE(0.0f)       /* first tile: m = -inf -> exact max */    \
+                if ((T_) < SPLIT) FA_MAX_RESCALE(0.0f)   /* the group's first tile: m = -inf -> exact max */ \
             } else {                                                                               \
                 FA_MAX_RESCALE(RESCALE_THR)                                                        \
             }                                                                                      \
@@ -291,16 +301,16 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // one pass over the workgroup's kv tiles (the kv loop is unrolled by two: LDS addresses are base + immediate)
 #define FA_PASS(MODE_)                                                                             \
     {                                                                                              \
-        FA_DMA_TILE(0, 0)                                                                          \
+        if (SPLIT == 1 || ws < n_tiles) FA_DMA_TILE(ws, 0)                                         \
         FA_TILE_BARRIER()                                                                          \
-        FA_STAMP(st1_)                                                                             \
-        for (int t = 0; t < n_tiles; t += 2) {                                                     \
-            if (t + 1 < n_tiles) FA_DMA_TILE(t + 1, 1)                                             \
+        for (int t0 = 0; t0 < n_tiles; t0 += 2 * SPLIT) {       /* (workgroup-uniform bounds) */   \
+            const int t = t0 + ws;                              /* this group's tile of the round */ \
+            if (t + SPLIT < n_tiles) FA_DMA_TILE(t + SPLIT, 1)                                     \
             FA_COMPUTE(t, 0, MODE_)                                                                \
             FA_TILE_BARRIER()                                                                      \
-            if (t + 1 < n_tiles) {                                                                 \
-                if (t + 2 < n_tiles) FA_DMA_TILE(t + 2, 0)                                         \
-                FA_COMPUTE(t + 1, 1, MODE_)                                                        \
+            if (t0 + SPLIT < n_tiles) {                                                            \
+                if (t + 2 * SPLIT < n_tiles) FA_DMA_TILE(t + 2 * SPLIT, 0)                         \
+                FA_COMPUTE(t + SPLIT, 1, MODE_)                                                    \
                 FA_TILE_BARRIER()                                                                  \
             }                                                                                      \
         }                                                                                          \
@@ -319,11 +329,11 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         bool bad = false;
 #pragma unroll
         for (int b = 0; b < QB; ++b) bad |= wave_active && sum_left_safe_range(lsum[b][0]);
-        flags[wave] = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
+        flags[wave_all] = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
         __syncthreads();
         int any_bad = 0;
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) any_bad |= flags[w];
+        for (int w = 0; w < NWAVES * SPLIT; ++w) any_bad |= flags[w];
         if (any_bad) {
             __syncthreads();   // (flags are rewritten only by a later launch; this orders the LDS buffer reuse)
             FA_RESET_STATE()
@@ -343,13 +353,55 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #undef FA_PV
 
     FA_STAMP(st2_)
+    // ---- split-KV: fold the other groups' (m, l, O) into group 0, one group at a time, through LDS (the K/V buffers are free
+    // after the pass's last barrier).  The exchange area lies behind the epilogue's row slabs; a lane's values sit at
+    // [value][lane], so writes and reads are conflict-free.  A group that saw no key of a row hands over m = -inf, l = 0,
+    // O = 0: its weight 2^((m - m_new) c) is 0.
+    if constexpr (SPLIT > 1) {
+        constexpr int NVAL = QB * (DT * 16 + 2);
+        float* xb = (float*)(smem_all + NWAVES * WQ * ROWB) + wave * (NVAL * 64) + lane;
+        static_assert(NWAVES * WQ * ROWB + NWAVES * NVAL * 64 * 4 <= SPLIT * GROUP_B, "exchange area must fit the K/V buffers");
+        for (int sgrp = 1; sgrp < SPLIT; ++sgrp) {
+            __syncthreads();
+            if (ws == sgrp) {
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    xb[(b * (DT * 16 + 2) + 0) * 64] = m[b];
+                    xb[(b * (DT * 16 + 2) + 1) * 64] = lsum[b][0];
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) xb[(b * (DT * 16 + 2) + 2 + dt * 16 + e) * 64] = o[b][dt][e];
+                }
+            }
+            __syncthreads();
+            if (ws == 0 && wave_active) {
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+                    const float m1 = xb[(b * (DT * 16 + 2) + 0) * 64], l1 = xb[(b * (DT * 16 + 2) + 1) * 64];
+                    const float mn = max2(m[b], m1);
+                    const float a0 = fast_exp2((m[b] - mn) * c), a1 = fast_exp2((m1 - mn) * c);
+                    m[b] = mn;
+                    const float ln = lsum[b][0] * a0 + l1 * a1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) lsum[b][j] = ln;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            o[b][dt][e] = o[b][dt][e] * a0 + xb[(b * (DT * 16 + 2) + 2 + dt * 16 + e) * 64] * a1;
+                }
+            }
+        }
+        if (ws != 0) return;
+    }
     // ---- epilogue: O /= l, staged through LDS so that every store instruction writes whole rows.
     // (A lane owns 8-byte pieces of ONE row at a 16-byte pitch; stored directly, one instruction touches
     // 32 rows x 2 pieces.)  The K buffers are free after the last barrier; each wave uses a private
     // 32-row slab [32][D] with the 16-byte chunk index XORed by the row, so writes and reads are
     // conflict-free and no workgroup barrier is needed.
     if (!wave_active) return;
-    unsigned char* slab = smem + wave * (32 * ROWB);
+    unsigned char* slab = smem_all + wave * (WQ * ROWB);
     constexpr int CPR = D / 8;   // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;   // rows per store instruction (8 at D=64, 4 at D=128)
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
@@ -399,40 +451,49 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #endif
 }
 
-template <typename T, int D, int NWAVES, bool SKIP, int QB>
-__global__ __launch_bounds__(NWAVES * 64) void fa_fwd_dma_kernel(const FwdParams p) {
-    fa_fwd_dma_body<T, D, NWAVES, SKIP, QB>(p);
+template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT>
+__global__ __launch_bounds__(NWAVES * SPLIT * 64) void fa_fwd_dma_kernel(const FwdParams p) {
+    fa_fwd_dma_body<T, D, NWAVES, SKIP, QB, SPLIT>(p);
 }
 
 template <typename T, int D, bool SKIP>
-static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, hipStream_t stream) {
+static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, int split, hipStream_t stream) {
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
+    if (split == 2) return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 2>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    if (split == 4) {   // 16 waves = 4 per SIMD: needs the 128-register kernel (head_dim 64)
+        if constexpr (D == 64) {
+            return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 4>), dim3((unsigned)grid), dim3(1024), 0, stream, p);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (qb == 2) {   // 64 query rows per wave (head_dim 64, 4 waves): half the LDS operand reads and half the K/V DMA per FLOP
         if constexpr (D == 64) {
-            return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+            return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 2, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         } else {
             return hipErrorInvalidValue;
         }
     }
     hipError_t e;
     switch (waves) {
-        case 8: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 8, SKIP, 1>), dim3((unsigned)grid), dim3(512), 0, stream, p); break;
-        case 4: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 2: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 2, SKIP, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
-        default: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 1, SKIP, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
+        case 8: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 8, SKIP, 1, 1>), dim3((unsigned)grid), dim3(512), 0, stream, p); break;
+        case 4: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 2, SKIP, 1, 1>), dim3((unsigned)grid), dim3(128), 0, stream, p); break;
+        default: e = launch1((const void*)(fa_fwd_dma_kernel<T, D, 1, SKIP, 1, 1>), dim3((unsigned)grid), dim3(64), 0, stream, p); break;
     }
     return e;
 }
 
-// qb = 32-row query blocks per wave (1, or 2 for head_dim 64 with 4 waves; the host sized p.nq_tiles for it)
-hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream) {
+// waves = waves per kv split group (the workgroup has waves x split); qb = 32-row query blocks per wave (1, or 2 for head_dim 64
+// with 4 waves); split = kv split groups (1; 2 | 4 with 4 waves and qb 1).  The host sized p.nq_tiles for 32 waves qb rows.
+hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, int split, hipStream_t stream) {
     if (dtype == 1) {   // bf16: always skip-max
-        return p.D == 64 ? launch_dma_w<__bf16, 64, true>(p, waves, qb, stream) : launch_dma_w<__bf16, 128, true>(p, waves, qb, stream);
+        return p.D == 64 ? launch_dma_w<__bf16, 64, true>(p, waves, qb, split, stream) : launch_dma_w<__bf16, 128, true>(p, waves, qb, split, stream);
     }
     if (p.skipmax) {
-        return p.D == 64 ? launch_dma_w<_Float16, 64, true>(p, waves, qb, stream) : launch_dma_w<_Float16, 128, true>(p, waves, qb, stream);
+        return p.D == 64 ? launch_dma_w<_Float16, 64, true>(p, waves, qb, split, stream) : launch_dma_w<_Float16, 128, true>(p, waves, qb, split, stream);
     }
-    return p.D == 64 ? launch_dma_w<_Float16, 64, false>(p, waves, qb, stream) : launch_dma_w<_Float16, 128, false>(p, waves, qb, stream);
+    return p.D == 64 ? launch_dma_w<_Float16, 64, false>(p, waves, qb, split, stream) : launch_dma_w<_Float16, 128, false>(p, waves, qb, split, stream);
 }
 
 }  // namespace fa

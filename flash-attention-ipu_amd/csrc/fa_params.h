@@ -62,7 +62,7 @@ hipError_t launch_bwd_generic(const BwdParams& p, int dtype, hipStream_t stream)
 hipError_t launch_bwd_f32(const BwdParams& p, hipStream_t stream);   // fa_bwd_f32.hip: fp32, D in {64, 128}
 
 hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream);
-hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);
+hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, int split, hipStream_t stream);
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream);
 hipError_t launch_fwd_f32(const FwdParams& p, hipStream_t stream);   // fa_fwd_f32.hip
 

@@ -75,15 +75,16 @@ typedef struct fa_plan_t {
     int32_t kernel;      /* 0 = MFMA kernel, 64-key tiles (bf16/f16, D in {64,128}), 1 = generic kernel,
                             2 = MFMA kernel, software-pipelined 32-key steps,
                             3 = fp32 MFMA kernel (fp32 inputs, D in {64,128}, 16-byte rows),
-                            4 = software-pipelined kernel on v_mfma_f32_16x16x32 (bf16/f16, D = 128) */
+                            4 = software-pipelined kernel on v_mfma_f32_16x16x32 (bf16/f16, D in {64,128}) */
     int32_t block_q;     /* q rows per workgroup */
     int32_t block_kv;    /* keys per LDS tile / step */
-    int32_t waves;       /* wavefronts per workgroup */
+    int32_t waves;       /* wavefronts per workgroup; waves * qb * 32 / block_q = kv split groups of the workgroup (1, or 2 | 4
+                            when a grid too small to fill the chip is served by splitting each q tile's kv loop) */
     int32_t chunk_q;     /* L / num_chunks_q  : the reference's chunkedQueryLen */
     int32_t chunk_kv;    /* L / num_chunks_kv : the reference's chunkedKVLen */
     int64_t grid;        /* workgroups launched */
     int64_t lds_bytes;   /* LDS per workgroup */
-    int32_t qb;          /* 32-row query blocks per wave (block_q = 32 * waves * qb) */
+    int32_t qb;          /* 32-row query blocks per wave (block_q = 32 * waves * qb / kv split groups) */
     int32_t sched;       /* groups per XCD bunch of the block -> (group, q tile) map */
     int32_t skipmax;     /* 1 = reference max fixed on a wave's first tile, optimistic pass + exact fallback pass
                             (bf16 always; f16 when softmax_scale <= 0.25), 0 = per-tile row max with lazy rescale */
@@ -128,10 +129,11 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
 /* TEST / TUNING ONLY - not part of the data path contract.  Overrides one knob of the tile plan for the whole
  * process until set back to its "auto" value.  The FA_AMD_* environment variables of round 1 are read ONCE, at the
  * first call into the library, into the same knobs; nothing reads the environment per launch.
- *   "kernel"  0 auto | 'd' (64-key tiles, LDS-DMA) | 'p' (pipelined 32-key steps) | 'x' (the same on 16x16x32 MFMAs,
- *             head_dim 128) | 't' (register-staged baseline)
+ *   "kernel"  0 auto | 'd' (64-key tiles, LDS-DMA) | 'p' (pipelined 32-key steps) | 'x' (the same on 16x16x32 MFMAs)
+ *             | 't' (register-staged baseline)
  *   "qb"      0 auto | 1 | 2        "waves"  0 auto | 1 | 2 | 4 | 8        "sched"  0 auto | n >= 1
  *   "skipmax" -1 auto | 0 | 1       "f32_generic" 0 | 1                    "table"  1 use the tuning table | 0 rules only
+ *   "split"   0 auto | 1 | 2 | 4    kv split groups per workgroup ('d' kernel, 4 waves x 32 rows per group)
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
 int fa_debug_set_option(const char* name, int32_t value);
 int fa_debug_get_option(const char* name, int32_t* value);

@@ -75,6 +75,10 @@ def candidates(G, L, D, skip, causal, scheds=True):
         for w in (4, 8):
             for b in bunches:
                 out.append({"kernel": "pipe16", "qb": 1, "waves": w, "sched": b})
+    wg128 = (G + 7) // 8 * 8 * ((L + 127) // 128)
+    if wg128 <= 2048 and L >= 256:        # under-filled grids: kv split groups inside the dma kernel's workgroup
+        for sp in ((2, 4) if D == 64 else (2,)):
+            out.append({"kernel": "dma", "qb": 1, "waves": 4, "sched": auto, "split": sp})
     if D == 64 and skip and L >= 256:     # ... at head_dim 64: 4 waves x 32 or 64 rows
         for qb in (1, 2):
             for b in bunches:
@@ -135,13 +139,13 @@ def emit(args):
                 med, n = measure(shape, cands, rounds=3 if args.quick else 5)
                 best = min(med, key=med.get)
                 # prefer the automatic L2 bunch unless another one is clearly (> 1 %) faster for the same tile
-                same_tile_auto = [i for i, c in enumerate(cands) if all(c[k] == cands[best][k] for k in ("kernel", "qb", "waves")) and c["sched"] == auto]
+                same_tile_auto = [i for i, c in enumerate(cands) if all(c.get(k, 1) == cands[best].get(k, 1) for k in ("kernel", "qb", "waves", "split")) and c["sched"] == auto]
                 sched = cands[best]["sched"]
                 if same_tile_auto and med[same_tile_auto[0]] <= med[best] * 1.01:
                     best, sched = same_tile_auto[0], 0
                 c = cands[best]
                 rows.append((D, skip, causal, L_lo, L_hi, wg, {"dma": "d", "pipe": "p", "pipe16": "x"}[c["kernel"]], c["waves"], c["qb"], sched, L, G,
-                             shape.flops / med[best] / 1e9))
+                             shape.flops / med[best] / 1e9, c.get("split", 1)))
                 log.append(f"D={D} skip={skip} causal={causal} L={L} G={G} wg128={wg}: {c} sched->{sched}  "
                            f"{shape.flops / med[best] / 1e9:.0f} TFLOP/s (runner-up {sorted(med.values())[1] / med[best]:.3f}x time)")
                 print(log[-1], flush=True)
@@ -161,11 +165,11 @@ def emit(args):
     head = TABLE.read_text().split("// generated on:")[0]
     body = [f"// generated on: {stamp}, {dev}, {len(out_rows)} rows, by scripts/tune.py --emit{' --quick' if args.quick else ''}",
             "static const TuneRow kTuneTable[] = {",
-            "    //  D  skip causal   L_lo        L_hi        wg_lo                wg_hi          kernel waves qb sched    measured at (L, G): TFLOP/s"]
+            "    //  D  skip causal   L_lo        L_hi        wg_lo                wg_hi          kernel waves qb sched split   measured at (L, G): TFLOP/s"]
     for r, lo, hi in out_rows:
-        D, skip, causal, L_lo, L_hi, wg, kern, waves, qb, sched, L, G, tf = r
-        body.append(f"    {{{D:4d}, {skip}, {causal}, {L_lo:10d}, {L_hi:10d}, {lo:20d}ll, {hi:20d}ll, '{kern}', {waves}, {qb}, {sched:3d}}},   // L={L} G={G}: {tf:.0f}")
-    body += ["    {0, 0, 0, 0, 0, 0, 0, 'd', 0, 0, 0},   // sentinel (D = 0 never matches)", "};", "", "}  // namespace fa", "#endif", ""]
+        D, skip, causal, L_lo, L_hi, wg, kern, waves, qb, sched, L, G, tf, split = r
+        body.append(f"    {{{D:4d}, {skip}, {causal}, {L_lo:10d}, {L_hi:10d}, {lo:20d}ll, {hi:20d}ll, '{kern}', {waves}, {qb}, {sched:3d}, {split}}},   // L={L} G={G}: {tf:.0f}")
+    body += ["    {0, 0, 0, 0, 0, 0, 0, 'd', 0, 0, 0, 0},   // sentinel (D = 0 never matches)", "};", "", "}  // namespace fa", "#endif", ""]
     TABLE.write_text(head + "\n".join(body))
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
     (ROOT / "gpurun_out" / "tune_log.txt").write_text("\n".join(log) + "\n")

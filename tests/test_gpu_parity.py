@@ -160,6 +160,30 @@ def test_pipelined_kernel_on_16x16x32_mfma_head_dim_128(knobs, dtype, scale, G, 
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("D,split", [(64, 2), (64, 4), (128, 2)])
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.float16, 1.0), (torch.float16, 0.125)])
+@pytest.mark.parametrize("G,L", [(2, 32), (3, 100), (2, 257), (2, 1000), (1, 4608), (9, 600), (2, 2049)])
+def test_split_kv_inside_the_workgroup(knobs, D, split, dtype, scale, G, L):
+    """fa_fwd_dma_kernel with 2 | 4 kv split groups per workgroup (each group streams every split-th kv tile for the same
+    128 query rows; (m, l, O) merged through LDS): out and logsumexp against the oracle - groups with no tile at all
+    (short rows), with an odd tile count, ragged last tiles; skip-max (bf16, scaled f16) and exact-max (unscaled f16)."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    knobs.set("split", split)
+    p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale)
+    assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (0, 4 * split, 1, 128, 64)
+    x = (frozen_randn(SEED + 19 * L + G + D, (3, G, L, D)) * (0.5 if dtype == torch.float16 and scale == 1.0 else 1.0)).to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale)
+    q, k, v = x.cuda()
+    out = torch.empty_like(q)
+    lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+    st = (L * D, 0, D)
+    native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, scale)
+    _check(out, ref, dtype, f"split-kv {split} {dtype} scale={scale:.3g} {G}x{L}x{D}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("qb", [1, 2])
 @pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 64 ** -0.5), (torch.float16, 64 ** -0.5)])
 @pytest.mark.parametrize("G,L", [(2, 32), (3, 100), (2, 257), (2, 1000), (1, 4608), (9, 600), (2, 2049)])
@@ -571,7 +595,7 @@ def test_cpp_caller_of_the_c_abi(tmp_path):
     assert res.returncode == 0 and "PASSED" in res.stdout, res.stdout + res.stderr
 
 
-@pytest.mark.parametrize("kernel,qb", [("", 0), ("dma", 2), ("pipe", 1), ("pipe", 2)])
+@pytest.mark.parametrize("kernel,qb", [("", 0), ("dma", 2), ("pipe", 1), ("pipe", 2), ("split2", 1), ("split4", 1)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
 def test_growing_logits_force_the_redo_branch(knobs, dtype, step, kernel, qb):
@@ -584,7 +608,9 @@ def test_growing_logits_force_the_redo_branch(knobs, dtype, step, kernel, qb):
     fa, _, _ = _mods()
     from oracle import frozen_randn
 
-    if kernel:
+    if kernel.startswith("split"):      # kv split groups: the groups' reference maxima differ by up to 3 tiles of growth
+        knobs.set("split", int(kernel[5:]))
+    elif kernel:
         knobs.set("FA_AMD_KERNEL", kernel)
         knobs.set("FA_AMD_QB", str(qb))
 

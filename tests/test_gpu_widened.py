@@ -54,15 +54,18 @@ def test_noncausal_forward_vs_oracle(dtype, B, H, L, D):
 
 
 @pytest.mark.parametrize("kernel,qb,waves", [("dma", 1, 4), ("dma", 2, 4), ("dma", 1, 8), ("dma", 1, 1), ("tile", 1, 4),
-                                             ("pipe", 2, 4), ("pipe", 1, 4), ("pipe", 1, 2), ("pipe16", 1, 4), ("pipe16", 2, 4)])
+                                             ("pipe", 2, 4), ("pipe", 1, 4), ("pipe", 1, 2), ("pipe16", 1, 4), ("pipe16", 2, 4), ("split2", 1, 4), ("split4", 1, 4)])
 def test_noncausal_every_kernel_variant(knobs, kernel, qb, waves):
     """is_causal=False through every MFMA kernel (the mask mode is a template parameter of the pipelined kernels: no
     dead block in the last step, only keys past L masked), ragged L, unscaled bf16 logits."""
     from oracle import dense_attention_lse, frozen_randn
 
-    knobs.set("kernel", kernel)
-    knobs.set("qb", qb)
-    knobs.set("waves", waves)
+    if kernel.startswith("split"):      # the dma kernel with 2 | 4 kv split groups per workgroup
+        knobs.set("split", int(kernel[5:]))
+    else:
+        knobs.set("kernel", kernel)
+        knobs.set("qb", qb)
+        knobs.set("waves", waves)
     B, H, L, D = 1, 3, 600, 64
     x = (frozen_randn(SEED + 5, (3, B, H, L, D)) * 0.6).to(torch.bfloat16)
     ref, ref_lse = dense_attention_lse(x[0], x[1], x[2], scale=1.0, causal=False)

@@ -117,13 +117,14 @@ def test_measured_tuning_table_is_consulted_and_bounded_by_the_chunks(native):
     import re
 
     text = (ROOT / "flash-attention-ipu_amd" / "csrc" / "fa_tuning_table.h").read_text()
-    rows = re.findall(r"\{\s*(\d+), (\d), (\d),\s*(\d+),\s*(\d+),\s*(\d+)ll,\s*(\d+)ll, '(\w)', (\d), (\d),\s*(\d+)\}", text)
+    rows = re.findall(r"\{\s*(\d+), (\d), (\d),\s*(\d+),\s*(\d+),\s*(\d+)ll,\s*(\d+)ll, '(\w)', (\d), (\d),\s*(\d+)(?:, (\d))?\}", text)
     rows = [r for r in rows if int(r[0]) != 0]
     if not rows:
         pytest.skip("no measured rows in this build")
     assert "generated on:" in text and len(rows) >= 20
     checked = 0
-    for D, skip, causal, L_lo, L_hi, wg_lo, wg_hi, kern, waves, qb, sched in rows[::7]:
+    for D, skip, causal, L_lo, L_hi, wg_lo, wg_hi, kern, waves, qb, sched, split in rows[::7]:
+        split = max(1, int(split or 1))      # (kv split groups: plan.waves counts all of the workgroup's waves)
         D, L_lo, L_hi, wg_lo, wg_hi, waves, qb = int(D), int(L_lo), int(L_hi), int(wg_lo), int(wg_hi), int(waves), int(qb)
         L = 128 * ((max(L_lo, 256) + 127) // 128)
         if L > min(L_hi, 1 << 20):
@@ -133,7 +134,7 @@ def test_measured_tuning_table_is_consulted_and_bounded_by_the_chunks(native):
             continue
         dt = torch.bfloat16 if skip == "1" else torch.float16
         p = native.plan(G, L, D, dt, 1, 1, causal=causal == "1")
-        assert p.source == 1 and (p.kernel, p.waves, p.qb) == ({"p": 2, "x": 4, "d": 0}[kern], waves, qb), (D, skip, causal, L, G)
+        assert p.source == 1 and (p.kernel, p.waves, p.qb) == ({"p": 2, "x": 4, "d": 0}[kern], waves * split, qb), (D, skip, causal, L, G)
         with native.debug_options(table=0):
             assert native.plan(G, L, D, dt, 1, 1, causal=causal == "1").source == 0
         checked += 1
@@ -165,8 +166,16 @@ def _check_builtin_rules(native):
     assert (p.kernel, p.block_q, p.block_kv) == (0, 128, 64)
     p = native.plan(16, 32768, 128, torch.bfloat16, 16, 16)    # config 3: head_dim 128, long, bf16 -> 8 waves = 256 rows
     assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 256, 8, 2 * 16384 + 8 * (4096 + 64))
-    p = native.plan(16, 2048, 128, torch.bfloat16, 8, 8)
+    p = native.plan(64, 2048, 128, torch.bfloat16, 8, 8)
     assert (p.kernel, p.block_q, p.waves) == (0, 128, 4)
+    # a grid of <= 512 128-row workgroups cannot fill the chip: the kv loop of every q tile is split over 2 | 4 wave groups
+    # of the same workgroup (plan.waves counts them all; block_q stays 128)
+    p = native.plan(16, 2048, 128, torch.bfloat16, 8, 8)
+    assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 128, 8, 2 * (2 * 16384 + 8 * (4096 + 64)))
+    p = native.plan(8, 4096, 64, torch.bfloat16, 8, 8)
+    assert (p.kernel, p.block_q, p.waves, p.grid) == (0, 128, 16, 8 * 32)
+    p = native.plan(8, 1024, 64, torch.bfloat16, 8, 8)
+    assert (p.kernel, p.block_q, p.waves) == (0, 128, 8)
     assert native.plan(4, 4096, 64, torch.float16, 64, 64).block_q == 64     # 64-row chunks honoured
     # num_chunks_kv bounds the kv step: a chunk below 64 keys is served by 32-key steps where the pipelined kernel
     # applies (skip-max arithmetic, causal); 64-key tiles otherwise (the result never depends on the chunking)
