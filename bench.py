@@ -48,6 +48,7 @@ CONFIGS = {
     "cfg2_f16": (128, 4096, 64, "f16", (8, 8)),
     "cfg3": (16, 32768, 128, "bf16", (16, 16)),      # configs[2] long context
     "cfg5_shard": (256, 8192, 64, "bf16", (16, 8)),  # configs[4] per-GPU shard at 8 GPUs
+    "small_grid": (8, 4096, 64, "bf16", (8, 8)),     # not a BASELINE config: 256 workgroups on 256 CUs (split-KV plan)
     # total work fixed ("strong"): G is the TOTAL group count, G/N per rank
     "cfg5": (2048, 8192, 64, "bf16", (16, 8)),       # configs[4]: batch 64 x heads 32, seq 8192, head_dim 64
 }
@@ -157,7 +158,8 @@ def secondary_attention(name, dev, steps=20, warmup=5):
     tf = flops / (ms * 1e-3) / 1e12
     return {"metric": f"fwd_attention_tflops_causal_L{L}_D{D}", "value": round(tf, 2), "unit": "TFLOP/s", "dtype": dname,
             "config": {"workload": f"{name}: packed qkv [3,{G},{L},{D}] {dname}, causal, num_chunks=({nq},{nk})",
-                       "tile": f"{plan.block_q} query rows x {plan.block_kv} keys ({plan.waves} waves, {plan.qb} query blocks per wave)"},
+                       "tile": f"{plan.block_q} query rows x {plan.block_kv} keys ({plan.waves} waves, {plan.qb} query blocks per wave"
+                               + (f", {32 * plan.waves * plan.qb // plan.block_q} kv split groups)" if 32 * plan.waves * plan.qb > plan.block_q else ")")},
             "steps": steps, "warmup": warmup,
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / PEAK_TFLOPS, 4), "traffic": profiled_traffic(name, plan)[0],
@@ -520,7 +522,7 @@ def main():
         }
         if world == 1 and not args.no_secondary and not strong:
             sec = {}
-            for name in ("cfg3", "cfg5_shard"):
+            for name in ("cfg3", "cfg5_shard", "small_grid"):
                 if name != args.config:
                     try:
                         sec[name] = secondary_attention(name, dev)
