@@ -303,6 +303,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     {                                                                                              \
         if (SPLIT == 1 || ws < n_tiles) FA_DMA_TILE(ws, 0)                                         \
         FA_TILE_BARRIER()                                                                          \
+        FA_STAMP(st1_)                                                                             \
         for (int t0 = 0; t0 < n_tiles; t0 += 2 * SPLIT) {       /* (workgroup-uniform bounds) */   \
             const int t = t0 + ws;                              /* this group's tile of the round */ \
             if (t + SPLIT < n_tiles) FA_DMA_TILE(t + SPLIT, 1)                                     \

@@ -3,7 +3,7 @@
 // arithmetic with an exact fallback pass, PV-first step order with the next step's V^T fragments requested mid-step).
 //
 // Why a second MFMA shape: the forward is power-bound - the in-kernel clock under the pipelined 32x32x16 kernels is
-// 1.4-1.65 GHz of 2.4 (scripts/phase_times.py, profiles/r02_cfg3) - and on this chip the clock held under a bf16 MFMA
+// 1.65-1.75 GHz of 2.4 (scripts/phase_times.py, profiles/r02_cfg3) - and on this chip the clock held under a bf16 MFMA
 // stream depends on the MFMA shape: 16x16x32 delivers 1.12-1.14x the FLOP/s of 32x32x16 at equal cycles with operands
 // read from LDS (MI355X_MICROARCH.md, DVFS give-back item 7; cdna_hip_programming.md rule 28).  The shape costs issue
 // slots (twice the MFMAs, each holding the issue port 8 cycles):

@@ -53,9 +53,15 @@ def launch():
     assert rc == 0, lib.fa_last_error().decode()
 
 
-for _ in range(20):
-    launch()
-torch.cuda.synchronize()
+import time  # noqa: E402
+t_end = time.time() + 2.5          # the clock the chip holds under this load settles over seconds, not launches (guide, DVFS item 6)
+n_warm = 0
+while time.time() < t_end:
+    for _ in range(50):
+        launch()
+    torch.cuda.synchronize()
+    n_warm += 50
+print(f"warm-up: {n_warm} launches over 2.5 s")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 launch()
