@@ -94,8 +94,8 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void fa_bwd_f32_dq_kernel(const Bwd
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.H, hh = g - bb * p.H;
-    const float* __restrict__ kg = (const float*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
-    const float* __restrict__ vg = (const float*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+    const float* __restrict__ kg = (const float*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;   // (grouped-query K/V head)
+    const float* __restrict__ vg = (const float*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
     const int q_row0 = qi * BQ + wave * 32;
     const int qrow = q_row0 + r;
@@ -199,15 +199,18 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void fa_bwd_f32_dkdv_kernel(const B
     __shared__ float rowc[2][2 * BQ];          // per q tile: lse * log2(e) for 32 rows, then Dsum for 32 rows
 
     int g, kb;
-    if (!f32_block_map(p.G8, p.G, p.sched, p.nk_tiles, false, g, kb)) return;   // key block 0 is the heaviest
+    // (grouped-query attention: one K/V head per workgroup, its kv_div query heads swept one after the other as one stream
+    // of (head, query tile) items - see fa_bwd_dkdv_kernel)
+    if (!f32_block_map(p.G8kv, p.Gkv, p.sched_kv, p.nk_tiles, false, g, kb)) return;   // key block 0 is the heaviest
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int bb = g / p.H, hh = g - bb * p.H;
-    const float* __restrict__ qg = (const float*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
-    const float* __restrict__ gg = (const float*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh;
-    const float* __restrict__ lse_g = p.lse + (int64_t)g * L;
-    const float* __restrict__ dsum_g = p.dsum + (int64_t)g * L;
+    const int bb = g / p.Hkv, hh = g - bb * p.Hkv;
+    const int hq0 = hh * p.kv_div;
+    const float* __restrict__ qg0 = (const float*)p.q + (int64_t)bb * p.q_sb + (int64_t)hq0 * p.q_sh;
+    const float* __restrict__ gg0 = (const float*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hq0 * p.do_sh;
+    const float* __restrict__ lse_g0 = p.lse + ((int64_t)bb * p.H + hq0) * L;
+    const float* __restrict__ dsum_g0 = p.dsum + ((int64_t)bb * p.H + hq0) * L;
 
     const int key0 = kb * BKW + wave * 32;
     const int key = key0 + r;
@@ -235,25 +238,32 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void fa_bwd_f32_dkdv_kernel(const B
 
     TilePair<D, NT> stage;
     float rc_stage = 0.f;
-    auto load_rowc = [&](int i) {      // threads 0..31: lse2, 32..63: Dsum; rows past L: lse2 = +inf (P = 0), Dsum = 0
+    const int n_sweep = n_qt - i0;                 // query tiles per head
+    const int n_items = n_sweep > 0 ? n_sweep * p.kv_div : 0;
+    auto item = [&](int j, int& hq, int& i) { hq = p.kv_div == 1 ? 0 : j / n_sweep; i = i0 + j - hq * n_sweep; };
+    auto load_rowc = [&](int hq, int i) {   // threads 0..31: lse2, 32..63: Dsum; rows past L: lse2 = +inf (P = 0), Dsum = 0
         const int rr = i * BQ + (tid & 31);
         rc_stage = tid < 32 ? INFINITY : 0.f;
-        if (tid < 32 && rr < L) rc_stage = lse_g[rr] * LOG2E_F;
-        if (tid >= 32 && tid < 64 && rr < L) rc_stage = dsum_g[rr];
+        if (tid < 32 && rr < L) rc_stage = lse_g0[(int64_t)hq * L + rr] * LOG2E_F;
+        if (tid >= 32 && tid < 64 && rr < L) rc_stage = dsum_g0[(int64_t)hq * L + rr];
     };
-    if (i0 < n_qt) {
-        stage.load(qg, p.q_sl, gg, p.do_sl, i0 * BQ, L, tid);
-        load_rowc(i0);
+    if (n_items > 0) {
+        stage.load(qg0, p.q_sl, gg0, p.do_sl, i0 * BQ, L, tid);
+        load_rowc(0, i0);
         stage.store(qs[0], gs[0], tid);
         if (tid < 64) rowc[0][tid] = rc_stage;
     }
     __syncthreads();
 
-    for (int i = i0; i < n_qt; ++i) {
-        const int buf = (i - i0) & 1;
-        if (i + 1 < n_qt) {
-            stage.load(qg, p.q_sl, gg, p.do_sl, (i + 1) * BQ, L, tid);
-            load_rowc(i + 1);
+    for (int j = 0; j < n_items; ++j) {
+        const int buf = j & 1;
+        int hq, i;
+        item(j, hq, i);
+        if (j + 1 < n_items) {
+            int hn, in;
+            item(j + 1, hn, in);
+            stage.load(qg0 + (int64_t)hn * p.q_sh, p.q_sl, gg0 + (int64_t)hn * p.do_sh, p.do_sl, in * BQ, L, tid);
+            load_rowc(hn, in);
         }
         const int q0 = i * BQ;
         if (wave_active && (!causal || q0 + BQ - 1 >= key0)) {
@@ -282,18 +292,18 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void fa_bwd_f32_dkdv_kernel(const B
                 dp[e] = s[e] * (dp[e] - rowc[buf][BQ + qi_]);
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int qq = (j & 3) + 8 * (j >> 2) + 4 * h;
+            for (int jj = 0; jj < 16; ++jj) {
+                const int qq = (jj & 3) + 8 * (jj >> 2) + 4 * h;
                 const float* gr = &gs[buf][qq * KP + r];
                 const float* qr = &qs[buf][qq * KP + r];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gr[32 * dt], s[j], dv[dt], 0, 0, 0);    // dV^T += dO^T P
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[32 * dt], dp[j], dk[dt], 0, 0, 0);   // dK^T += Q^T dS
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gr[32 * dt], s[jj], dv[dt], 0, 0, 0);    // dV^T += dO^T P
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[32 * dt], dp[jj], dk[dt], 0, 0, 0);   // dK^T += Q^T dS
                 }
             }
         }
-        if (i + 1 < n_qt) {
+        if (j + 1 < n_items) {
             stage.store(qs[buf ^ 1], gs[buf ^ 1], tid);
             if (tid < 64) rowc[buf ^ 1][tid] = rc_stage;
         }
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void fa_bwd_f32_dkdv_kernel(const B
 
 // fp32, D in {64, 128}, 16-byte aligned rows; p.nq_tiles = p.nk_tiles = ceil(L / 128)
 hipError_t launch_bwd_f32(const BwdParams& p, hipStream_t stream) {
-    const dim3 gq((unsigned)((int64_t)p.G8 * p.nq_tiles)), gk((unsigned)((int64_t)p.G8 * p.nk_tiles));
+    const dim3 gq((unsigned)((int64_t)p.G8 * p.nq_tiles)), gk((unsigned)((int64_t)p.G8kv * p.nk_tiles));
     hipError_t e;
     if (p.D == 64) {
         e = launch1((const void*)(fa_bwd_f32_dq_kernel<64, 4>), gq, dim3(256), 0, stream, p);

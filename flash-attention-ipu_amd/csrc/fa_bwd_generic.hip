@@ -36,8 +36,8 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dq_kernel(const Bwd
     const int bb = g / p.H, hh = g - bb * p.H;
     const T* qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh + (int64_t)row * p.q_sl;
     const T* gg = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh + (int64_t)row * p.do_sl;
-    const T* kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
-    const T* vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+    const T* kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;   // (grouped-query K/V head)
+    const T* vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
     const int tid = threadIdx.x;
     float* qs = rowbuf;
     float* gs = rowbuf + D;
@@ -88,14 +88,10 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dkdv_kernel(const B
     __shared__ float dsbuf[GB_CHUNK];
     extern __shared__ float rowbuf[];   // k row then v row
     const int L = p.L, D = p.D;
-    const int g = blockIdx.x / L, key = blockIdx.x - g * L;
-    const int bb = g / p.H, hh = g - bb * p.H;
+    const int g = blockIdx.x / L, key = blockIdx.x - g * L;       // g: K/V group (batch entry x K/V head)
+    const int bb = g / p.Hkv, hh = g - bb * p.Hkv;
     const T* kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh + (int64_t)key * p.k_sl;
     const T* vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh + (int64_t)key * p.v_sl;
-    const T* qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
-    const T* gg = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh;
-    const float* lse = p.lse + (int64_t)g * L;
-    const float* dsum = p.dsum + (int64_t)g * L;
     const int tid = threadIdx.x;
     float* ks = rowbuf;
     float* vs = rowbuf + D;
@@ -106,37 +102,43 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dkdv_kernel(const B
     for (int i = 0; i < GB_MAXD_PER_THREAD; ++i) { ak[i] = 0.f; av[i] = 0.f; }
     const int row_lo = p.causal ? key : 0;   // causal: rows key .. L-1 can see this key; otherwise every row
     const int nrows = L - row_lo;
-    for (int r0 = 0; r0 < nrows; r0 += GB_CHUNK) {
-        const int rn = nrows - r0 < GB_CHUNK ? nrows - r0 : GB_CHUNK;
-        for (int c = tid; c < rn; c += GB_THREADS) {
-            const int row = row_lo + r0 + c;
-            const T* qp = qg + (int64_t)row * p.q_sl;
-            const T* gp = gg + (int64_t)row * p.do_sl;
-            float s = 0.f, dp = 0.f;
-            for (int d = 0; d < D; ++d) {
-                s = __builtin_fmaf((float)qp[d], ks[d], s);
-                dp = __builtin_fmaf((float)gp[d], vs[d], dp);
-            }
-            const float pr = __expf(s * p.scale - lse[row]);
-            pbuf[c] = pr;
-            dsbuf[c] = pr * (dp - dsum[row]) * p.scale;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < GB_MAXD_PER_THREAD; ++i) {
-            const int d = tid + i * GB_THREADS;
-            if (d < D) {
-                float a = ak[i], b = av[i];
-                const T* qp = qg + (int64_t)(row_lo + r0) * p.q_sl + d;
-                const T* gp = gg + (int64_t)(row_lo + r0) * p.do_sl + d;
-                for (int c = 0; c < rn; ++c) {
-                    a = __builtin_fmaf(dsbuf[c], (float)qp[(int64_t)c * p.q_sl], a);
-                    b = __builtin_fmaf(pbuf[c], (float)gp[(int64_t)c * p.do_sl], b);
+    for (int hq = hh * p.kv_div; hq < (hh + 1) * p.kv_div; ++hq) {   // every query head that reads this K/V head
+        const T* qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hq * p.q_sh;
+        const T* gg = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hq * p.do_sh;
+        const float* lse = p.lse + ((int64_t)bb * p.H + hq) * L;
+        const float* dsum = p.dsum + ((int64_t)bb * p.H + hq) * L;
+        for (int r0 = 0; r0 < nrows; r0 += GB_CHUNK) {
+            const int rn = nrows - r0 < GB_CHUNK ? nrows - r0 : GB_CHUNK;
+            for (int c = tid; c < rn; c += GB_THREADS) {
+                const int row = row_lo + r0 + c;
+                const T* qp = qg + (int64_t)row * p.q_sl;
+                const T* gp = gg + (int64_t)row * p.do_sl;
+                float s = 0.f, dp = 0.f;
+                for (int d = 0; d < D; ++d) {
+                    s = __builtin_fmaf((float)qp[d], ks[d], s);
+                    dp = __builtin_fmaf((float)gp[d], vs[d], dp);
                 }
-                ak[i] = a; av[i] = b;
+                const float pr = __expf(s * p.scale - lse[row]);
+                pbuf[c] = pr;
+                dsbuf[c] = pr * (dp - dsum[row]) * p.scale;
             }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < GB_MAXD_PER_THREAD; ++i) {
+                const int d = tid + i * GB_THREADS;
+                if (d < D) {
+                    float a = ak[i], b = av[i];
+                    const T* qp = qg + (int64_t)(row_lo + r0) * p.q_sl + d;
+                    const T* gp = gg + (int64_t)(row_lo + r0) * p.do_sl + d;
+                    for (int c = 0; c < rn; ++c) {
+                        a = __builtin_fmaf(dsbuf[c], (float)qp[(int64_t)c * p.q_sl], a);
+                        b = __builtin_fmaf(pbuf[c], (float)gp[(int64_t)c * p.do_sl], b);
+                    }
+                    ak[i] = a; av[i] = b;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     T* dkg = (T*)p.dk + (int64_t)bb * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)key * p.dk_sl;
     T* dvg = (T*)p.dv + (int64_t)bb * p.dv_sb + (int64_t)hh * p.dv_sh + (int64_t)key * p.dv_sl;
@@ -153,7 +155,8 @@ static hipError_t launch_bwd_generic_t(const BwdParams& p, hipStream_t stream) {
     const size_t dyn = 2 * (size_t)p.D * sizeof(float);
     hipError_t e = launch1((const void*)(fa_bwd_generic_dsum_kernel<T>), dim3(rows), dim3(64), 0, stream, p);
     if (e == hipSuccess) e = launch1((const void*)(fa_bwd_generic_dq_kernel<T>), dim3(rows), dim3(GB_THREADS), dyn, stream, p);
-    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_generic_dkdv_kernel<T>), dim3(rows), dim3(GB_THREADS), dyn, stream, p);
+    const unsigned kv_rows = (unsigned)((int64_t)p.Gkv * p.L);
+    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_generic_dkdv_kernel<T>), dim3(kv_rows), dim3(GB_THREADS), dyn, stream, p);
     return e;
 }
 

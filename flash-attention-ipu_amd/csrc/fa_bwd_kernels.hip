@@ -86,8 +86,8 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.H, hh = g - bb * p.H;
-    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh;
-    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh;
+    const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;   // (grouped-query K/V head)
+    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
     const int q_row0 = qi * BQ + wave * 32;
     const int qrow = q_row0 + r;
@@ -277,16 +277,20 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     unsigned char* const smem_g = smem + 2 * IMG_B;
     float* const rowc = (float*)(smem + 4 * IMG_B);      // [buf][ lse2 0..63 | dsum 0..63 ]
 
+    // Grouped-query attention: the workgroup owns 128 keys of ONE K/V head and sweeps the query tiles of all kv_div query
+    // heads that read it, one head after the other, as one stream of (head, query tile) items: dK and dV of the shared
+    // head are summed in registers - no expanded K/V, no atomics, no second pass.
     int g, kb;
-    if (!bwd_block_map(p.G8, p.G, p.sched, p.nk_tiles, false, g, kb)) return;   // key block 0 is the heaviest
+    if (!bwd_block_map(p.G8kv, p.Gkv, p.sched_kv, p.nk_tiles, false, g, kb)) return;   // key block 0 is the heaviest
 
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int bb = g / p.H, hh = g - bb * p.H;
-    const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
-    const T* __restrict__ gg = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh;
+    const int bb = g / p.Hkv, hh = g - bb * p.Hkv;                 // batch entry, K/V head
+    const int hq0 = hh * p.kv_div;                                 // its first query head
+    const T* __restrict__ qg0 = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hq0 * p.q_sh;
+    const T* __restrict__ gg0 = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hq0 * p.do_sh;
 
     const int key0 = kb * BKW + wave * 32;        // first key of this wave
     const int key = key0 + r;                     // this lane's key (both halves hold the same key)
@@ -320,11 +324,16 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     }
     const unsigned q_bytes = ((unsigned)(L - 1) * (unsigned)p.q_sl + D) * 2;
     const unsigned g_bytes = ((unsigned)(L - 1) * (unsigned)p.do_sl + D) * 2;
-#define FA_DMA_QG(I_, BUF_)                                                                        \
+    // item J_ of the stream = query tile i0 + J_ % n_sweep of query head hq0 + J_ / n_sweep
+#define FA_ITEM(J_, HQ_, I_)                                                                       \
+        const int HQ_ = p.kv_div == 1 ? 0 : (J_) / n_sweep;                                        \
+        const int I_ = i0 + (J_) - HQ_ * n_sweep;
+#define FA_DMA_QG(J_, BUF_)                                                                        \
     {                                                                                              \
-        const unsigned qo_ = (unsigned)(I_) * BQ * q_slb, go_ = (unsigned)(I_) * BQ * g_slb;       \
-        const i32x4 qr_ = make_raw_rsrc((const char*)qg + qo_, q_bytes - qo_);                     \
-        const i32x4 gr_ = make_raw_rsrc((const char*)gg + go_, g_bytes - go_);                     \
+        FA_ITEM(J_, hq_, it_)                                                                      \
+        const unsigned qo_ = (unsigned)it_ * BQ * q_slb, go_ = (unsigned)it_ * BQ * g_slb;         \
+        const i32x4 qr_ = make_raw_rsrc((const char*)(qg0 + (int64_t)hq_ * p.q_sh) + qo_, q_bytes - qo_);   \
+        const i32x4 gr_ = make_raw_rsrc((const char*)(gg0 + (int64_t)hq_ * p.do_sh) + go_, g_bytes - go_);  \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
             lds_dma_b128(qr_, smem_lds + (BUF_) * IMG_B + dst[j], q_vo[j]);                        \
             lds_dma_b128(gr_, smem_lds + (2 + (BUF_)) * IMG_B + dst[j], g_vo[j]);                  \
@@ -333,14 +342,15 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     const unsigned smem_lds = lds_offset(smem);
     // row constants of q tile I_: threads 0..63 fetch lse*log2e, 64..127 fetch -Dsum; rows past L get
     // lse2 = +inf (P = 0) and Dsum = 0
-    const float* __restrict__ lse_g = p.lse + (int64_t)g * L;
-    const float* __restrict__ dsum_g = p.dsum + (int64_t)g * L;
-#define FA_ROWC_LOAD(I_)                                                                           \
+    const float* __restrict__ lse_g0 = p.lse + ((int64_t)bb * p.H + hq0) * L;       // [G, L] rows of query head hq0
+    const float* __restrict__ dsum_g0 = p.dsum + ((int64_t)bb * p.H + hq0) * L;
+#define FA_ROWC_LOAD(J_)                                                                           \
     {                                                                                              \
-        const int rr_ = (I_) * BQ + (tid & 63);                                                    \
+        FA_ITEM(J_, hq_, it_)                                                                      \
+        const int rr_ = it_ * BQ + (tid & 63);                                                     \
         rc_stage = (tid < 64) ? INFINITY : 0.f;                                                    \
-        if (tid < 64 && rr_ < L) rc_stage = lse_g[rr_] * LOG2E;                                    \
-        if (tid >= 64 && tid < 128 && rr_ < L) rc_stage = -dsum_g[rr_];   /* negated: see the dP accumulators */ \
+        if (tid < 64 && rr_ < L) rc_stage = lse_g0[(int64_t)hq_ * L + rr_] * LOG2E;                \
+        if (tid >= 64 && tid < 128 && rr_ < L) rc_stage = -dsum_g0[(int64_t)hq_ * L + rr_];   /* negated: see the dP accumulators */ \
     }
 #define FA_ROWC_STORE(BUF_) \
     if (tid < 128) rowc[(BUF_) * 128 + tid] = rc_stage;
@@ -357,6 +367,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     const int n_qt = (L + BQ - 1) / BQ;
     const bool causal = p.causal != 0;             // 0: every query tile sees this workgroup's keys, no mask
     const int i0 = causal ? (kb * BKW) / BQ : 0;
+    const int n_sweep = n_qt - i0;                 // query tiles per head
+    const int n_items = n_sweep > 0 ? n_sweep * p.kv_div : 0;
 
     f32x16 dk[DT], dv[DT];
 #pragma unroll
@@ -365,9 +377,11 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
     float rc_stage = 0.f;
 
-#define FA_DKDV_TILE(I_, BUF_)                                                                     \
+#define FA_DKDV_TILE(J_, BUF_)                                                                     \
     {                                                                                              \
-        const int q0 = (I_) * BQ;                                                                  \
+        FA_ITEM(J_, hqt_, itt_)                                                                    \
+        (void)hqt_;                                                                                \
+        const int q0 = itt_ * BQ;                                                                  \
         if (wave_active && (!causal || q0 + BQ - 1 >= key0)) {                                     \
             const unsigned char* qb_ = smem + (BUF_) * IMG_B;                                      \
             const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
@@ -436,9 +450,9 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         }                                                                                          \
     }
 
-    if (i0 < n_qt) {
-        FA_DMA_QG(i0, 0)
-        FA_ROWC_LOAD(i0)
+    if (n_items > 0) {
+        FA_DMA_QG(0, 0)
+        FA_ROWC_LOAD(0)
         FA_ROWC_STORE(0)
     }
     lds_dma_wait_all();
@@ -446,26 +460,27 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));   // row operands landed
 
-    for (int i = i0; i < n_qt; i += 2) {
-        if (i + 1 < n_qt) {
-            FA_DMA_QG(i + 1, 1)
-            FA_ROWC_LOAD(i + 1)
+    for (int j = 0; j < n_items; j += 2) {
+        if (j + 1 < n_items) {
+            FA_DMA_QG(j + 1, 1)
+            FA_ROWC_LOAD(j + 1)
         }
-        FA_DKDV_TILE(i, 0)
-        if (i + 1 < n_qt) FA_ROWC_STORE(1)
+        FA_DKDV_TILE(j, 0)
+        if (j + 1 < n_items) FA_ROWC_STORE(1)
         lds_dma_wait_all();
         __syncthreads();
-        if (i + 1 < n_qt) {
-            if (i + 2 < n_qt) {
-                FA_DMA_QG(i + 2, 0)
-                FA_ROWC_LOAD(i + 2)
+        if (j + 1 < n_items) {
+            if (j + 2 < n_items) {
+                FA_DMA_QG(j + 2, 0)
+                FA_ROWC_LOAD(j + 2)
             }
-            FA_DKDV_TILE(i + 1, 1)
-            if (i + 2 < n_qt) FA_ROWC_STORE(0)
+            FA_DKDV_TILE(j + 1, 1)
+            if (j + 2 < n_items) FA_ROWC_STORE(0)
             lds_dma_wait_all();
             __syncthreads();
         }
     }
+#undef FA_ITEM
 #undef FA_DMA_QG
 #undef FA_ROWC_LOAD
 #undef FA_ROWC_STORE
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dkdv_kernel(const BwdParam
 template <typename T, int D>
 static hipError_t launch_bwd_t(const BwdParams& p, hipStream_t stream) {
     hipError_t e = launch1((const void*)(fa_bwd_dq_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
-    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nk_tiles)), dim3(256), 0, stream, p);
+    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8kv * p.nk_tiles)), dim3(256), 0, stream, p);
     return e;
 }
 

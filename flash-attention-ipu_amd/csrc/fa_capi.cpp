@@ -393,7 +393,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
 
 int fa_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
            void* dq, void* dk, void* dv, float* dsum_workspace,
-           int64_t G, int64_t L, int64_t D, int64_t heads, const int64_t strides[8][3],
+           int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
            int32_t dtype, float softmax_scale, int32_t causal, void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !dsum_workspace || !strides)
         return fail(FA_ERR_NULL_POINTER, "fa_bwd: every pointer argument must be non-null");
@@ -401,6 +401,7 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1");
     if (!(softmax_scale > 0.0f) || !isfinite(softmax_scale)) return fail(FA_ERR_BAD_SCALE, "softmax_scale must be finite and > 0 (got %g)", (double)softmax_scale);
     if (heads < 1 || G % heads != 0) return fail(FA_ERR_BAD_SHAPE, "G=%lld must be a positive multiple of heads=%lld", (long long)G, (long long)heads);
+    if (heads_kv < 1 || heads % heads_kv != 0) return fail(FA_ERR_BAD_SHAPE, "heads=%lld must be a positive multiple of heads_kv=%lld", (long long)heads, (long long)heads_kv);
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     if (L > (1ll << 30) || G > (1ll << 30)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30");
     const void* const ptrs[8] = {q, k, v, out, dout, dq, dk, dv};
@@ -431,16 +432,18 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
     p.dk_sb = strides[6][0]; p.dk_sh = strides[6][1]; p.dk_sl = strides[6][2];
     p.dv_sb = strides[7][0]; p.dv_sh = strides[7][1]; p.dv_sl = strides[7][2];
     p.G = (int32_t)G; p.G8 = (int32_t)((G + 7) / 8 * 8); p.H = (int32_t)heads; p.L = (int32_t)L; p.D = (int32_t)D;
+    p.Hkv = (int32_t)heads_kv; p.kv_div = (int32_t)(heads / heads_kv);
+    p.Gkv = (int32_t)(G / p.kv_div); p.G8kv = (int32_t)((p.Gkv + 7) / 8 * 8);
     p.causal = causal;
     p.nq_tiles = (int32_t)((L + 127) / 128);
     p.nk_tiles = (int32_t)((L + 127) / 128);
     {
         int64_t bunch = (8ll << 20) / (2 * L * D * 2);
         if (options().sched > 0) bunch = options().sched;
-        const int64_t ng = p.G8 / 8;
         if (bunch < 1) bunch = 1;
-        if (bunch > ng) bunch = ng;
-        p.sched = (int32_t)bunch;
+        const int64_t ng = p.G8 / 8, ngkv = p.G8kv / 8;
+        p.sched = (int32_t)(bunch > ng ? ng : bunch);
+        p.sched_kv = (int32_t)(bunch > ngkv ? ngkv : bunch);
     }
     if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     p.scale = softmax_scale;

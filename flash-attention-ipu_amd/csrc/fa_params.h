@@ -41,10 +41,13 @@ struct BwdParams {
     int64_t q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl, do_sb, do_sh, do_sl;
     int64_t dq_sb, dq_sh, dq_sl, dk_sb, dk_sh, dk_sl, dv_sb, dv_sh, dv_sl;
     int32_t G, G8, H, L, D;
+    int32_t Hkv, kv_div;   // K/V heads per batch entry, query heads per K/V head (grouped-query attention: H = Hkv * kv_div)
+    int32_t Gkv, G8kv;     // K/V groups (G / kv_div) and that count rounded up to a multiple of 8: the dK/dV grid
     int32_t causal;        // 1 causal mask, 0 none
     int32_t nq_tiles;      // workgroup row tiles per group (32 rows x waves x query blocks per wave each)
     int32_t nk_tiles;      // 128-key blocks per group
-    int32_t sched;         // groups per XCD bunch
+    int32_t sched;         // query groups per XCD bunch (dQ grid)
+    int32_t sched_kv;      // K/V groups per XCD bunch (dK/dV grid)
     float scale, scale_log2;
 };
 // One launch, reporting ITS OWN status: hipLaunchKernel returns this launch's result, whereas hipGetLastError()

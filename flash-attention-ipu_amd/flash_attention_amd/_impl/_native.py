@@ -17,7 +17,7 @@ _LIB = None
 _LIB_PATH = None
 
 FA_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class FaPlan(ctypes.Structure):
@@ -90,7 +90,7 @@ def _declare(lib):
     lib.fa_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, p64, p64, p64, p64,
                            i32, i32, i32, ctypes.c_float, i32, vp]
     lib.fa_bwd.restype = ctypes.c_int
-    lib.fa_bwd.argtypes = [vp] * 10 + [i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32, vp]
+    lib.fa_bwd.argtypes = [vp] * 10 + [i64, i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32, vp]
     lib.fa_probe_clock.restype = ctypes.c_int
     lib.fa_probe_clock.argtypes = [ctypes.c_void_p, i32, ctypes.c_void_p]
     lib.fa_probe_mfma_peak.restype = ctypes.c_double
@@ -236,8 +236,9 @@ def group_strides(t: torch.Tensor, heads: int):
     return (t.stride(0), t.stride(1), t.stride(2))
 
 
-def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale, causal: bool = True):
-    """Backward through the C ABI (fa_bwd).  Tensors are [G,L,D] or [B,H,L,D] views with unit inner stride."""
+def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale, causal: bool = True, heads_kv=None):
+    """Backward through the C ABI (fa_bwd).  Tensors are [G,L,D] or [B,H,L,D] views with unit inner stride; with
+    heads_kv < heads (grouped-query attention) k, v, dk, dv are [B,H_kv,L,D]."""
     lib = load_native_library()
     if q.ndim == 3:
         flat = [x for t in (q, k, v, out, dout, dq, dk, dv) for x in (t.stride(0), 0, t.stride(1))]
@@ -248,6 +249,7 @@ def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale, causal: bool
     with _on_device_of(q) as stream:
         rc = lib.fa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
                         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(), G, L, D, heads,
+                        heads if heads_kv is None else heads_kv,
                         ctypes.cast(arr, _P_I64x3), FA_DTYPE[q.dtype], float(scale), int(bool(causal)), stream)
     if rc != 0:
         _raise(rc)

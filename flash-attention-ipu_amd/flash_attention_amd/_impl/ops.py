@@ -177,6 +177,75 @@ def _(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
     return _bhld_out_like(q)
 
 
+# ---- training with grouped-query K/V heads: [B, H, L, D] query, [B, H_kv, L, D] key / value --------------------
+# Forward and backward resolve the head mapping inside the kernels (fa_fwd / fa_bwd `heads_kv`): K and V are never
+# expanded, and dK / dV of a shared head are summed over its query heads inside one workgroup per 128 keys.
+def _st4(t):
+    return (t.stride(0), t.stride(1), t.stride(2))
+
+
+def _fwd_gqa_impl(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal):
+    q, k, v = _rows(q), _rows(k), _rows(v)
+    B, H, L, D = q.shape
+    out = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B * H, L), dtype=torch.float32, device=q.device)
+    if out.numel() > 0:
+        _native.fwd_strided(q, k, v, out, lse, B * H, L, D, H, _st4(q), _st4(k), _st4(v), _st4(out),
+                            num_chunks_q, num_chunks_kv, softmax_scale, causal, heads_kv=k.shape[1])
+    return out, lse
+
+
+def _bwd_gqa_impl(q, k, v, out, dout, lse, softmax_scale, causal):
+    q, k, v, out, dout = (_rows(t) for t in (q, k, v, out, dout))
+    B, H, L, D = q.shape
+    dq = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
+    dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+    dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+    if dq.numel() > 0:
+        _native.bwd(q, k, v, out, dout, lse, dq, dk, dv, B * H, L, D, H, softmax_scale, causal, heads_kv=k.shape[1])
+    return dq, dk, dv
+
+
+@custom_op("flash_attention_amd::fwd_gqa", mutates_args=())
+def fwd_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, softmax_scale: float,
+            num_chunks_q: int, num_chunks_kv: int, causal: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    return _fwd_gqa_impl(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+
+
+@fwd_gqa.register_fake
+def _(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
+    B, H, L, D = q.shape
+    return q.new_empty((B, H, L, D)), q.new_empty((B * H, L), dtype=torch.float32)
+
+
+@custom_op("flash_attention_amd::bwd_gqa", mutates_args=())
+def bwd_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor,
+            lse: torch.Tensor, softmax_scale: float, causal: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    return _bwd_gqa_impl(q, k, v, out, dout, lse, softmax_scale, causal)
+
+
+@bwd_gqa.register_fake
+def _(q, k, v, out, dout, lse, softmax_scale, causal=True):
+    return q.new_empty(q.shape), k.new_empty(k.shape), v.new_empty(v.shape)
+
+
+def _gqa_setup(ctx, inputs, output):
+    q, k, v, softmax_scale, _, _, causal = inputs
+    out, lse = output
+    ctx.save_for_backward(q, k, v, out, lse)
+    ctx.softmax_scale = softmax_scale
+    ctx.causal = causal
+
+
+def _gqa_backward(ctx, dout, _dlse):
+    q, k, v, out, lse = ctx.saved_tensors
+    dq, dk, dv = bwd_gqa(q, k, v, out, dout, lse, ctx.softmax_scale, ctx.causal)
+    return dq, dk, dv, None, None, None, None
+
+
+fwd_gqa.register_autograd(_gqa_backward, setup_context=_gqa_setup)
+
+
 # ---- eager fast path ------------------------------------------------------------------------------------
 # The custom ops above are what torch.compile traces (opaque ops with fake implementations and registered autograd).
 # In eager mode their Python dispatch costs more than a small attention call takes on the GPU (measured on an MI355X
@@ -199,6 +268,21 @@ class _AttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None
 
 
+class _GqaAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal):
+        out, lse = _fwd_gqa_impl(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.softmax_scale, ctx.causal = softmax_scale, causal
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = _bwd_gqa_impl(q, k, v, out, dout, lse, ctx.softmax_scale, ctx.causal)
+        return dq, dk, dv, None, None, None, None
+
+
 class _PackedAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, num_chunks_q, num_chunks_kv):
@@ -217,6 +301,25 @@ def attention(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
     if torch.compiler.is_compiling():
         return fwd(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)[0]
     return _AttentionFn.apply(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+
+
+# The dK / dV kernel of the grouped-query backward runs one workgroup per (K/V head, 128 keys) that sweeps ALL query heads of
+# the group: with fewer than 512 such workgroups the chip is under-filled and the expanded route (more, shorter workgroups)
+# is faster (measured, scripts/bench_gqa.py: 256-384 workgroups 0.56-0.92x, 512 and more 1.02-1.17x, and 28 % less memory).
+GQA_NATIVE_MIN_WORKGROUPS = 512
+
+
+def attention_gqa(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
+    """[B, H, L, D] query with [B, H_kv, L, D] key / value (H a multiple of H_kv) -> out [B, H, L, D], differentiable."""
+    B, H, L, D = q.shape
+    if k.shape[0] * k.shape[1] * ((L + 127) // 128) < GQA_NATIVE_MIN_WORKGROUPS and k.shape[1] != H:
+        rep = H // k.shape[1]       # small K/V grid: expanded heads through the multi-head kernels, autograd sums the copies
+        ke, ve = k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1)
+        return attention(q.reshape(-1, L, D), ke.reshape(-1, L, D), ve.reshape(-1, L, D),
+                         softmax_scale, num_chunks_q, num_chunks_kv, causal).view(B, H, L, D)
+    if torch.compiler.is_compiling():
+        return fwd_gqa(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)[0]
+    return _GqaAttentionFn.apply(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)
 
 
 def attention_qkv_packed(qkv, num_chunks_q, num_chunks_kv):

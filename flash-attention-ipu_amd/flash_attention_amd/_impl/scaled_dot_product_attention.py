@@ -85,10 +85,8 @@ def _scaled_dot_product_attention_amd(
             # inference on [B, H, L, D] views (e.g. slices of a fused [B, T, 3C] projection): no copies at all;
             # grouped-query K/V heads are resolved inside the kernel
             return ops.attention_bhld(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal)
-        if gqa:   # training with grouped K/V heads: expand them (autograd sums the head gradients back)
-            rep = query.shape[1] // key.shape[1]
-            key = key.repeat_interleave(rep, dim=1)
-            value = value.repeat_interleave(rep, dim=1)
+        if gqa:   # training with grouped K/V heads: resolved inside the forward AND the backward kernels (no expanded K/V)
+            return ops.attention_gqa(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal)
         out = ops.attention(query.reshape(-1, L, D), key.reshape(-1, L, D), value.reshape(-1, L, D),
                             softmax_scale, num_chunks_q, num_chunks_kv, causal)
         return out.view(*batch_shape, L, D)

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 2
+#define FA_ABI_VERSION 3   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V) */
 
 /* element types (reference allows FLOAT16 and FLOAT, FA.cpp:609; bf16 is new here) */
 enum { FA_DTYPE_F16 = 0, FA_DTYPE_BF16 = 1, FA_DTYPE_F32 = 2 };
@@ -170,13 +170,16 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
  *                    i = 0..7 for q, k, v, out, dout, dq, dk, dv
  *   lse            : float32 [G, L] contiguous, as written by fa_fwd (log-sum-exp of the scaled logits)
  *   dsum_workspace : float32 [G, L] contiguous scratch (rowsum(dout * out)), caller-owned
- * f16/bf16 with D in {64, 128} and 16-byte aligned rows run the MFMA kernels; every other case
- * (fp32, other D <= 1024, unaligned rows) runs generic fp32-arithmetic kernels.
+ *   heads, heads_kv : as in fa_fwd.  With heads_kv < heads (grouped-query attention) k, v, dk and dv have
+ *                    G / (heads / heads_kv) groups; dk / dv of a key/value head are the sums over the query heads that
+ *                    read it, formed inside ONE workgroup per 128 keys (no expanded K/V, no atomics)   [ABI 3]
+ * f16/bf16/fp32 with D in {64, 128} and 16-byte aligned rows run the MFMA kernels; every other case
+ * (other D <= 1024, unaligned rows) runs generic fp32-arithmetic kernels.
  * Deterministic: no gradient is accumulated across workgroups.
  */
 int fa_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
            void* dq, void* dk, void* dv, float* dsum_workspace,
-           int64_t G, int64_t L, int64_t D, int64_t heads, const int64_t strides[8][3],
+           int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
            int32_t dtype, float softmax_scale, int32_t causal, void* stream);
 
 /* Forward on a contiguous packed qkv [3,G,L,D] -> out [G,L,D] (scale 1, causal). */

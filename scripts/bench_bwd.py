@@ -36,7 +36,7 @@ for spec in args or ["cfg2"]:          # cfg2 | cfg2:f32 | d128:f16 ...
     def fwd(): _native.fwd_packed(qkv, out, lse, 8, 8)
     def bwd(lib):
         rc = lib.fa_bwd(qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                        dqkv[0].data_ptr(), dqkv[1].data_ptr(), dqkv[2].data_ptr(), dsum.data_ptr(), G, L, D, 1, arr,
+                        dqkv[0].data_ptr(), dqkv[1].data_ptr(), dqkv[2].data_ptr(), dsum.data_ptr(), G, L, D, 1, 1, arr,
                         _native.FA_DTYPE[dt], ctypes.c_float(1.0), 1, torch.cuda.current_stream().cuda_stream)
         assert rc == 0
     def t(fn, n=10):

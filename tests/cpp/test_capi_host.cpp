@@ -95,15 +95,17 @@ int main() {
     int64_t st8[8][3];
     for (auto& r : st8) { r[0] = 128 * 64; r[1] = 0; r[2] = 64; }
     float fbuf[4];
-    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'B');
-    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_F32, 1.0f, 0, nullptr) == FA_OK && g_stub_last == 'F');
-    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 80, 1, st8, FA_DTYPE_F32, 1.0f, 0, nullptr) == FA_OK && g_stub_last == 'b');
-    EXPECT(fa_bwd(p, p, p, p, p, nullptr, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_NULL_POINTER);
-    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, -2.0f, 1, nullptr) == FA_ERR_BAD_SCALE);
-    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, 1.0f, 3, nullptr) == FA_ERR_NOT_CAUSAL);
-    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 3, 128, 64, 2, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_SHAPE);
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'B');
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_F32, 1.0f, 0, nullptr) == FA_OK && g_stub_last == 'F');
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 80, 1, 1, st8, FA_DTYPE_F32, 1.0f, 0, nullptr) == FA_OK && g_stub_last == 'b');
+    EXPECT(fa_bwd(p, p, p, p, p, nullptr, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_NULL_POINTER);
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, -2.0f, 1, nullptr) == FA_ERR_BAD_SCALE);
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 3, nullptr) == FA_ERR_NOT_CAUSAL);
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 3, 128, 64, 2, 2, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_SHAPE);
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 6, 128, 64, 6, 4, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_SHAPE);   // heads % heads_kv
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 8, 128, 64, 4, 2, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'B');   // grouped-query
     st8[3][1] = -5;
-    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_STRIDE);
+    EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_STRIDE);
     // ---- thread-local error text; concurrent plan + option calls (ThreadSanitizer-style smoke under ASan/UBSan)
     std::vector<std::thread> th;
     for (int t = 0; t < 4; ++t)

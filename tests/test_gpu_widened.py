@@ -174,13 +174,15 @@ def test_sdpa_nonpositive_scale_goes_to_stock_sdpa(scale):
 
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.float16, 128), (torch.float32, 64), (torch.bfloat16, 24)])
-def test_backward_causal_and_noncausal_vs_oracle_autograd(dtype, D, causal):
+def test_backward_causal_and_noncausal_vs_oracle_autograd(monkeypatch, dtype, D, causal):
     """dQ, dK, dV through the SDPA override (MFMA backward kernels, generic kernels for fp32 / odd head dims) against
-    autograd through the fp64 oracle, for both mask modes; grouped K/V heads are expanded for training and autograd
-    sums their gradients back."""
+    autograd through the fp64 oracle, for both mask modes; grouped K/V heads (H = 4 over H_kv = 2) are resolved inside the
+    forward and backward kernels (fa_fwd / fa_bwd `heads_kv`)."""
     import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl import ops
     from oracle import dense_attention_lse, frozen_randn
 
+    monkeypatch.setattr(ops, "GQA_NATIVE_MIN_WORKGROUPS", 0)      # (the kernels' own head mapping, whatever the grid size)
     B, H, Hkv, L = 2, 4, 2, 200
     q0 = (frozen_randn(SEED + 60, (B, H, L, D)) * 0.7).to(dtype)
     k0 = (frozen_randn(SEED + 61, (B, Hkv, L, D)) * 0.7).to(dtype)
@@ -199,6 +201,62 @@ def test_backward_causal_and_noncausal_vs_oracle_autograd(dtype, D, causal):
         floor = tol * max(1e-3, want.abs().max().item())
         assert torch.isfinite(got).all(), name
         assert bool((err <= floor + 2e-2 * want.abs()).all()), f"{name} {dtype} D={D} causal={causal}: max|d|={err.max().item():.3e}"
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("dtype,D,tol", [(torch.bfloat16, 64, 1.5e-2), (torch.bfloat16, 128, 1.5e-2), (torch.float32, 128, 1e-5), (torch.float16, 40, 4e-3)])
+@pytest.mark.parametrize("H,Hkv", [(8, 1), (6, 2), (8, 8)])
+@pytest.mark.parametrize("native", [True, False])
+def test_grouped_query_backward_inside_the_kernels(monkeypatch, native, dtype, D, tol, H, Hkv, causal):
+    """Grouped- / multi-query training: dQ with the K/V head h // (H / H_kv), dK and dV of a shared head summed over its query
+    heads inside one workgroup (MFMA kernels for 16-bit and fp32 at head_dim 64 / 128, generic kernels at head_dim 40) -
+    against autograd through the fp64 oracle on the unexpanded tensors; head-inner (projection-style) q layout, ragged L
+    spanning several query tiles."""
+    import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl import ops
+    from oracle import dense_attention_lse, frozen_randn
+
+    monkeypatch.setattr(ops, "GQA_NATIVE_MIN_WORKGROUPS", 0 if native else 1 << 30)   # both routes of attention_gqa
+    B, L = 2, 320          # (divisible by the chunk heuristic, 2.5 q tiles of 128 rows)
+    q0 = (frozen_randn(SEED + 80 + H, (B, L, H, D)) * 0.7).to(dtype).transpose(1, 2)      # [B, H, L, D] view of [B, L, H, D]
+    k0 = (frozen_randn(SEED + 81 + H, (B, Hkv, L, D)) * 0.7).to(dtype)
+    v0 = frozen_randn(SEED + 82 + H, (B, Hkv, L, D)).to(dtype)
+    g0 = frozen_randn(SEED + 83 + H, (B, H, L, D)).to(dtype)
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q0, k0, v0))
+    ref, _ = dense_attention_lse(qr, kr, vr, scale=D ** -0.5, causal=causal)
+    ref.backward(g0.double())
+    q, k, v = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
+    out = F.scaled_dot_product_attention(q, k, v, is_causal=causal, enable_gqa=True)
+    out.backward(g0.cuda())
+    assert k.grad.shape == k0.shape and v.grad.shape == v0.shape and q.grad.shape == q0.shape
+    for name, got, want in (("out", out, ref.detach()), ("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+        got = got.detach().cpu().double()
+        err = (got - want).abs()
+        floor = tol * max(1e-3, want.abs().max().item())
+        assert torch.isfinite(got).all(), name
+        assert bool((err <= floor + 2e-2 * want.abs()).all()), f"{name} {dtype} D={D} H={H}/{Hkv} causal={causal}: max|d|={err.max().item():.3e}"
+
+
+def test_grouped_query_training_under_torch_compile(monkeypatch):
+    """The grouped-query training path as torch.compile sees it: custom ops flash_attention_amd::{fwd_gqa, bwd_gqa} with fake
+    implementations and registered autograd, fullgraph."""
+    from flash_attention_amd._impl import ops
+    from oracle import frozen_randn
+
+    B, H, Hkv, L, D = 1, 4, 2, 192, 64
+    q0, k0, v0 = (frozen_randn(SEED + 90 + i, (B, h, L, D)).to(torch.bfloat16) for i, h in enumerate((H, Hkv, Hkv)))
+    monkeypatch.setattr(ops, "GQA_NATIVE_MIN_WORKGROUPS", 0)
+
+    def f(q, k, v):
+        return ops.attention_gqa(q, k, v, D ** -0.5, 2, 2, True).float().square().sum()
+
+    grads = []
+    for fn in (f, torch.compile(f, fullgraph=True)):
+        q, k, v = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
+        fn(q, k, v).backward()
+        grads.append((q.grad, k.grad, v.grad))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
 
 
 def test_kv_chunk_below_64_keys_runs_32_key_steps(knobs):
