@@ -25,6 +25,10 @@
 
 #include "fa_device.h"
 
+#ifndef FA_BWD_ABL
+#define FA_BWD_ABL 0    /* timing-only ablations (wrong results): 1 no K/V DMA in dq, 2 no Q/dO DMA in dkdv */
+#endif
+
 namespace fa {
 
 // ---------------------------------------------------------------------------------------------
@@ -145,9 +149,11 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
         const unsigned ko_ = (unsigned)(T_) * BK * k_slb, vo_ = (unsigned)(T_) * BK * v_slb;       \
         const i32x4 kr_ = make_raw_rsrc((const char*)kg + ko_, k_bytes - ko_);                     \
         const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
+        if (FA_BWD_ABL != 1) {                                                                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
             lds_dma_b128(kr_, smem_lds + (BUF_) * IMG_B + dst[j], k_vo[j]);                        \
             lds_dma_b128(vr_, smem_lds + (2 + (BUF_)) * IMG_B + dst[j], v_vo[j]);                  \
+        }                                                                                          \
         }                                                                                          \
     }
 #define FA_TILE_BARRIER() { lds_dma_wait_all(); __syncthreads(); }
@@ -334,9 +340,11 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         const unsigned qo_ = (unsigned)it_ * BQ * q_slb, go_ = (unsigned)it_ * BQ * g_slb;         \
         const i32x4 qr_ = make_raw_rsrc((const char*)(qg0 + (int64_t)hq_ * p.q_sh) + qo_, q_bytes - qo_);   \
         const i32x4 gr_ = make_raw_rsrc((const char*)(gg0 + (int64_t)hq_ * p.do_sh) + go_, g_bytes - go_);  \
+        if (FA_BWD_ABL != 2) {                                                                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
             lds_dma_b128(qr_, smem_lds + (BUF_) * IMG_B + dst[j], q_vo[j]);                        \
             lds_dma_b128(gr_, smem_lds + (2 + (BUF_)) * IMG_B + dst[j], g_vo[j]);                  \
+        }                                                                                          \
         }                                                                                          \
     }
     const unsigned smem_lds = lds_offset(smem);
