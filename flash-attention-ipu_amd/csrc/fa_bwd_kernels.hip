@@ -179,6 +179,54 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
 
+#ifndef FA_BWD_HALVES
+#define FA_BWD_HALVES 1   /* 1: a 64-row (dK/dV) / 64-key (dQ) tile is consumed as two 32-wide halves one after the other: one score and
+                             one dP tile live at a time - the head_dim 128 dK/dV kernel then fits two waves per SIMD, the others gain a
+                             wave, and a half that lies wholly behind the causal diagonal is skipped; 0: both halves at once */
+#endif
+#if FA_BWD_HALVES
+#define FA_DQ_TILE(T_, BUF_)                                                                       \
+    {                                                                                              \
+        const int kv0 = (T_) * BK;                                                                 \
+        if (wave_active && kv0 <= wave_kv_last) {                                                  \
+            const unsigned char* kb_ = smem + (BUF_) * IMG_B;                                      \
+            const unsigned char* vb_ = smem_v + (BUF_) * IMG_B;                                    \
+            _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {        /* keys kv0 + 32 hb .. +31 */ \
+                if (kv0 + 32 * hb > wave_kv_last) continue;           /* every key of this half lies after the wave's rows */ \
+                f32x16 s0, t0;                                                                     \
+                /* the accumulators of dP^T start at -Dsum: the MFMA chain delivers dP^T - Dsum */ \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[e] = 0.f; t0[e] = ndsum; }     \
+                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                \
+                    s0 = E::mfma(*(const vec8*)(kb_ + 2048 * hb + a_rd[ks]), qf[ks], s0);          \
+                    t0 = E::mfma(*(const vec8*)(vb_ + 2048 * hb + a_rd[ks]), dof[ks], t0);         \
+                }                                                                                  \
+                if (kv0 + 32 * hb + 31 > wave_last) {                                              \
+                    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                               \
+                        const int key = kv0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;            \
+                        if (key > klim) s0[e] = -INFINITY;                                         \
+                    }                                                                              \
+                }                                                                                  \
+                /* dS^T = P^T o (dP^T - Dsum), P^T = 2^(S^T c - lse2): the row constants are lane scalars */ \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e)                                     \
+                    s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -lse2)) * t0[e];                    \
+                vec8 dsf[2];                                                                       \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) { dsf[0][j] = (T)s0[j]; dsf[1][j] = (T)s0[8 + j]; } \
+                /* dQ^T += K^T dS^T */                                                             \
+                _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                \
+                    _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                             \
+                        const unsigned char* ap = kb_ + dt * 4096 + (2 * hb + k2) * 1024;          \
+                        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                  \
+                            (i16x4 __attribute__((address_space(3)))*)(ap + trb0));                \
+                        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                  \
+                            (i16x4 __attribute__((address_space(3)))*)(ap + 512 + trb1));          \
+                        const i16x8 a8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);  \
+                        dq[dt] = E::mfma(__builtin_bit_cast(vec8, a8), dsf[k2], dq[dt]);           \
+                    }                                                                              \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
+#else
 #define FA_DQ_TILE(T_, BUF_)                                                                       \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
@@ -227,6 +275,8 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             }                                                                                      \
         }                                                                                          \
     }
+
+#endif
 
     FA_DMA_KV(0, 0)
     FA_TILE_BARRIER()
@@ -385,6 +435,70 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
     float rc_stage = 0.f;
 
+#if FA_BWD_HALVES
+#define FA_DKDV_TILE(J_, BUF_)                                                                     \
+    {                                                                                              \
+        FA_ITEM(J_, hqt_, itt_)                                                                    \
+        (void)hqt_;                                                                                \
+        const int q0 = itt_ * BQ;                                                                  \
+        if (wave_active && (!causal || q0 + BQ - 1 >= key0)) {                                     \
+            const unsigned char* qb_ = smem + (BUF_) * IMG_B;                                      \
+            const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
+            const float* rc_ = rowc + (BUF_) * 128;                                                \
+            _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {       /* query rows q0 + 32 hb .. +31 */ \
+                if (causal && q0 + 32 * hb + 31 < key0) continue;    /* every query of this half lies before the wave's keys */ \
+                f32x16 s0, t0;                                                                     \
+                /* dP accumulators start at -Dsum[q] (rowc holds the negated sums) */              \
+                _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                 \
+                    const f32x4 da = *(const f32x4*)(rc_ + 64 + 32 * hb + 8 * gq + 4 * h);         \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) { s0[4 * gq + j] = 0.f; t0[4 * gq + j] = da[j]; } \
+                }                                                                                  \
+                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                \
+                    s0 = E::mfma(*(const vec8*)(qb_ + 2048 * hb + a_rd[ks]), kf[ks], s0);          \
+                    t0 = E::mfma(*(const vec8*)(gb_ + 2048 * hb + a_rd[ks]), vf[ks], t0);          \
+                }                                                                                  \
+                if (causal && q0 + 32 * hb < key0 + 31) { /* diagonal: query < key is masked */    \
+                    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                               \
+                        const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;              \
+                        if (qq < key) s0[e] = -INFINITY;                                           \
+                    }                                                                              \
+                }                                                                                  \
+                _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                 \
+                    const f32x4 la = *(const f32x4*)(rc_ + 32 * hb + 8 * gq + 4 * h);              \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                \
+                        const int e = 4 * gq + j;                                                  \
+                        s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -la[j]));                       \
+                        t0[e] = s0[e] * t0[e];                                                     \
+                    }                                                                              \
+                }                                                                                  \
+                vec8 pf[2], dsf[2];                                                                \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                    \
+                    pf[0][j] = (T)s0[j];  pf[1][j] = (T)s0[8 + j];                                 \
+                    dsf[0][j] = (T)t0[j]; dsf[1][j] = (T)t0[8 + j];                                \
+                }                                                                                  \
+                _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                \
+                    _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                             \
+                        const int kk = 2 * hb + k2;                                                \
+                        const unsigned char* gp_ = gb_ + dt * 4096 + kk * 1024;                    \
+                        const unsigned char* qp_ = qb_ + dt * 4096 + kk * 1024;                    \
+                        const i16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                 \
+                            (i16x4 __attribute__((address_space(3)))*)(gp_ + trb0));               \
+                        const i16x4 ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                 \
+                            (i16x4 __attribute__((address_space(3)))*)(gp_ + 512 + trb1));         \
+                        const i16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                 \
+                            (i16x4 __attribute__((address_space(3)))*)(qp_ + trb0));               \
+                        const i16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                 \
+                            (i16x4 __attribute__((address_space(3)))*)(qp_ + 512 + trb1));         \
+                        const i16x8 g8 = __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7); \
+                        const i16x8 q8 = __builtin_shufflevector(qlo, qhi, 0, 1, 2, 3, 4, 5, 6, 7); \
+                        dv[dt] = E::mfma(__builtin_bit_cast(vec8, g8), pf[k2], dv[dt]);            \
+                        dk[dt] = E::mfma(__builtin_bit_cast(vec8, q8), dsf[k2], dk[dt]);           \
+                    }                                                                              \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
+#else
 #define FA_DKDV_TILE(J_, BUF_)                                                                     \
     {                                                                                              \
         FA_ITEM(J_, hqt_, itt_)                                                                    \
@@ -458,6 +572,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         }                                                                                          \
     }
 
+#endif
+
     if (n_items > 0) {
         FA_DMA_QG(0, 0)
         FA_ROWC_LOAD(0)
@@ -513,8 +629,9 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     }
 }
 
+// (head_dim 128: 254 + 4 registers as allocated freely - held to 256 = two waves per SIMD)
 template <typename T, int D, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dkdv_kernel(const BwdParams p) {
+__global__ __launch_bounds__(NWAVES * 64, D == 128 ? 2 : 1) void fa_bwd_dkdv_kernel(const BwdParams p) {
     fa_bwd_dkdv_body<T, D, NWAVES>(p);
 }
 
