@@ -25,6 +25,9 @@
 
 #include "fa_device.h"
 
+#ifndef FA_BWD_NBUF
+#define FA_BWD_NBUF(D_) 2   /* streamed-tile buffers per operand; 3 at head_dim 64 (-DFA_BWD_NBUF\(D_\)=...) measured +0.2..0.9 %: not worth 16 KB of LDS */
+#endif
 #ifndef FA_BWD_ABL
 #define FA_BWD_ABL 0    /* timing-only ablations (wrong results): 1 no K/V DMA in dq, 2 no Q/dO DMA in dkdv */
 #endif
@@ -48,6 +51,8 @@ struct BwdGeom {
     static constexpr int PPW = PIECES / NWAVES;      // pieces per wave
     static constexpr int KS = D / 16;
     static constexpr int DT = D / 32;
+    // streamed-tile buffers per operand (a ring: with three, a tile's LDS-DMA has two tile times to land)
+    static constexpr int NB = FA_BWD_NBUF(D);
     static_assert(PIECES % NWAVES == 0 && PPW >= 1, "pieces must split evenly over the waves");
 };
 
@@ -77,10 +82,10 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     using vec8 = typename E::vec8;
     using GM = BwdGeom<T, D, NWAVES>;
     typedef T vec4 __attribute__((ext_vector_type(4)));
-    constexpr int BQ = NWAVES * 32, BK = 64, KS = GM::KS, DT = GM::DT, IMG_B = GM::IMG_B, PPW = GM::PPW;
+    constexpr int BQ = NWAVES * 32, BK = 64, KS = GM::KS, DT = GM::DT, IMG_B = GM::IMG_B, PPW = GM::PPW, NB = GM::NB;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * IMG_B];   // K0 K1 V0 V1
-    unsigned char* const smem_v = smem + 2 * IMG_B;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NB * IMG_B];   // K0 .. K(NB-1)  V0 .. V(NB-1)
+    unsigned char* const smem_v = smem + NB * IMG_B;
 
     int g, qi;
     if (!bwd_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, g, qi)) return;
@@ -152,7 +157,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
         if (FA_BWD_ABL != 1) {                                                                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
             lds_dma_b128(kr_, smem_lds + (BUF_) * IMG_B + dst[j], k_vo[j]);                        \
-            lds_dma_b128(vr_, smem_lds + (2 + (BUF_)) * IMG_B + dst[j], v_vo[j]);                  \
+            lds_dma_b128(vr_, smem_lds + (NB + (BUF_)) * IMG_B + dst[j], v_vo[j]);                 \
         }                                                                                          \
         }                                                                                          \
     }
@@ -278,20 +283,26 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 
 #endif
 
-    FA_DMA_KV(0, 0)
+    // ring of NB buffers: tile t lives in buffer t % NB; at the top of tile t the DMA for tile t + NB - 1 goes out (its buffer
+    // was released by the barrier that ended tile t - 1); at the end of tile t only that newest DMA may still be in flight
+    fa_static_for<0, NB - 1>([&](auto bi_) { constexpr int b_ = decltype(bi_)::value; if (b_ < n_tiles) FA_DMA_KV(b_, b_) });
     FA_TILE_BARRIER()
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));   // row operands landed
 
-    for (int t = 0; t < n_tiles; t += 2) {
-        if (t + 1 < n_tiles) FA_DMA_KV(t + 1, 1)
-        FA_DQ_TILE(t, 0)
-        FA_TILE_BARRIER()
-        if (t + 1 < n_tiles) {
-            if (t + 2 < n_tiles) FA_DMA_KV(t + 2, 0)
-            FA_DQ_TILE(t + 1, 1)
-            FA_TILE_BARRIER()
-        }
+    for (int t0 = 0; t0 < n_tiles; t0 += NB) {
+        fa_static_for<0, NB>([&](auto ki_) {
+            constexpr int k_ = decltype(ki_)::value;
+            const int t = t0 + k_;
+            if (t < n_tiles) {                                   // (workgroup-uniform)
+                const bool more = t + NB - 1 < n_tiles;
+                if (more) FA_DMA_KV(t + NB - 1, (k_ + NB - 1) % NB)
+                FA_DQ_TILE(t, k_)
+                if (more && NB > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NB - 2)) : "memory");
+                else lds_dma_wait_all();
+                __syncthreads();
+            }
+        });
     }
 #undef FA_DMA_KV
 #undef FA_TILE_BARRIER
@@ -326,12 +337,12 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     using GM = BwdGeom<T, D, NWAVES>;
     typedef T vec4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    constexpr int BKW = NWAVES * 32, BQ = 64, KS = GM::KS, DT = GM::DT, IMG_B = GM::IMG_B, PPW = GM::PPW;
+    constexpr int BKW = NWAVES * 32, BQ = 64, KS = GM::KS, DT = GM::DT, IMG_B = GM::IMG_B, PPW = GM::PPW, NB = GM::NB;
 
-    // Q0 Q1 dO0 dO1 images, then per-buffer row constants: lse2[64], dsum[64]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * IMG_B + 2 * 512];
-    unsigned char* const smem_g = smem + 2 * IMG_B;
-    float* const rowc = (float*)(smem + 4 * IMG_B);      // [buf][ lse2 0..63 | dsum 0..63 ]
+    // Q0 .. Q(NB-1), dO0 .. dO(NB-1) images, then per-buffer row constants: lse2[64], dsum[64]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NB * IMG_B + NB * 512];
+    unsigned char* const smem_g = smem + NB * IMG_B;
+    float* const rowc = (float*)(smem + 2 * NB * IMG_B);  // [buf][ lse2 0..63 | dsum 0..63 ]
 
     // Grouped-query attention: the workgroup owns 128 keys of ONE K/V head and sweeps the query tiles of all kv_div query
     // heads that read it, one head after the other, as one stream of (head, query tile) items: dK and dV of the shared
@@ -393,7 +404,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         if (FA_BWD_ABL != 2) {                                                                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
             lds_dma_b128(qr_, smem_lds + (BUF_) * IMG_B + dst[j], q_vo[j]);                        \
-            lds_dma_b128(gr_, smem_lds + (2 + (BUF_)) * IMG_B + dst[j], g_vo[j]);                  \
+            lds_dma_b128(gr_, smem_lds + (NB + (BUF_)) * IMG_B + dst[j], g_vo[j]);                 \
         }                                                                                          \
         }                                                                                          \
     }
@@ -574,35 +585,39 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 
 #endif
 
-    if (n_items > 0) {
-        FA_DMA_QG(0, 0)
-        FA_ROWC_LOAD(0)
-        FA_ROWC_STORE(0)
-    }
+    // ring of NB buffers (see fa_bwd_dq_kernel).  The row constants of an item travel through one staging register: loaded
+    // BEFORE that item's DMA is issued - vmcnt retires in order, so waiting for them at the end of a tile does not wait for
+    // the newer DMA - and stored to the item's buffer at the end of the tile during which they were loaded.
+    fa_static_for<0, NB - 1>([&](auto bi_) {
+        constexpr int b_ = decltype(bi_)::value;
+        if (b_ < n_items) {
+            FA_ROWC_LOAD(b_)
+            FA_DMA_QG(b_, b_)
+            FA_ROWC_STORE(b_)
+        }
+    });
     lds_dma_wait_all();
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));   // row operands landed
 
-    for (int j = 0; j < n_items; j += 2) {
-        if (j + 1 < n_items) {
-            FA_DMA_QG(j + 1, 1)
-            FA_ROWC_LOAD(j + 1)
-        }
-        FA_DKDV_TILE(j, 0)
-        if (j + 1 < n_items) FA_ROWC_STORE(1)
-        lds_dma_wait_all();
-        __syncthreads();
-        if (j + 1 < n_items) {
-            if (j + 2 < n_items) {
-                FA_DMA_QG(j + 2, 0)
-                FA_ROWC_LOAD(j + 2)
+    for (int j0 = 0; j0 < n_items; j0 += NB) {
+        fa_static_for<0, NB>([&](auto ki_) {
+            constexpr int k_ = decltype(ki_)::value;
+            const int j = j0 + k_;
+            if (j < n_items) {                                   // (workgroup-uniform)
+                const bool more = j + NB - 1 < n_items;
+                if (more) {
+                    FA_ROWC_LOAD(j + NB - 1)
+                    FA_DMA_QG(j + NB - 1, (k_ + NB - 1) % NB)
+                }
+                FA_DKDV_TILE(j, k_)
+                if (more) FA_ROWC_STORE((k_ + NB - 1) % NB)
+                if (more && NB > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NB - 2)) : "memory");
+                else lds_dma_wait_all();
+                __syncthreads();
             }
-            FA_DKDV_TILE(j + 1, 1)
-            if (j + 2 < n_items) FA_ROWC_STORE(0)
-            lds_dma_wait_all();
-            __syncthreads();
-        }
+        });
     }
 #undef FA_ITEM
 #undef FA_DMA_QG
