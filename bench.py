@@ -18,7 +18,7 @@ line and the exit code.
 `value` is end-to-end (gather included); `roofline.achieved` is kernel-only (HIP events around the launches) and
 `kernel_only_value` repeats it as a whole-job figure.
 
-N = 1 also reports, in `secondary`, the other single-GPU configs of BASELINE.json (cfg3 long context, the cfg5
+N = 1 also reports, in `secondary`, a small-grid shape (split-KV plan), the backward at cfg2, and the other single-GPU configs of BASELINE.json (cfg3 long context, the cfg5
 per-GPU shard shape, and cfg4: a GPT-2-small forward step through the automatic SDPA override with the attention
 share) - the headline stays cfg2.
 
@@ -164,6 +164,31 @@ def secondary_attention(name, dev, steps=20, warmup=5):
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / PEAK_TFLOPS, 4), "traffic": profiled_traffic(name, plan)[0],
                          "kernel": kernel_name(plan), "avg_launch_ms": round(ms, 4), "algorithmic_bytes": 4 * G * L * D * 2}}
+
+
+def secondary_backward(name, dev, steps=10, warmup=3):
+    """the backward of the packed op at a BASELINE shape (fa_bwd through the C ABI: dQ kernel + dK/dV kernel per call),
+    on the 5 G L^2 D convention (2.5x the forward's FLOPs; the kernels execute 3.5x: scores are recomputed in both)."""
+    import torch
+    import flash_attention_amd as fa
+    from flash_attention_amd._impl import _native
+
+    G, L, D, dname, (nq, nk) = CONFIGS[name]
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dname]
+    gen = torch.Generator(device=dev).manual_seed(2)
+    qkv = (torch.randn(3, G, L, D, device=dev, generator=gen) * 0.5).to(dtype)
+    dout = torch.randn(G, L, D, device=dev, generator=gen).to(dtype)
+    from flash_attention_amd._impl.flash_attention_qkv_packed import flash_attention_qkv_packed_with_lse
+    out, lse = flash_attention_qkv_packed_with_lse(qkv, nq, nk)
+    dqkv = torch.empty_like(qkv)
+    ms = time_kernel(lambda: _native.bwd(qkv[0], qkv[1], qkv[2], out, dout, lse, dqkv[0], dqkv[1], dqkv[2], G, L, D, 1, 1.0, True),
+                     steps, warmup, ramp_ms=60.0)
+    tf = 5.0 * G * L * L * D / (ms * 1e-3) / 1e12
+    return {"metric": f"bwd_attention_tflops_causal_L{L}_D{D}", "value": round(tf, 2), "unit": "TFLOP/s", "dtype": dname,
+            "config": {"workload": f"{name}: gradients of packed qkv [3,{G},{L},{D}] {dname}, causal (fa_bwd: dQ + dK/dV kernels)"},
+            "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "flops_convention": "5*G*L^2*D",
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS, 4),
+                         "traffic": None, "kernel": "fa_bwd_dq_kernel + fa_bwd_dkdv_kernel"}}
 
 
 def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
@@ -528,6 +553,10 @@ def main():
                         sec[name] = secondary_attention(name, dev)
                     except Exception as e:  # noqa: BLE001  (a secondary record must never cost the headline)
                         sec[name] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                sec["cfg2_bwd"] = secondary_backward("cfg2", dev)
+            except Exception as e:  # noqa: BLE001
+                sec["cfg2_bwd"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 sec["cfg4_gpt2_fwd"] = secondary_gpt2_forward(dev)
             except Exception as e:  # noqa: BLE001
