@@ -301,9 +301,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--ramp-ms", type=float, default=150.0,
-                    help="untimed clock ramp before the W warm-up steps: an idle MI355X needs ~30-100 ms of load "
-                         "to reach its sustained clock (measured: 784 TFLOP/s after 10 warm-up launches, 886 after 400)")
+    ap.add_argument("--ramp-ms", type=float, default=400.0,
+                    help="untimed clock ramp before the W warm-up steps: an idle MI355X needs ~60 ms of load to come within 1.5 %% "
+                         "of its sustained clock and seconds for the rest (scripts/clock_ramp.py: 838 TFLOP/s after 7 ms, 1031 after "
+                         "60 ms, 1036 after 0.3 s, 1045 after 3 s)")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the cfg3 / cfg4 / cfg5-shard records")
