@@ -640,3 +640,29 @@ def test_differential_fuzz_of_the_kernel_variants():
     msgs = []
     bad, _ = fuzz(40, 20260, log=msgs.append)
     assert bad == 0, "\n".join(m for m in msgs if m.startswith("MISMATCH"))
+
+
+def test_graft_entry_smoke_runs():
+    """`__graft_entry__.smoke()` - what the driver runs on the GPU box before the bench - must pass with the shipped tuning
+    table (its plan check follows the table, not a fixed kernel)."""
+    import __graft_entry__
+
+    __graft_entry__.smoke()
+
+
+def test_bench_short_timed_region_is_not_slower_than_a_long_one():
+    """bench.py's headline must not depend on K: a 20-step timed region (the driver's round-1 setting) against a 200-step one,
+    both after the untimed ramp that carries the device past its one-time stall ~0.5 s after load onset (bench.py --ramp-ms)."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    vals = {}
+    for k in (20, 200):
+        res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", str(k), "--warmup", "5",
+                              "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        vals[k] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])["value"]
+    assert vals[20] >= 0.95 * vals[200], vals
