@@ -49,6 +49,9 @@ CONFIGS = {
     "cfg3": (16, 32768, 128, "bf16", (16, 16)),      # configs[2] long context
     "cfg5_shard": (256, 8192, 64, "bf16", (16, 8)),  # configs[4] per-GPU shard at 8 GPUs
     "small_grid": (8, 4096, 64, "bf16", (8, 8)),     # not a BASELINE config: 256 workgroups on 256 CUs (split-KV plan)
+    "l1024": (512, 1024, 64, "bf16", (4, 4)),        # not a BASELINE config: the short-sequence regime on a full grid
+    "cfg4_attn": (96, 1024, 64, "bf16", (4, 4)),     # configs[3]'s attention call alone: SDPA override on head-inner [8,12,1024,64] views
+    "nb_65536": (8, 65536, 64, "f16", (64, 64)),     # the reference notebook's longest demonstrated context (nb:939, :952-963)
     # total work fixed ("strong"): G is the TOTAL group count, G/N per rank
     "cfg5": (2048, 8192, 64, "bf16", (16, 8)),       # configs[4]: batch 64 x heads 32, seq 8192, head_dim 64
 }
@@ -118,6 +121,59 @@ def cpu_baseline(L, D, budget_s=9.0):
     }
 
 
+def make_op(name, dev, seed=1, backward=False):
+    """(fn, flops, kernel names, description) for one launch of a config: the packed op (default), the SDPA override on the
+    head-inner views of a fused [B, T, 3C] projection (cfg4_attn: exactly GPT-2 small's attention call), or fa_bwd."""
+    import torch
+    import flash_attention_amd as fa
+    from flash_attention_amd._impl import _native
+
+    G, L, D, dname, (nq, nk) = CONFIGS[name]
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dname]
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    if backward:
+        qkv = (torch.randn(3, G, L, D, device=dev, generator=gen) * 0.5).to(dtype)
+        dout = torch.randn(G, L, D, device=dev, generator=gen).to(dtype)
+        from flash_attention_amd._impl.flash_attention_qkv_packed import flash_attention_qkv_packed_with_lse
+        out, lse = flash_attention_qkv_packed_with_lse(qkv, nq, nk)
+        dqkv = torch.empty_like(qkv)
+        fn = lambda: _native.bwd(qkv[0], qkv[1], qkv[2], out, dout, lse, dqkv[0], dqkv[1], dqkv[2], G, L, D, 1, 1.0, True)  # noqa: E731
+        return fn, 5.0 * G * L * L * D, "fa_bwd_dq_kernel + fa_bwd_dkdv_kernel", \
+            f"{name}: gradients of packed qkv [3,{G},{L},{D}] {dname}, causal (fa_bwd: dQ + dK/dV kernels)", None
+    if name == "cfg4_attn":
+        import torch.nn.functional as F
+        import flash_attention_amd.auto  # noqa: F401
+        B, H = 8, 12
+        proj = torch.randn(B, L, 3 * H * D, device=dev, generator=gen).to(dtype)
+        q, k, v = (t.view(B, L, H, D).transpose(1, 2) for t in proj.split(H * D, dim=2))
+
+        def fn():
+            with torch.no_grad():
+                return F.scaled_dot_product_attention(q, k, v, is_causal=True)
+        plan = _native.plan(G, L, D, dtype, nq, nk, softmax_scale=D ** -0.5)
+        return fn, 2.0 * G * L * L * D, kernel_name(plan), \
+            f"{name}: F.scaled_dot_product_attention(is_causal=True) through the override on head-inner [{B},{H},{L},{D}] {dname} views of a [B,T,3C] projection", plan
+    qkv = torch.randn(3, G, L, D, device=dev, generator=gen).to(dtype)
+    plan = _native.plan(G, L, D, dtype, nq, nk)
+    return (lambda: fa.flash_attention_qkv_packed(qkv, nq, nk)), 2.0 * G * L * L * D, kernel_name(plan), \
+        f"{name}: packed qkv [3,{G},{L},{D}] {dname}, causal, num_chunks=({nq},{nk})", plan
+
+
+def per_step_ms(fn, steps):
+    """Per-step durations from HIP events between consecutive steps (a pass of its own: the headline's timed region carries no
+    events inside it) -> (median, min) in ms."""
+    import torch
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    d = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    return d[len(d) // 2], d[0]
+
+
 def time_kernel(fn, steps, warmup, ramp_ms=0.0):
     """avg ms per call of fn() on the current stream: untimed ramp + warm-up, then HIP events around `steps` calls."""
     import torch
@@ -143,52 +199,30 @@ def time_kernel(fn, steps, warmup, ramp_ms=0.0):
     return e0.elapsed_time(e1) / steps
 
 
-def secondary_attention(name, dev, steps=20, warmup=5):
-    """One of the other single-GPU BASELINE configs through the same op: value + roofline (kernel-only)."""
-    import torch
-    import flash_attention_amd as fa
-    from flash_attention_amd._impl import _native
+def roofline_record(tf, ms, kname, config, plan, algorithmic_bytes):
+    traffic, note = profiled_traffic(config, plan, kname)
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS, 4),
+            "traffic": traffic, "traffic_note": note,
+            "hbm_gbps": round(traffic / (ms * 1e-3) / 1e9, 1) if traffic else None,
+            "kernel": kname, "avg_launch_ms": round(ms, 4), "algorithmic_bytes": algorithmic_bytes}
 
+
+def secondary_attention(name, dev, steps=20, warmup=5, backward=False):
+    """One of the other single-GPU configs through the same op (or fa_bwd): value + roofline (kernel-only)."""
     G, L, D, dname, (nq, nk) = CONFIGS[name]
-    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dname]
-    qkv = torch.randn(3, G, L, D, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(dtype)
-    ms = time_kernel(lambda: fa.flash_attention_qkv_packed(qkv, nq, nk), steps, warmup, ramp_ms=60.0)
-    flops = 2.0 * G * L * L * D
-    plan = _native.plan(G, L, D, dtype, nq, nk)
+    fn, flops, kname, desc, plan = make_op(name, dev, backward=backward)
+    ms = time_kernel(fn, steps, warmup, ramp_ms=60.0)
+    med, mn = per_step_ms(fn, steps)
     tf = flops / (ms * 1e-3) / 1e12
-    return {"metric": f"fwd_attention_tflops_causal_L{L}_D{D}", "value": round(tf, 2), "unit": "TFLOP/s", "dtype": dname,
-            "config": {"workload": f"{name}: packed qkv [3,{G},{L},{D}] {dname}, causal, num_chunks=({nq},{nk})",
-                       "tile": f"{plan.block_q} query rows x {plan.block_kv} keys ({plan.waves} waves, {plan.qb} query blocks per wave"
-                               + (f", {32 * plan.waves * plan.qb // plan.block_q} kv split groups)" if 32 * plan.waves * plan.qb > plan.block_q else ")")},
-            "steps": steps, "warmup": warmup,
-            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / PEAK_TFLOPS, 4), "traffic": profiled_traffic(name, plan)[0],
-                         "kernel": kernel_name(plan), "avg_launch_ms": round(ms, 4), "algorithmic_bytes": 4 * G * L * D * 2}}
-
-
-def secondary_backward(name, dev, steps=10, warmup=3):
-    """the backward of the packed op at a BASELINE shape (fa_bwd through the C ABI: dQ kernel + dK/dV kernel per call),
-    on the 5 G L^2 D convention (2.5x the forward's FLOPs; the kernels execute 3.5x: scores are recomputed in both)."""
-    import torch
-    import flash_attention_amd as fa
-    from flash_attention_amd._impl import _native
-
-    G, L, D, dname, (nq, nk) = CONFIGS[name]
-    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dname]
-    gen = torch.Generator(device=dev).manual_seed(2)
-    qkv = (torch.randn(3, G, L, D, device=dev, generator=gen) * 0.5).to(dtype)
-    dout = torch.randn(G, L, D, device=dev, generator=gen).to(dtype)
-    from flash_attention_amd._impl.flash_attention_qkv_packed import flash_attention_qkv_packed_with_lse
-    out, lse = flash_attention_qkv_packed_with_lse(qkv, nq, nk)
-    dqkv = torch.empty_like(qkv)
-    ms = time_kernel(lambda: _native.bwd(qkv[0], qkv[1], qkv[2], out, dout, lse, dqkv[0], dqkv[1], dqkv[2], G, L, D, 1, 1.0, True),
-                     steps, warmup, ramp_ms=60.0)
-    tf = 5.0 * G * L * L * D / (ms * 1e-3) / 1e12
-    return {"metric": f"bwd_attention_tflops_causal_L{L}_D{D}", "value": round(tf, 2), "unit": "TFLOP/s", "dtype": dname,
-            "config": {"workload": f"{name}: gradients of packed qkv [3,{G},{L},{D}] {dname}, causal (fa_bwd: dQ + dK/dV kernels)"},
-            "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "flops_convention": "5*G*L^2*D",
-            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS, 4),
-                         "traffic": None, "kernel": "fa_bwd_dq_kernel + fa_bwd_dkdv_kernel"}}
+    rec = {"metric": f"{'bwd' if backward else 'fwd'}_attention_tflops_causal_L{L}_D{D}", "value": round(tf, 2), "unit": "TFLOP/s", "dtype": dname,
+           "config": {"workload": desc}, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "median_ms": round(med, 4), "min_ms": round(mn, 4),
+           "roofline": roofline_record(tf, ms, kname, name + ("_bwd" if backward else ""), plan, (8 if backward else 4) * G * L * D * 2)}
+    if backward:
+        rec["flops_convention"] = "5*G*L^2*D (the kernels execute 7: scores are recomputed in both)"
+    elif plan is not None:
+        rec["config"]["tile"] = (f"{plan.block_q} query rows x {plan.block_kv} keys ({plan.waves} waves, {plan.qb} query blocks per wave"
+                                 + (f", {32 * plan.waves * plan.qb // plan.block_q} kv split groups)" if 32 * plan.waves * plan.qb > plan.block_q else ")"))
+    return rec
 
 
 def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
@@ -267,8 +301,12 @@ def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
             "attention_tflops": round(tf, 2),
             "fwd_step_ms_stock_torch_sdpa": round(stock_ms, 3),
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None, "kernel": f"{kernel_name(plan)} (12 launches per step, "
+                         "frac": round(tf / PEAK_TFLOPS, 4), "traffic": profiled_traffic("cfg4_attn", plan)[0],
+                         "traffic_note": "per attention launch, from the PMC passes of the same call timed alone (secondary.cfg4_attn)",
+                         "kernel": f"{kernel_name(plan)} (12 launches per step, "
                          f"[{batch},12,1024,64] head-inner views)", "avg_launch_ms": round(attn_ms / layers, 4),
+                         "avg_launch_note": "HIP events around each of the 12 calls inside the model step (event and launch gaps included; "
+                                            "the same call back to back: secondary.cfg4_attn)",
                          "algorithmic_bytes": 4 * batch * H * T * hs * 2}}
 
 
@@ -277,7 +315,7 @@ def kernel_name(plan):
             4: "fa_fwd_pipe16_kernel"}[plan.kernel]
 
 
-def profiled_traffic(config, plan):
+def profiled_traffic(config, plan, kname=None):
     """HBM bytes per launch from the PMC passes of scripts/profile.sh (profiles/hbm_traffic.json), valid only for
     the kernel sources and the kernel it was measured on - otherwise null with the reason."""
     tfile = ROOT / "profiles" / "hbm_traffic.json"
@@ -291,8 +329,9 @@ def profiled_traffic(config, plan):
         return None, f"no PMC record for {config}"
     if rec.get("csrc_sha256_16") != csrc_fingerprint():
         return None, f"PMC record is for kernel sources {rec.get('csrc_sha256_16')}, this build is {csrc_fingerprint()}: re-run scripts/profile.sh"
-    if rec.get("kernel") and not rec["kernel"].startswith(kernel_name(plan)):
-        return None, f"PMC record is for {rec.get('kernel')}, this run launched {kernel_name(plan)}"
+    kname = kname or kernel_name(plan)
+    if rec.get("kernel") and not kname.startswith(rec["kernel"].split(" ")[0]):
+        return None, f"PMC record is for {rec.get('kernel')}, this run launched {kname}"
     return rec.get("hbm_bytes_per_launch"), f"rocprofv3 PMC passes ({rec.get('source', 'profiles/')}), FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE"
 
 
@@ -314,6 +353,10 @@ def main():
     ap.add_argument("--gather", default="allgather", choices=("allgather", "direct", "root"),
                     help="N>1: RCCL all-gather (default), direct point-to-point gather, or gather to rank 0")
     ap.add_argument("--slabs", type=int, default=8, help="cfg5: slabs per rank (gather of slab s under the kernel of slab s+1)")
+    ap.add_argument("--backward", action="store_true", help="N=1: time fa_bwd (dQ + dK/dV kernels) of the config instead of the forward")
+    ap.add_argument("--no-probes", action="store_true",
+                    help="skip the MFMA-peak probes, the clock sampler and the per-step event pass after the timed region: the LAST --steps "
+                         "dispatches of the kernel are then the timed region (scripts/profile.sh computes its kernel statistics over them)")
     ap.add_argument("--print-csrc-fingerprint", action="store_true")
     args = ap.parse_args()
     if args.print_csrc_fingerprint:
@@ -367,6 +410,15 @@ def main():
     g_launch = G // args.slabs if strong else G    # groups per kernel launch
     plan = _native.plan(g_launch, L, D, dtype, nq, nk)
 
+    if world > 1 and (args.backward or args.config == "cfg4_attn"):
+        raise SystemExit("--backward / cfg4_attn are single-GPU records")
+    op_fn, op_flops, op_kernel, op_desc = None, None, None, None
+    if world == 1 and not strong and (args.backward or args.config == "cfg4_attn"):
+        del qkv
+        op_fn, op_flops, op_kernel, op_desc, plan_ = make_op(args.config, dev, seed=rank, backward=args.backward)
+        plan = plan_ or plan
+        flops_step = op_flops
+
     do_gather = world > 1 and not args.no_gather
     use_gloo = rehearse
     launches_per_step = args.slabs if strong else 1
@@ -399,7 +451,7 @@ def main():
             if record[0]:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            out = fa.flash_attention_qkv_packed(qkv, nq, nk)
+            out = op_fn() if op_fn is not None else fa.flash_attention_qkv_packed(qkv, nq, nk)
             if record[0]:
                 e1.record()
                 kernel_events.append((e0, e1))
@@ -414,6 +466,7 @@ def main():
                     pending[b][1].wait()
                     pending[b] = None
 
+    ramp_info = None
     step(0)                      # first call pays one-off host costs (library load, op registration)
     drain()
     torch.cuda.synchronize()
@@ -433,13 +486,27 @@ def main():
             if (i + 1) % 16 == 0:
                 torch.cuda.synchronize()
     else:
+        # groups of 16 steps between events: the slowest group stays visible in the JSON line (`ramp`): the idle -> sustained
+        # clock transition of the device, including the one-time stall DESIGN.md 3.8 describes, happens here and not in the timed region
         t_ramp = time.perf_counter()
         i_ramp = 0
+        g_ev = [(0.0, torch.cuda.Event(enable_timing=True))]
+        g_ev[0][1].record()
         while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
             step(i_ramp)
             i_ramp += 1
             if i_ramp % 16 == 0:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
                 torch.cuda.synchronize()
+                g_ev.append(((time.perf_counter() - t_ramp) * 1e3, e))
+        if len(g_ev) > 1:
+            durs = [(g_ev[i][1].elapsed_time(g_ev[i + 1][1]) / 16, g_ev[i + 1][0]) for i in range(len(g_ev) - 1)]
+            slow = max(durs)
+            srt = sorted(d for d, _ in durs)
+            ramp_info = {"ms": args.ramp_ms, "groups_of_16_steps": len(durs), "median_group_ms_per_step": round(srt[len(srt) // 2], 4),
+                         "slowest_group_ms_per_step": round(slow[0], 4), "slowest_group_ended_at_ms": round(slow[1], 1),
+                         "first_group_ms_per_step": round(durs[0][0], 4)}
     drain()
     torch.cuda.synchronize()
     for i in range(args.warmup):
@@ -486,32 +553,46 @@ def main():
     elapsed, kernel_ms = t[0].item(), t[1].item()
 
     rc = 0
+    median_ms = min_ms = None
+    if world == 1 and not strong and not args.no_probes:
+        median_ms, min_ms = per_step_ms(lambda: step(0), args.steps)     # median and min, a pass of its own
     if rank == 0:
         lib_ = _native.load_native_library()
-        with torch.cuda.device(dev):
+        measured_peak = measured_peak_random = clock_mhz = None
+        if not args.no_probes:
+          with torch.cuda.device(dev):
             mp = lib_.fa_probe_mfma_peak(_native.FA_DTYPE[dtype], 4000, 0)
             mpr = lib_.fa_probe_mfma_peak(_native.FA_DTYPE[dtype], 40000, 1)   # ~30 ms per repetition: clock settles
-        measured_peak = round(mp, 1) if mp > 0 else None
-        measured_peak_random = round(mpr, 1) if mpr > 0 else None
+          measured_peak = round(mp, 1) if mp > 0 else None
+          measured_peak_random = round(mpr, 1) if mpr > 0 else None
         # which core clock does the device hold under this load?  (untimed repeat of the kernel with a one-wave clock
         # sampler on a side stream: the kernels are power-bound; nominal peak assumes 2400 MHz)
-        qk = qkv[:, :g_launch].contiguous() if strong else qkv
-        side = torch.cuda.Stream(device=dev)
-        buf = torch.zeros(2, dtype=torch.int64, device=dev)
-        n_rep = max(8 + 2, int(60.0 / max(kernel_ms, 1e-3)))                   # >= 60 ms of load
-        for i in range(n_rep):
-            fa.flash_attention_qkv_packed(qk, nq, nk)                           # (kernel only: no collective on one rank)
-            if i == 8:                                                          # the load is running: start sampling
-                lib_.fa_probe_clock(buf.data_ptr(), 15000, side.cuda_stream)   # ~30-40 ms
-        torch.cuda.synchronize()
-        cyc, ticks = (int(x) for x in buf.tolist())
-        clock_mhz = round(cyc / ticks * 100.0) if ticks > 0 else None
+        if not args.no_probes:
+            if op_fn is not None:
+                probe_fn = op_fn
+            else:
+                qk = qkv[:, :g_launch].contiguous() if strong else qkv
+                probe_fn = lambda: fa.flash_attention_qkv_packed(qk, nq, nk)   # noqa: E731  (kernel only: no collective on one rank)
+            side = torch.cuda.Stream(device=dev)
+            buf = torch.zeros(2, dtype=torch.int64, device=dev)
+            n_rep = max(8 + 2, int(60.0 / max(kernel_ms, 1e-3)))                   # >= 60 ms of load
+            for i in range(n_rep):
+                probe_fn()
+                if i == 8:                                                          # the load is running: start sampling
+                    lib_.fa_probe_clock(buf.data_ptr(), 15000, side.cuda_stream)   # ~30-40 ms
+            torch.cuda.synchronize()
+            cyc, ticks = (int(x) for x in buf.tolist())
+            clock_mhz = round(cyc / ticks * 100.0) if ticks > 0 else None
 
         total_tflops = world * flops_step * args.steps / elapsed / 1e12
-        flops_launch = 2.0 * g_launch * L * L * D
+        flops_launch = op_flops if op_fn is not None else 2.0 * g_launch * L * L * D
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
-        traffic, traffic_note = profiled_traffic(args.config if not strong else "cfg5_slab", plan)
+        kname = op_kernel if op_fn is not None else kernel_name(plan)
+        tkey = "cfg5_slab" if strong else args.config + ("_bwd" if args.backward else "")
+        traffic, traffic_note = profiled_traffic(tkey, plan, kname)
         metric = "fwd_attention_tflops_causal_L4096_D64" if args.config.startswith("cfg2") else f"fwd_attention_tflops_causal_L{L}_D{D}_{args.config}"
+        if args.backward:
+            metric = f"bwd_attention_tflops_causal_L{L}_D{D}_{args.config}"
         exchange = "none"
         if do_gather:
             exchange = {"allgather": "rccl all-gather of O", "direct": "direct point-to-point gather of O (rccl send/recv)",
@@ -523,7 +604,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": dname,
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: packed qkv [3,{G},{L},{D}] {dname} per GPU"
+            "median_ms": round(median_ms, 4) if median_ms is not None else None,
+            "min_ms": round(min_ms, 4) if min_ms is not None else None,
+            "median_min_note": "per-step HIP events in a pass of its own after the timed region (BASELINE.md section 2)",
+            "ramp": ramp_info,
+            "config": {"workload": op_desc if op_fn is not None else
+                                   f"{args.config}: packed qkv [3,{G},{L},{D}] {dname} per GPU"
                                    + (f" ({Gc} groups in total over {world} GPUs)" if strong else "")
                                    + f", causal, num_chunks=({nq},{nk}), flash_attention_qkv_packed forward",
                        "groups_per_gpu": G, "seq_len": L, "head_dim": D,
@@ -538,26 +624,29 @@ def main():
             "kernel_only_value": round(world * achieved, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "hbm_gbps": round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
+                         "hbm_gbps_note": "fabric bytes per launch (PMC) / average launch duration; algorithmic bytes / launch = "
+                                          f"{round(4 * g_launch * L * D * 2 / (kernel_ms * 1e-3) / 1e9, 1)} GB/s",
                          "shader_clock_mhz_under_load": clock_mhz,
                          "frac_at_that_clock": round(achieved / (PEAK_TFLOPS * clock_mhz / 2400.0), 4) if clock_mhz else None,
                          "measured_mfma_peak": measured_peak,
                          "frac_of_measured_peak": round(achieved / measured_peak, 4) if measured_peak else None,
                          "measured_mfma_peak_random_operands": measured_peak_random,
                          "frac_of_measured_peak_random_operands": round(achieved / measured_peak_random, 4) if measured_peak_random else None,
-                         "kernel": kernel_name(plan), "avg_launch_ms": round(kernel_ms, 4), "avg_launch_note": kernel_note,
+                         "kernel": kname, "avg_launch_ms": round(kernel_ms, 4), "avg_launch_note": kernel_note,
                          "flops_per_launch": flops_launch,
                          "algorithmic_bytes": 4 * g_launch * L * D * 2},
         }
         if world == 1 and not args.no_secondary and not strong:
             sec = {}
-            for name in ("cfg3", "cfg5_shard", "small_grid"):
+            for name in ("cfg3", "cfg5_shard", "small_grid", "l1024", "cfg4_attn", "nb_65536"):
                 if name != args.config:
                     try:
                         sec[name] = secondary_attention(name, dev)
                     except Exception as e:  # noqa: BLE001  (a secondary record must never cost the headline)
                         sec[name] = {"error": f"{type(e).__name__}: {e}"}
             try:
-                sec["cfg2_bwd"] = secondary_backward("cfg2", dev)
+                sec["cfg2_bwd"] = secondary_attention("cfg2", dev, steps=10, warmup=3, backward=True)
             except Exception as e:  # noqa: BLE001
                 sec["cfg2_bwd"] = {"error": f"{type(e).__name__}: {e}"}
             try:

@@ -1,0 +1,31 @@
+// Backward of a forward that ran with an attention mask / additive bias and / or dropout (fa_extras.h).  The kernels
+// ARE fa_bwd_dq_body / fa_bwd_dkdv_body (fa_bwd_kernels.hip) instantiated with EXTRA = true: the mask terms go onto the recomputed
+// scores, the dropout decisions are regenerated from (seed, offset, g, row, col) - the same pure function the forward used.
+// Deterministic like the plain backward: no gradient is summed across workgroups.  No gradient flows to a bias.
+#define FA_BWD_BODY_ONLY 1
+#include "fa_bwd_kernels.hip"
+
+namespace fa {
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void fa_bwd_dq_extra_kernel(const BwdParams p) {
+    fa_bwd_dq_body<T, D, 4, true>(p);
+}
+template <typename T, int D>
+__global__ __launch_bounds__(256) void fa_bwd_dkdv_extra_kernel(const BwdParams p) {
+    fa_bwd_dkdv_body<T, D, 4, true>(p);
+}
+
+template <typename T, int D>
+static hipError_t launch_bwd_extra_t(const BwdParams& p, hipStream_t stream) {
+    hipError_t e = launch1((const void*)(fa_bwd_dq_extra_kernel<T, D>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
+    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_extra_kernel<T, D>), dim3((unsigned)((int64_t)p.G8kv * p.nk_tiles)), dim3(256), 0, stream, p);
+    return e;
+}
+
+hipError_t launch_bwd_extra(const BwdParams& p, int dtype, hipStream_t stream) {
+    if (dtype == 1) return p.D == 64 ? launch_bwd_extra_t<__bf16, 64>(p, stream) : launch_bwd_extra_t<__bf16, 128>(p, stream);
+    return p.D == 64 ? launch_bwd_extra_t<_Float16, 64>(p, stream) : launch_bwd_extra_t<_Float16, 128>(p, stream);
+}
+
+}  // namespace fa

@@ -24,6 +24,7 @@
 // documented in fa_fwd_kernels.hip / fa_fwd_dma.hip.
 
 #include "fa_device.h"
+#include "fa_extras.h"
 
 #ifndef FA_BWD_NBUF
 #define FA_BWD_NBUF(D_) 2   /* streamed-tile buffers per operand; 3 at head_dim 64 (-DFA_BWD_NBUF\(D_\)=...) measured +0.2..0.9 %: not worth 16 KB of LDS */
@@ -76,7 +77,10 @@ __device__ __forceinline__ bool bwd_block_map(int G8, int G, int sched, int nblk
 // ---------------------------------------------------------------------------------------------
 // dQ: one workgroup = NWAVES x 32 query rows; streams K and V tiles of 64 keys
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int NWAVES>
+// EXTRA: the forward ran with an attention mask / bias and / or dropout (fa_extras.h): the same additive terms go onto the recomputed
+// scores, the dropout decisions are regenerated from (seed, offset, g, row, col):  dP = keep ? dP_raw / (1 - p) : 0  before
+// dS = P o (dP - Dsum)  (Dsum = rowsum(dO o O) still equals sum_j P_j dP_j);  dV sees  keep ? P / (1 - p) : 0.
+template <typename T, int D, int NWAVES, bool EXTRA = false>
 __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -114,7 +118,12 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             dof[ks] = *(const vec8*)(gp + 16 * ks);
         }
     }
-    const float lse2 = p.lse[(int64_t)g * L + qr] * LOG2E;
+    // (a row whose every key was masked has lse = -inf and P = 0: its exponent offset is taken as 0, never inf - inf)
+    const float lse_row = p.lse[(int64_t)g * L + qr];
+    const float lse2 = (EXTRA && lse_row == -INFINITY) ? 0.f : lse_row * LOG2E;
+    const int mask_esz = p.ex.mask_kind == 2 ? (int)sizeof(T) : 1;
+    const char* const mrow = EXTRA && p.ex.mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh + (int64_t)qr * p.ex.m_sl) * mask_esz : nullptr;
+    const unsigned drop_kg = EXTRA ? drop_group_key(p.ex.drop_key0, (unsigned)g) : 0u;
     // Dsum = rowsum(dO o O) of this lane's row (FA.cpp:375-378), from the dO fragments already in registers and the
     // matching O fragments; the two half-waves hold the two halves of the row.  Published for fa_bwd_dkdv_kernel,
     // which runs after this kernel on the same stream (this replaces a separate pass over dO and O).
@@ -189,6 +198,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
                              one dP tile live at a time - the head_dim 128 dK/dV kernel then fits two waves per SIMD, the others gain a
                              wave, and a half that lies wholly behind the causal diagonal is skipped; 0: both halves at once */
 #endif
+    static_assert(!EXTRA || FA_BWD_HALVES, "mask / dropout: the two-halves tile bodies only");
 #if FA_BWD_HALVES
 #define FA_DQ_TILE(T_, BUF_)                                                                       \
     {                                                                                              \
@@ -205,10 +215,31 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
                     s0 = E::mfma(*(const vec8*)(kb_ + 2048 * hb + a_rd[ks]), qf[ks], s0);          \
                     t0 = E::mfma(*(const vec8*)(vb_ + 2048 * hb + a_rd[ks]), dof[ks], t0);         \
                 }                                                                                  \
+                if constexpr (EXTRA) {                                                             \
+                    if (mrow != nullptr) {                                                         \
+                        const bool fast_ = p.ex.mask_vec != 0 && kv0 + BK <= L;                    \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                            \
+                            float a_[4];                                                           \
+                            mask_load4<T>(p.ex.mask_kind, fast_, mrow, kv0 + 32 * hb + 8 * j + 4 * h, L, p.ex.inv_scale, a_); \
+                            _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += a_[i];  \
+                        }                                                                          \
+                    }                                                                              \
+                }                                                                                  \
                 if (kv0 + 32 * hb + 31 > wave_last) {                                              \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) {                               \
                         const int key = kv0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;            \
                         if (key > klim) s0[e] = -INFINITY;                                         \
+                    }                                                                              \
+                }                                                                                  \
+                if constexpr (EXTRA) {                                                             \
+                    if (p.ex.drop_thr != 0u) {   /* t0 = dP_raw - Dsum  ->  keep ? dP_raw / (1 - p) - Dsum : -Dsum */ \
+                        const unsigned col0_ = (unsigned)(kv0 + 32 * hb);                          \
+                        const unsigned base_ = drop_tile_key(drop_kg, (unsigned)qrow, col0_) ^ (((unsigned)qrow & 0xffffu) << 16) ^ ((col0_ & 0xffffu) | (unsigned)(4 * h)); \
+                        const float dd_ = ndsum * (1.f - p.ex.drop_rp);     /* = Dsum (rp - 1) */  \
+                        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                           \
+                            const unsigned ce_ = (unsigned)((e & 3) + 8 * (e >> 2));               \
+                            t0[e] = mix32(base_ ^ ce_) < p.ex.drop_thr ? ndsum : __builtin_fmaf(t0[e], p.ex.drop_rp, dd_); \
+                        }                                                                          \
                     }                                                                              \
                 }                                                                                  \
                 /* dS^T = P^T o (dP^T - Dsum), P^T = 2^(S^T c - lse2): the row constants are lane scalars */ \
@@ -322,15 +353,17 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     }
 }
 
+#ifndef FA_BWD_BODY_ONLY
 template <typename T, int D, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dq_kernel(const BwdParams p) {
     fa_bwd_dq_body<T, D, NWAVES>(p);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // dK, dV: one workgroup = NWAVES x 32 keys; streams Q and dO tiles of 64 query rows
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int NWAVES>
+template <typename T, int D, int NWAVES, bool EXTRA = false>
 __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -376,6 +409,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         }
     }
     const float c = p.scale_log2;
+    const int mask_esz = p.ex.mask_kind == 2 ? (int)sizeof(T) : 1;
 
     const unsigned q_slb = (unsigned)p.q_sl * 2, g_slb = (unsigned)p.do_sl * 2;
     unsigned q_vo[PPW], g_vo[PPW];
@@ -418,7 +452,10 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         FA_ITEM(J_, hq_, it_)                                                                      \
         const int rr_ = it_ * BQ + (tid & 63);                                                     \
         rc_stage = (tid < 64) ? INFINITY : 0.f;                                                    \
-        if (tid < 64 && rr_ < L) rc_stage = lse_g0[(int64_t)hq_ * L + rr_] * LOG2E;                \
+        if (tid < 64 && rr_ < L) {                                                                 \
+            const float l_ = lse_g0[(int64_t)hq_ * L + rr_];                                       \
+            rc_stage = (EXTRA && l_ == -INFINITY) ? INFINITY : l_ * LOG2E;   /* a fully masked row: P = 0 */ \
+        }                                                                                          \
         if (tid >= 64 && tid < 128 && rr_ < L) rc_stage = -dsum_g0[(int64_t)hq_ * L + rr_];   /* negated: see the dP accumulators */ \
     }
 #define FA_ROWC_STORE(BUF_) \
@@ -450,7 +487,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #define FA_DKDV_TILE(J_, BUF_)                                                                     \
     {                                                                                              \
         FA_ITEM(J_, hqt_, itt_)                                                                    \
-        (void)hqt_;                                                                                \
+        (void)hqt_; (void)mask_esz;                                                                \
         const int q0 = itt_ * BQ;                                                                  \
         if (wave_active && (!causal || q0 + BQ - 1 >= key0)) {                                     \
             const unsigned char* qb_ = smem + (BUF_) * IMG_B;                                      \
@@ -468,6 +505,15 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                     s0 = E::mfma(*(const vec8*)(qb_ + 2048 * hb + a_rd[ks]), kf[ks], s0);          \
                     t0 = E::mfma(*(const vec8*)(gb_ + 2048 * hb + a_rd[ks]), vf[ks], t0);          \
                 }                                                                                  \
+                if constexpr (EXTRA) {                                                             \
+                    if (p.ex.mask != nullptr) {   /* mask[row][this lane's key], one row per register */ \
+                        const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqt_) * p.ex.m_sh) * mask_esz; \
+                        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                           \
+                            const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;          \
+                            s0[e] += mask_load1<T>(p.ex.mask_kind, mb_, (int64_t)(qq < L ? qq : L - 1) * p.ex.m_sl, kr, p.ex.inv_scale); \
+                        }                                                                          \
+                    }                                                                              \
+                }                                                                                  \
                 if (causal && q0 + 32 * hb < key0 + 31) { /* diagonal: query < key is masked */    \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) {                               \
                         const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;              \
@@ -479,12 +525,29 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                \
                         const int e = 4 * gq + j;                                                  \
                         s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -la[j]));                       \
-                        t0[e] = s0[e] * t0[e];                                                     \
                     }                                                                              \
                 }                                                                                  \
+                f32x16 pd_ = s0;   /* what dV sees: P, or with dropout keep ? P / (1 - p) : 0 */    \
+                if constexpr (EXTRA) {                                                             \
+                    if (p.ex.drop_thr != 0u) {                                                     \
+                        const unsigned row0_ = (unsigned)(q0 + 32 * hb);                           \
+                        const unsigned kgq_ = drop_group_key(p.ex.drop_key0, (unsigned)(bb * p.H + hq0 + hqt_)); \
+                        const unsigned base_ = drop_tile_key(kgq_, row0_, (unsigned)key0) ^ (((row0_ & 0xffffu) | (unsigned)(4 * h)) << 16) ^ ((unsigned)key & 0xffffu); \
+                        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                         \
+                            const f32x4 da = *(const f32x4*)(rc_ + 64 + 32 * hb + 8 * gq + 4 * h);   /* -Dsum[row] */ \
+                            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                        \
+                                const int e = 4 * gq + j;                                          \
+                                const bool keep_ = mix32(base_ ^ ((unsigned)((e & 3) + 8 * (e >> 2)) << 16)) >= p.ex.drop_thr; \
+                                pd_[e] = keep_ ? s0[e] * p.ex.drop_rp : 0.f;                       \
+                                t0[e] = keep_ ? __builtin_fmaf(t0[e], p.ex.drop_rp, da[j] * (1.f - p.ex.drop_rp)) : da[j]; \
+                            }                                                                      \
+                        }                                                                          \
+                    }                                                                              \
+                }                                                                                  \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) t0[e] = s0[e] * t0[e];              \
                 vec8 pf[2], dsf[2];                                                                \
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                    \
-                    pf[0][j] = (T)s0[j];  pf[1][j] = (T)s0[8 + j];                                 \
+                    pf[0][j] = (T)pd_[j];  pf[1][j] = (T)pd_[8 + j];                               \
                     dsf[0][j] = (T)t0[j]; dsf[1][j] = (T)t0[8 + j];                                \
                 }                                                                                  \
                 _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                \
@@ -644,6 +707,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     }
 }
 
+#ifndef FA_BWD_BODY_ONLY
 // (head_dim 128: 254 + 4 registers as allocated freely - held to 256 = two waves per SIMD)
 template <typename T, int D, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, D == 128 ? 2 : 1) void fa_bwd_dkdv_kernel(const BwdParams p) {
@@ -664,5 +728,7 @@ hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream) {
     if (dtype == 1) return p.D == 64 ? launch_bwd_t<__bf16, 64>(p, stream) : launch_bwd_t<__bf16, 128>(p, stream);
     return p.D == 64 ? launch_bwd_t<_Float16, 64>(p, stream) : launch_bwd_t<_Float16, 128>(p, stream);
 }
+
+#endif  // FA_BWD_BODY_ONLY
 
 }  // namespace fa

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "fa_extras.h"
 #include "fa_params.h"
 #include "fa_tuning_table.h"
 
@@ -44,9 +45,15 @@ struct Options {
     std::atomic<int> f32_generic{0};
     std::atomic<int> table{1};      // 1 = consult the measured tuning table (fa_tuning_table.h), 0 = built-in rules only
     std::atomic<int> split{0};      // 0 auto, 1 | 2 | 4 kv split groups per workgroup (fa_fwd_dma.hip)
+    std::atomic<int> pair{-1};      // -1 auto, 0 | 1 q-tile pairs per workgroup (fa_fwd_dma.hip, causal)
+    std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
+    std::atomic<int> nsplit{-1};    // -1 auto, n >= 0: MIXED launch of 2-group workgroups with the n heaviest q tiles of a group split (fa_fwd_dma.hip)
 };
 Options g_opt;
 std::once_flag g_opt_once;
+// measurement builds (-DFA_STAMPS): device buffer that receives the phase stamps, and its size in bytes
+std::atomic<void*> g_stamp_buf{nullptr};
+std::atomic<int64_t> g_stamp_bytes{0};
 
 int parse_kernel(const char* v) {   // dma | pipe | pipe16 | tile
     if (!v) return 0;
@@ -64,6 +71,9 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_SKIPMAX")) { if (*e) g_opt.skipmax = atoi(e); }
         if (const char* e = getenv("FA_AMD_F32")) g_opt.f32_generic = e[0] == 'g';
         if (const char* e = getenv("FA_AMD_TABLE")) { if (*e) g_opt.table = atoi(e); }
+        if (const char* e = getenv("FA_AMD_PAIR")) { if (*e) g_opt.pair = atoi(e); }
+        if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
+        if (const char* e = getenv("FA_AMD_NSPLIT")) { if (*e) g_opt.nsplit = atoi(e); }
     });
     return g_opt;
 }
@@ -105,7 +115,44 @@ struct Selection {
     fa_plan_t plan;
     char which;      // 'd' | 'p' | 't' | 'g' generic | 'f' fp32 MFMA
     int split;       // kv split groups per workgroup ('d' only; plan.waves counts all of the workgroup's waves)
+    int pair;        // 'd' only: 1 = a workgroup owns q tiles (nq - 1 - i) and i, one after the other
+    int nsplit;      // 'd' with split 2 only: >= 0 = MIXED launch, that many of a group's heaviest q tiles are split, the rest go two per workgroup
+    int perm_n;      // 'd' only: > 0 = placement-balanced order of the XCD's first perm_n slots
+    uint8_t perm[128];
 };
+
+// Placement-balanced block order for a causal 'd' launch whose workgroups are all resident at once (a grid of at most one
+// round of slots: e.g. GPT-2 small's attention call, 96 groups x 8 q tiles = 768 workgroups on 1024 slots).  Nothing is
+// refilled in such a launch, so the dispatcher's list scheduling cannot even out the 2..16-tile workgroups: the launch lasts as
+// long as the CU with the largest sum of kv tiles.  Observed placement on MI355X (scripts/phase_times.py, profiles/r03_cfg4:
+// speed only, never correctness - any order computes the same result): the blocks of one XCD, b = 8 s + x, go to its 32 CUs
+// round-robin, slot s -> CU s mod 32; with heaviest-first order CU 0 gets {16, 12, 6} tiles = 34 and CU 31 {12, 6, 2} = 20.
+// Greedy longest-processing-time over the CUs (capacity = that CU's slot count) gives 26..28 on every CU.
+//   weight(slot)  kv tiles of the natural order's work item `slot`;  perm[hardware slot] = natural slot
+constexpr int kCusPerXcd = 32;
+int balanced_order(int n_slots, const int* weight, uint8_t* perm) {
+    if (n_slots <= kCusPerXcd || n_slots > 128) return 0;
+    int order[128], load[kCusPerXcd] = {0}, cap[kCusPerXcd], cnt[kCusPerXcd] = {0};
+    int items[kCusPerXcd][4];
+    for (int c = 0; c < kCusPerXcd; ++c) cap[c] = (n_slots - c + kCusPerXcd - 1) / kCusPerXcd;
+    for (int i = 0; i < n_slots; ++i) order[i] = i;
+    for (int i = 1; i < n_slots; ++i) {          // insertion sort by weight, descending, stable
+        const int v = order[i];
+        int j = i - 1;
+        while (j >= 0 && weight[order[j]] < weight[v]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = v;
+    }
+    for (int i = 0; i < n_slots; ++i) {
+        int best = -1;
+        for (int c = 0; c < kCusPerXcd; ++c)
+            if (cnt[c] < cap[c] && (best < 0 || load[c] < load[best])) best = c;
+        items[best][cnt[best]++] = order[i];
+        load[best] += weight[order[i]];
+    }
+    for (int c = 0; c < kCusPerXcd; ++c)
+        for (int k = 0; k < cnt[c]; ++k) perm[c + kCusPerXcd * k] = (uint8_t)items[c][k];   // a CU's heaviest item in its first round
+    return n_slots;
+}
 
 int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, float scale, int32_t causal,
                 bool mfma16_ok, bool f32_ok, Selection* sel) {
@@ -120,6 +167,9 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     fa_plan_t* plan = &sel->plan;
     memset(plan, 0, sizeof(*plan));
     sel->split = 1;
+    sel->pair = 0;
+    sel->perm_n = 0;
+    sel->nsplit = -1;
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
     const int64_t g8 = (G + 7) / 8 * 8;
@@ -178,7 +228,53 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
         if (which == 't' && waves > 4) waves = 4;
         if (split > 1 && !(which == 'd' && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
+        // ---- q-tile pairs and the placement-balanced order ('d', causal)
+        int pair = 0;
+        {
+            const int64_t nq128 = (L + 127) / 128;
+            const bool pair_ok = which == 'd' && causal && waves == 4 && qb == 1 && split == 1 && nq128 >= 2;
+            // rule (measured, profiles/r03_pair): pairs pay where the fixed phases of a workgroup are a large share of its life
+            // (L <= 2048) and the paired grid still fills at least one round of the chip's slots
+            // measured (profiles/r03_short/sweep_*.txt): pairs LOSE 2..10 % at L = 1024 .. 4096 (4 resident workgroups per CU already hide each
+            // other's prologues; the pair's second tile waits for the first tile's stores at its first barrier) - built-in rule: off
+            if (opt.pair >= 0) { pair = (opt.pair != 0 && pair_ok) ? 1 : 0; source = 2; }
+        }
+        sel->pair = pair;
+        // MIXED launch (fa_fwd_dma.hip): 8-wave workgroups, the heaviest q tiles split, the others two per workgroup
+        if (which == 'd' && causal && waves == 4 && qb == 1 && !pair && (split == 1 || split == 2)) {
+            int ns = -1;
+            if (opt.nsplit >= 0) { ns = opt.nsplit; source = 2; }
+            if (ns >= 0) { split = 2; sel->nsplit = ns; }
+        }
+        sel->perm_n = 0;
+        if (which == 'd' && causal && !pair && qb == 1 && waves == 4 && (split == 1 || (split == 2 && sel->nsplit >= 0)) && opt.balance != 0) {
+            const int64_t nqt = (L + 32 * waves - 1) / (32 * waves), ng = g8 / 8;
+            const bool mixed = split == 2;
+            const int64_t ns = mixed ? (sel->nsplit < nqt ? sel->nsplit : nqt) : 0;
+            const int64_t nitem = mixed ? ns + (nqt - ns + 1) / 2 : nqt;                       // workgroups per group
+            const int64_t slots_per_xcd = (D == 64 ? 4 : 2) * kCusPerXcd / (mixed ? 2 : 1);    // resident workgroups per XCD
+            if (ng * nitem <= slots_per_xcd && ng * nitem <= 128) {
+                int bunch_sz = (int)((8ll << 20) / (2 * L * D * es));
+                if (sched > 0) bunch_sz = sched;
+                if (opt.sched > 0) bunch_sz = opt.sched;
+                if (bunch_sz < 1) bunch_sz = 1;
+                if (bunch_sz > ng) bunch_sz = (int)ng;
+                const auto tiles_of = [&](int64_t qi) { const int64_t kv_end = (qi + 1) * 128 < L ? (qi + 1) * 128 : L; return (int)((kv_end + 63) / 64); };
+                int weight[128];
+                for (int s_ = 0; s_ < ng * nitem; ++s_) {    // the kernels' natural slot -> (group, work item) map (fa_fwd_dma.hip)
+                    const int per_bunch = bunch_sz * (int)nitem, b_ = s_ / per_bunch, rem = s_ - b_ * per_bunch;
+                    const int g0 = b_ * bunch_sz, bc = (ng - g0) < bunch_sz ? (int)(ng - g0) : bunch_sz;
+                    const int64_t qd = rem / bc;
+                    if (!mixed) weight[s_] = tiles_of(nqt - 1 - qd);
+                    else if (qd < ns) weight[s_] = (tiles_of(nqt - 1 - qd) + 1) / 2;              // split: half the kv tiles per wave group
+                    else weight[s_] = tiles_of(nqt - ns - 1 - (qd - ns));                         // dual: as long as its heavier q tile
+                }
+                sel->perm_n = balanced_order((int)(ng * nitem), weight, sel->perm);
+            }
+        }
         plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : 0;
+        plan->pair = pair;
+        plan->balanced = sel->perm_n > 0;
         plan->waves = waves * split;
         plan->qb = qb;
         plan->block_q = 32 * waves * qb;
@@ -186,6 +282,12 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         plan->skipmax = skip;
         plan->source = source;
         plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
+        if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
+        plan->nsplit = sel->nsplit;
+        if (sel->nsplit >= 0) {
+            const int64_t nqt = (L + plan->block_q - 1) / plan->block_q, ns = sel->nsplit < nqt ? sel->nsplit : nqt;
+            plan->grid = g8 * (ns + (nqt - ns + 1) / 2);
+        }
         plan->lds_bytes = which == 'x' ? 8 * 32 * D * 2 + 16
                           : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
                                        : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
@@ -240,6 +342,7 @@ const OptionName kOptionNames[] = {
     {"kernel", &Options::kernel, 0, 127}, {"qb", &Options::qb, 0, 2}, {"waves", &Options::waves, 0, 8},
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
+    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"nsplit", &Options::nsplit, -1, 1 << 20},
 };
 
 }  // namespace
@@ -265,6 +368,9 @@ const char* fa_error_string(int code) {
         case FA_ERR_TOO_LARGE: return "problem too large";
         case FA_ERR_BAD_SCALE: return "softmax_scale must be finite and > 0";
         case FA_ERR_BAD_OPTION: return "unknown debug option or value out of range";
+        case FA_ERR_UNSUPPORTED: return "mask / dropout launches need f16 or bf16 operands, head_dim 64 or 128, 16-byte aligned rows";
+        case FA_ERR_BAD_MASK: return "bad mask kind or mask pointer";
+        case FA_ERR_BAD_DROPOUT: return "dropout_p must be in [0, 1)";
         default: return "unknown error";
     }
 }
@@ -284,6 +390,15 @@ int fa_debug_set_option(const char* name, int32_t value) {
         return FA_OK;
     }
     return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: unknown option '%s'", name);
+}
+
+int fa_debug_set_stamp_buffer(void* device_buffer, int64_t bytes) {
+    if (bytes < 0 || (device_buffer == nullptr) != (bytes == 0)) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_stamp_buffer: need (buffer, bytes > 0) or (NULL, 0)");
+    if (reinterpret_cast<uintptr_t>(device_buffer) & 7) return fail(FA_ERR_MISALIGNED, "fa_debug_set_stamp_buffer: buffer must be 8-byte aligned");
+    g_stamp_bytes.store(0);
+    g_stamp_buf.store(device_buffer);
+    g_stamp_bytes.store(bytes);
+    return FA_OK;
 }
 
 int fa_debug_get_option(const char* name, int32_t* value) {
@@ -330,11 +445,51 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
     return rc;
 }
 
-int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+}  // extern "C"
+
+namespace {
+
+// mask / bias / dropout arguments of fa_fwd_ex / fa_bwd_ex, validated into the kernels' ExtraParams (fa_extras.h)
+int make_extra(const void* mask, int32_t mask_kind, const int64_t* mask_strides, int32_t dtype, float softmax_scale,
+               float dropout_p, uint64_t seed, uint64_t offset, fa::ExtraParams* ex) {
+    memset(ex, 0, sizeof(*ex));
+    ex->drop_rp = 1.0f;
+    ex->inv_scale = 1.0f / softmax_scale;
+    if (mask_kind < FA_MASK_NONE || mask_kind > FA_MASK_BIAS) return fail(FA_ERR_BAD_MASK, "mask_kind must be FA_MASK_NONE/BOOL/BIAS (got %d)", mask_kind);
+    if ((mask_kind == FA_MASK_NONE) != (mask == nullptr)) return fail(FA_ERR_BAD_MASK, "mask pointer and mask_kind disagree");
+    if (mask_kind != FA_MASK_NONE) {
+        if (!mask_strides) return fail(FA_ERR_NULL_POINTER, "mask_strides must be non-null when a mask is given");
+        const int esz = mask_kind == FA_MASK_BIAS ? elt_size(dtype) : 1;
+        if (reinterpret_cast<uintptr_t>(mask) % esz) return fail(FA_ERR_MISALIGNED, "mask pointer is not element aligned");
+        bool vec = reinterpret_cast<uintptr_t>(mask) % (4 * esz) == 0;
+        for (int j = 0; j < 3; ++j) {
+            if (mask_strides[j] < 0 || mask_strides[j] > (1ll << 40)) return fail(FA_ERR_BAD_STRIDE, "mask strides must be in [0, 2^40] elements");
+            if (mask_strides[j] % 4) vec = false;
+        }
+        ex->mask = mask;
+        ex->mask_kind = mask_kind;
+        ex->m_sb = mask_strides[0]; ex->m_sh = mask_strides[1]; ex->m_sl = mask_strides[2];
+        ex->mask_vec = vec ? 1 : 0;
+    }
+    if (!(dropout_p >= 0.0f) || !(dropout_p < 1.0f)) return fail(FA_ERR_BAD_DROPOUT, "dropout_p must be in [0, 1) (got %g)", (double)dropout_p);
+    if (dropout_p > 0.0f) {
+        const double t = (double)dropout_p * 4294967296.0;
+        ex->drop_thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+        ex->drop_rp = 1.0f / (1.0f - dropout_p);
+        uint32_t k0 = fa::mix32((uint32_t)seed ^ 0x9E3779B9u);
+        k0 = fa::mix32(k0 ^ (uint32_t)(seed >> 32));
+        k0 = fa::mix32(k0 ^ (uint32_t)offset);
+        k0 = fa::mix32(k0 ^ (uint32_t)(offset >> 32));
+        ex->drop_key0 = k0;
+    }
+    return FA_OK;
+}
+
+int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
            int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,
            const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
            int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,
-           float softmax_scale, int32_t causal, void* stream) {
+           float softmax_scale, int32_t causal, void* stream, const fa::ExtraParams* ex) {
     if (!q || !k || !v || !out) return fail(FA_ERR_NULL_POINTER, "q, k, v and out must be non-null");
     if (!q_strides || !k_strides || !v_strides || !o_strides) return fail(FA_ERR_NULL_POINTER, "stride arrays must be non-null");
     if (heads < 1 || (G >= 1 && G % heads != 0)) return fail(FA_ERR_BAD_SHAPE, "G=%lld must be a positive multiple of heads=%lld", (long long)G, (long long)heads);
@@ -361,8 +516,13 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     const int rc = select_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal, mfma16_ok, f32_ok, &sel);
     if (rc != FA_OK) return rc;
     const fa_plan_t& plan = sel.plan;
+    const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
+    if (extra && !mfma16_ok)
+        return fail(FA_ERR_UNSUPPORTED, "mask / dropout launches need f16 or bf16 operands, head_dim 64 or 128 and 16-byte aligned rows");
 
     fa::FwdParams p;
+    memset(&p.ex, 0, sizeof(p.ex));
+    if (ex) p.ex = *ex;
     p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse;
     p.q_sb = q_strides[0]; p.q_sh = q_strides[1]; p.q_sl = q_strides[2];
     p.k_sb = k_strides[0]; p.k_sh = k_strides[1]; p.k_sl = k_strides[2];
@@ -376,25 +536,93 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
     p.D = (int32_t)D;
     p.causal = causal;
     p.nq_tiles = plan.kernel != 1 ? (int32_t)((L + plan.block_q - 1) / plan.block_q) : 0;
+    if (extra) p.nq_tiles = (int32_t)((L + 127) / 128);     // fa_fwd_extra_kernel: 4 waves x 32 rows, exact-max arithmetic
     p.sched = plan.sched;
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.skipmax = plan.skipmax;
+    p.nsplit = sel.nsplit;
+    p.perm_n = sel.perm_n;
+    if (sel.perm_n > 0) memcpy(p.perm, sel.perm, sizeof(p.perm));
+    p.stamps = nullptr;
+    if (void* sb = g_stamp_buf.load()) {   // 16 u64 per wave of the launch; too small a buffer = no stamps
+        if (plan.grid * plan.waves * 16 * 8 <= g_stamp_bytes.load()) p.stamps = static_cast<unsigned long long*>(sb);
+    }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = sel.which == 'g'   ? fa::launch_fwd_generic(p, dtype, st)
+    if (extra) { p.nsplit = -1; p.perm_n = 0; p.skipmax = 0; }
+    hipError_t e = extra              ? fa::launch_fwd_extra(p, dtype, st)
+                   : sel.which == 'g' ? fa::launch_fwd_generic(p, dtype, st)
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, plan.qb, st)
-                   : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves / sel.split, plan.qb, sel.split, st)
+                   : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves / sel.split, plan.qb, sel.split, sel.pair, st)
                                       : fa::launch_fwd_tile(p, dtype, plan.waves, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
+}
+
+int bwd_impl(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+             void* dq, void* dk, void* dv, float* dsum_workspace,
+             int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
+             int32_t dtype, float softmax_scale, int32_t causal, void* stream, const fa::ExtraParams* ex);
+
+}  // namespace
+
+extern "C" {
+
+int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+           int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,
+           const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
+           int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,
+           float softmax_scale, int32_t causal, void* stream) {
+    return fwd_impl(q, k, v, out, lse, G, L, D, heads, heads_kv, q_strides, k_strides, v_strides, o_strides,
+                    num_chunks_q, num_chunks_kv, dtype, softmax_scale, causal, stream, nullptr);
+}
+
+int fa_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
+              int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,
+              const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
+              int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, float softmax_scale, int32_t causal,
+              const void* mask, int32_t mask_kind, const int64_t mask_strides[3],
+              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, void* stream) {
+    if (!(softmax_scale > 0.0f) || !isfinite(softmax_scale)) return fail(FA_ERR_BAD_SCALE, "softmax_scale must be finite and > 0 (got %g)", (double)softmax_scale);
+    if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
+    fa::ExtraParams ex;
+    const int rc = make_extra(mask, mask_kind, mask_strides, dtype, softmax_scale, dropout_p, dropout_seed, dropout_offset, &ex);
+    if (rc != FA_OK) return rc;
+    return fwd_impl(q, k, v, out, lse, G, L, D, heads, heads_kv, q_strides, k_strides, v_strides, o_strides,
+                    num_chunks_q, num_chunks_kv, dtype, softmax_scale, causal, stream, &ex);
 }
 
 int fa_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
            void* dq, void* dk, void* dv, float* dsum_workspace,
            int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
            int32_t dtype, float softmax_scale, int32_t causal, void* stream) {
+    return bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, dsum_workspace, G, L, D, heads, heads_kv, strides, dtype, softmax_scale, causal, stream, nullptr);
+}
+
+int fa_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+              void* dq, void* dk, void* dv, float* dsum_workspace,
+              int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
+              int32_t dtype, float softmax_scale, int32_t causal,
+              const void* mask, int32_t mask_kind, const int64_t mask_strides[3],
+              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, void* stream) {
+    if (!(softmax_scale > 0.0f) || !isfinite(softmax_scale)) return fail(FA_ERR_BAD_SCALE, "softmax_scale must be finite and > 0 (got %g)", (double)softmax_scale);
+    if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
+    fa::ExtraParams ex;
+    const int rc = make_extra(mask, mask_kind, mask_strides, dtype, softmax_scale, dropout_p, dropout_seed, dropout_offset, &ex);
+    if (rc != FA_OK) return rc;
+    return bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, dsum_workspace, G, L, D, heads, heads_kv, strides, dtype, softmax_scale, causal, stream, &ex);
+}
+
+}  // extern "C"
+
+namespace {
+
+int bwd_impl(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+           void* dq, void* dk, void* dv, float* dsum_workspace,
+           int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
+           int32_t dtype, float softmax_scale, int32_t causal, void* stream, const fa::ExtraParams* ex) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !dsum_workspace || !strides)
         return fail(FA_ERR_NULL_POINTER, "fa_bwd: every pointer argument must be non-null");
     if (!(causal == 0 || causal == 1)) return fail(FA_ERR_NOT_CAUSAL, "causal must be 0 or 1 (got %d)", causal);
@@ -418,9 +646,14 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
         }
         if (strides[i][2] > (1ll << 32) || L * strides[i][2] >= (1ll << 31)) mfma = false;
     }
+    const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
+    if (extra && !(mfma && dtype != FA_DTYPE_F32))
+        return fail(FA_ERR_UNSUPPORTED, "mask / dropout launches need f16 or bf16 operands, head_dim 64 or 128 and 16-byte aligned rows");
     if (!mfma && D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic backward supports D <= 1024 (got %lld)", (long long)D);
     if (!mfma && G * L > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     fa::BwdParams p;
+    memset(&p.ex, 0, sizeof(p.ex));
+    if (ex) p.ex = *ex;
     p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse = lse; p.dsum = dsum_workspace;
     p.dq = dq; p.dk = dk; p.dv = dv;
     p.q_sb = strides[0][0]; p.q_sh = strides[0][1]; p.q_sl = strides[0][2];
@@ -448,18 +681,27 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
     if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    hipError_t e = !mfma                  ? fa::launch_bwd_generic(p, dtype, (hipStream_t)stream)
+    hipError_t e = extra                  ? fa::launch_bwd_extra(p, dtype, (hipStream_t)stream)
+                   : !mfma                ? fa::launch_bwd_generic(p, dtype, (hipStream_t)stream)
                    : dtype == FA_DTYPE_F32 ? fa::launch_bwd_f32(p, (hipStream_t)stream)
                                            : fa::launch_bwd(p, dtype, (hipStream_t)stream);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,
                       int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, void* stream) {
     if (!qkv || !out) return fail(FA_ERR_NULL_POINTER, "qkv and out must be non-null");
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1");
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
+    // (sizes are bounded BEFORE the pointer arithmetic: G * L * D * es below must not overflow; the whole packed tensor must
+    // also be addressable, 3 * G * L * D * es < 2^62)
+    if (L > (1ll << 30) || G > (1ll << 30) || D > (1ll << 20)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30, D < 2^20");
+    if (G * L > (1ll << 58) / (4 * D)) return fail(FA_ERR_TOO_LARGE, "packed qkv of %lld x %lld x %lld elements per operand is not addressable", (long long)G, (long long)L, (long long)D);
     const int64_t es = elt_size(dtype);
     const int64_t strides[3] = {L * D, 0, D};
     const char* base = static_cast<const char*>(qkv);

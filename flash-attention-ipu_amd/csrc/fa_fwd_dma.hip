@@ -16,6 +16,7 @@
 // from the VALU issue port, which is the binding resource of this kernel at head_dim 64.
 
 #include "fa_device.h"
+#include "fa_extras.h"
 
 // 1: no per-tile row max (bf16).  The reference max m is set exactly on a wave's first tile and then left
 // alone; a tile whose row-sum part exceeds P_LIMIT (some P outgrew the safe range) is redone with an
@@ -35,8 +36,26 @@ namespace fa {
 // (one workgroup barrier per tile round), and the groups' (m, l, O) are merged through LDS before the epilogue - the kv
 // loop of a q tile, the critical path of a launch with fewer workgroups than slots, shrinks SPLIT-fold with no second
 // kernel and no partial results in HBM.
-template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT>
+//
+// MIXED (SPLIT == 2, p.nsplit >= 0; causal grids of about one round of slots, e.g. GPT-2 small's attention call): such a launch lasts
+// as long as its heaviest workgroup's serial chain of kv tiles (profiles/r03_cfg4: 16 tiles x ~0.95 us, whatever else the CU holds),
+// so only the heaviest q tiles want their kv loop split - splitting all of them doubles the launch's waves past one round of slots.
+// The 8-wave workgroups of one launch then come in two kinds: the p.nsplit heaviest q tiles of a group are split as above; the
+// others are taken two per workgroup, wave group 0 on the heavier and wave group 1 on the lighter one ("dual": private K/V buffers
+// as before, but each group streams EVERY kv tile of ITS q tile, no merge, both groups run the epilogue).
+//
+// PAIR (causal, SPLIT == 1, QB == 1): the workgroup owns TWO q tiles, (nq - 1 - i) then i, one after the other.  Every workgroup
+// of a group then streams the same number of kv tiles (nq + 1 of 128-row q tiles: no light and heavy workgroups, no tail), the
+// dispatcher refills half as many slots, and the second tile's prologue disappears: its Q rows and its first K/V tile are requested
+// right after the first tile's loop, into the registers / LDS buffers that loop has just released, and land under the first tile's
+// epilogue (whose row slabs move to the K1 / V1 buffers for that).  Short sequences, where these fixed phases are 25-40 % of a
+// workgroup's life, are what it is for.
+//
+// EXTRA: attention mask / additive bias and dropout (fa_extras.h), exact-max arithmetic only (a mask can hide every key of a
+// tile from a row, so the fixed reference max of the skip-max mode has nothing to stand on); instantiated in fa_fwd_extra.hip.
+template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT, bool PAIR, bool EXTRA = false>
 __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
+    static_assert(!EXTRA || !SKIP, "mask / dropout launches use the exact-max arithmetic");
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
@@ -57,23 +76,30 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[SPLIT * GROUP_B];
     __shared__ int flags[NWAVES * SPLIT];
 
-    const int b = blockIdx.x;
+    static_assert(!PAIR || (SPLIT == 1 && QB == 1), "q-tile pairs: unsplit workgroups with one query block per wave");
     const int nq = p.nq_tiles;
-    int g, qi;
+    const int nsplit = (SPLIT == 2 && p.nsplit >= 0) ? (p.nsplit < nq ? p.nsplit : nq) : -1;   // MIXED: q tiles nq-1 .. nq-nsplit are split
+    const int nslot = PAIR ? (nq + 1) >> 1 : nsplit >= 0 ? nsplit + ((nq - nsplit + 1) >> 1) : nq;      // workgroups per group
+    int g, qd;
     {
+        int b = blockIdx.x;
+        if (p.perm_n > 0) {                            // placement-balanced order of a grid below one round of slots (fa_capi.cpp)
+            const int s_ = b >> 3;
+            b = (s_ < p.perm_n ? (int)p.perm[s_] : s_) * 8 + (b & 7);
+        }
         const int xcd = b & 7, slot = b >> 3;
         const int ng = p.G8 >> 3;
-        const int per_bunch = p.sched * nq;
+        const int per_bunch = p.sched * nslot;
         const int bunch = slot / per_bunch;
         const int rem = slot - bunch * per_bunch;
         const int g0 = bunch * p.sched;
         const int bc = (ng - g0) < p.sched ? (ng - g0) : p.sched;
-        const int qd = rem / bc;
-        qi = nq - 1 - qd;
+        qd = rem / bc;
         g = (g0 + (rem - qd * bc)) * 8 + xcd;
     }
     if (g >= p.G) return;
-#ifdef FA_STAMPS   /* measurement build only (scripts/phase_times.py): phase time stamps overwrite the LSE rows */
+    const int n_pass = (PAIR && qd != nq - 1 - qd) ? 2 : 1;
+#ifdef FA_STAMPS   /* measurement build only (scripts/phase_times.py): phase time stamps, written to p.stamps at the end */
     const unsigned long long st0_ = __builtin_amdgcn_s_memtime();
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
     unsigned long long st1_ = 0, st2_ = 0;
@@ -87,6 +113,9 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base -> M0)
     const int ws = SPLIT == 1 ? 0 : wave_all / NWAVES;               // kv split group of this wave
     const int wave = SPLIT == 1 ? wave_all : wave_all - ws * NWAVES; // its row block inside the group
+    const bool dual = nsplit >= 0 && qd >= nsplit;                   // MIXED: this workgroup's two wave groups own two different q tiles
+    const int tfirst = (SPLIT == 1 || dual) ? 0 : ws;                // the group's first kv tile ...
+    const int tstride = (SPLIT == 1 || dual) ? 1 : SPLIT;            // ... and the distance to its next one
     unsigned char* const smem = smem_all + ws * GROUP_B;
     unsigned char* const smem_v = smem + 2 * KTILE_B;
     const int r = lane & 31, h = lane >> 5;
@@ -94,19 +123,20 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
     const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
     const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
+    // EXTRA: this group's mask rows (byte addressed) and dropout key
+    const int mask_esz = p.ex.mask_kind == 2 ? (int)sizeof(T) : 1;
+    const char* const mask_g = EXTRA && p.ex.mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh) * mask_esz : nullptr;
+    const unsigned drop_kg = EXTRA ? drop_group_key(p.ex.drop_key0, (unsigned)g) : 0u;
 
-    const int q_row0 = qi * BQ + wave * WQ;
-    const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
-    const bool wave_active = q_row0 < L;
-
+    // Q^T fragments of q tile QI_ (B operands of S^T = K Q^T): block b of this wave owns row QI_ * BQ + wave * WQ + 32 b + r
     vec8 qf[QB][KS];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        const int qr = qrow + 32 * b < L ? qrow + 32 * b : L - 1;
-        const T* qp = qg + (int64_t)qr * p.q_sl + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[b][ks] = *(const vec8*)(qp + 16 * ks);
+#define FA_LOAD_Q(QI_)                                                                             \
+    _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
+        const int qr0_ = (QI_) * BQ + wave * WQ + r + 32 * b;                                      \
+        const T* qp = qg + (int64_t)(qr0_ < L ? qr0_ : L - 1) * p.q_sl + 8 * h;                    \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) qf[b][ks] = *(const vec8*)(qp + 16 * ks); \
     }
+    FA_LOAD_Q(nq - 1 - qd)
 
     // ---- LDS-DMA geometry: piece pc = wave + j*NWAVES of a tile, lane -> source byte offset
     const unsigned k_slb = (unsigned)p.k_sl * 2, v_slb = (unsigned)p.v_sl * 2;   // row strides in bytes
@@ -162,14 +192,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     }
     const int v_rd = (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
-    // causal: keys up to the workgroup's last row; otherwise every key.  `klim`: the last key a row may see is
-    // min(row, L - 1) under the causal mask and L - 1 without it (rows past L are clamped duplicates, never stored)
     const bool causal = p.causal != 0;
-    const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
-    const int n_tiles = (kv_end + BK - 1) / BK;
-    const int wave_last = causal ? q_row0 : L - 1;      // a tile reaching past this key carries a mask for the wave
-    const int wave_kv_last = causal ? q_row0 + WQ - 1 : L - 1;   // tiles starting after it hold nothing for the wave
-
     f32x16 o[QB][DT];
     float m[QB];
     // Softmax denominators are formed on the matrix pipe (fa_device.h, rowsum_selector): lsum[b] holds the FULL row
@@ -183,7 +206,6 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                          \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) o[b][dt][e] = 0.f;                      \
     }
-    FA_RESET_STATE()
     const float c = p.scale_log2;
     // Two arithmetic modes per kv tile:
     //   fast (MODE_ 0, "skip-max"): the reference max m is set exactly on the wave's first tile and then left alone -
@@ -213,6 +235,21 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                 s1[b] = E::mfma(k1, qf[b][ks], s1[b]);                                             \
             }                                                                                      \
         }                                                                                          \
+        if constexpr (EXTRA) {                                                                     \
+            if (mask_g != nullptr) {   /* additive terms on the raw scores: bias / scale, or 0 | -inf */ \
+                const bool fast_ = p.ex.mask_vec != 0 && kv0 + BK <= L;                            \
+                _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                   \
+                    const int mr_ = qrow + 32 * b < L ? qrow + 32 * b : L - 1;                     \
+                    const char* mrow_ = mask_g + (int64_t)mr_ * p.ex.m_sl * mask_esz;              \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                \
+                        float a0_[4], a1_[4];                                                      \
+                        mask_load4<T>(p.ex.mask_kind, fast_, mrow_, kv0 + 8 * j + 4 * h, L, p.ex.inv_scale, a0_);      \
+                        mask_load4<T>(p.ex.mask_kind, fast_, mrow_, kv0 + 32 + 8 * j + 4 * h, L, p.ex.inv_scale, a1_); \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i) { s0[b][4 * j + i] += a0_[i]; s1[b][4 * j + i] += a1_[i]; } \
+                    }                                                                              \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
         if (kv0 + BK - 1 > wave_last) { /* a diagonal tile of the wave / the ragged last tile */   \
             _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                       \
                 const int klim = causal ? qrow + 32 * b : L - 1;                                   \
@@ -233,7 +270,8 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         mx = half_swap_max(mx);                                                                    \
         if (__builtin_amdgcn_ballot_w64((mx - m[b]) * c > (THR_)) != 0) {                          \
             const float m_new = max2(m[b], mx);                                                    \
-            const float alpha = fast_exp2((m[b] - m_new) * c);                                     \
+            /* (EXTRA: a row that has met no admitted key yet keeps m = -inf; its O and l are 0 and stay 0) */ \
+            const float alpha = (EXTRA && m_new == -INFINITY) ? 1.f : fast_exp2((m[b] - m_new) * c); \
             m[b] = m_new;                                                                          \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) lsum[b][j] *= alpha;                     \
             _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                      \
@@ -243,7 +281,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // P = 2^(s*c - m*c) in place
 #define FA_SOFTMAX()                                                                               \
     _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
-        const float mc = m[b] * c;                                                                 \
+        const float mc = (EXTRA && m[b] == -INFINITY) ? 0.f : m[b] * c;   /* (all scores of such a row are -inf: P = 0) */ \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                           \
             s0[b][e] = fast_exp2(__builtin_fmaf(s0[b][e], c, -mc));                                \
             s1[b][e] = fast_exp2(__builtin_fmaf(s1[b][e], c, -mc));                                \
@@ -264,6 +302,25 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         }                                                                                          \
         _Pragma("unroll") for (int b = 0; b < QB; ++b)                                             \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) lsum[b] = E::mfma16(asel, pf[b][kk], lsum[b]); \
+        if constexpr (EXTRA) {                                                                     \
+            if (p.ex.drop_thr != 0u) {   /* the denominator keeps every P; the PV product sees the kept ones */ \
+                _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                   \
+                    const unsigned row_ = (unsigned)(qrow + 32 * b);                               \
+                    const unsigned base_ = drop_tile_key(drop_kg, row_, (unsigned)kv0) ^ ((row_ & 0xffffu) << 16) ^ (unsigned)((kv0 & 0xffff) | (4 * h)); \
+                    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                               \
+                        const unsigned ce_ = (unsigned)((e & 3) + 8 * (e >> 2));                   \
+                        if (mix32(base_ ^ ce_) < p.ex.drop_thr) s0[b][e] = 0.f;                    \
+                        if (mix32(base_ ^ (ce_ + 32u)) < p.ex.drop_thr) s1[b][e] = 0.f;            \
+                    }                                                                              \
+                    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                \
+                        pf[b][0][j] = (T)s0[b][j];                                                 \
+                        pf[b][1][j] = (T)s0[b][8 + j];                                             \
+                        pf[b][2][j] = (T)s1[b][j];                                                 \
+                        pf[b][3][j] = (T)s1[b][8 + j];                                             \
+                    }                                                                              \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
         _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                        \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                     \
                 const unsigned char* vp = vb_ + dt * VBLK_B + kk * 1024 + v_rd;                    \
@@ -287,7 +344,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[b][e] = o[b][0][e]; s1[b][e] = o[b][1][e]; } \
             }                                                                                      \
             if ((MODE_) == 0) {                                                                    \
-                if ((T_) < SPLIT) FA_MAX_RESCALE(0.0f)   /* the group's first tile: m = -inf -> exact max */ \
+                if ((T_) == tfirst) FA_MAX_RESCALE(0.0f)   /* the group's first tile: m = -inf -> exact max */ \
             } else {                                                                               \
                 FA_MAX_RESCALE(RESCALE_THR)                                                        \
             }                                                                                      \
@@ -301,22 +358,56 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // one pass over the workgroup's kv tiles (the kv loop is unrolled by two: LDS addresses are base + immediate)
 #define FA_PASS(MODE_)                                                                             \
     {                                                                                              \
-        if (SPLIT == 1 || ws < n_tiles) FA_DMA_TILE(ws, 0)                                         \
+        if (!tile0_requested && (SPLIT == 1 || tfirst < n_tiles)) FA_DMA_TILE(tfirst, 0)           \
+        tile0_requested = false;                                                                   \
         FA_TILE_BARRIER()                                                                          \
-        FA_STAMP(st1_)                                                                             \
-        for (int t0 = 0; t0 < n_tiles; t0 += 2 * SPLIT) {       /* (workgroup-uniform bounds) */   \
-            const int t = t0 + ws;                              /* this group's tile of the round */ \
-            if (t + SPLIT < n_tiles) FA_DMA_TILE(t + SPLIT, 1)                                     \
+        if (pass == 0) FA_STAMP(st1_)                                                              \
+        for (int rr = 0; rr < n_rounds; rr += 2) {              /* (workgroup-uniform bounds) */   \
+            const int t = tfirst + rr * tstride;                /* this group's tile of the round */ \
+            if (t + tstride < n_tiles) FA_DMA_TILE(t + tstride, 1)                                 \
             FA_COMPUTE(t, 0, MODE_)                                                                \
             FA_TILE_BARRIER()                                                                      \
-            if (t0 + SPLIT < n_tiles) {                                                            \
-                if (t + 2 * SPLIT < n_tiles) FA_DMA_TILE(t + 2 * SPLIT, 0)                         \
-                FA_COMPUTE(t + SPLIT, 1, MODE_)                                                    \
+            if (rr + 1 < n_rounds) {                                                               \
+                if (t + 2 * tstride < n_tiles) FA_DMA_TILE(t + 2 * tstride, 0)                     \
+                FA_COMPUTE(t + tstride, 1, MODE_)                                                  \
                 FA_TILE_BARRIER()                                                                  \
             }                                                                                      \
         }                                                                                          \
     }
 
+    bool tile0_requested = false;     // pairs: the next q tile's first K/V tile is already on its way to buffer 0
+    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
+#pragma nounroll
+    for (int pass = 0; pass < n_pass; ++pass) {
+    // the q tile of this wave: unsplit / split workgroups: nq-1-qd (heaviest first); pairs: then qd; MIXED dual workgroups: the
+    // q tiles below the split ones, wave group 0 the heavier (nrem-1-k), wave group 1 the lighter (k) - none if they coincide
+    int qi = pass == 0 ? nq - 1 - qd : qd;
+    bool group_idle = false;
+    int n_rounds_other = 0;                      // MIXED dual: kv tiles of the OTHER wave group's q tile
+    if constexpr (SPLIT == 2) {
+        if (dual) {
+            const int k_ = qd - nsplit, nrem = nq - nsplit;
+            const int qa = nrem - 1 - k_, qb_ = k_;
+            qi = ws == 0 ? qa : qb_;
+            group_idle = ws == 1 && qa == qb_;
+            const int qo = ws == 0 ? qb_ : qa;
+            const int ke_o = (causal && (qo + 1) * BQ < L) ? (qo + 1) * BQ : L;
+            n_rounds_other = (ws == 0 && qa == qb_) ? 0 : (ke_o + BK - 1) / BK;
+        }
+    }
+    const int q_row0 = qi * BQ + wave * WQ;
+    const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
+    const bool wave_active = q_row0 < L && !group_idle;
+    // causal: keys up to the workgroup's last row; otherwise every key.  `klim`: the last key a row may see is
+    // min(row, L - 1) under the causal mask and L - 1 without it (rows past L are clamped duplicates, never stored)
+    const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
+    const int n_tiles = group_idle ? 0 : (kv_end + BK - 1) / BK;
+    // rounds of the workgroup's lock-step loop (uniform over ALL its waves): every group must see its last tile
+    const int n_rounds = (SPLIT == 1) ? n_tiles : dual ? (n_tiles > n_rounds_other ? n_tiles : n_rounds_other)
+                                                       : (n_tiles + SPLIT - 1) / SPLIT;
+    const int wave_last = causal ? q_row0 : L - 1;      // a tile reaching past this key carries a mask for the wave
+    const int wave_kv_last = causal ? q_row0 + WQ - 1 : L - 1;   // tiles starting after it hold nothing for the wave
+    FA_RESET_STATE()
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -336,29 +427,33 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #pragma unroll
         for (int w = 0; w < NWAVES * SPLIT; ++w) any_bad |= flags[w];
         if (any_bad) {
-            __syncthreads();   // (flags are rewritten only by a later launch; this orders the LDS buffer reuse)
+            __syncthreads();   // (flags are rewritten only after later barriers; this orders the LDS buffer reuse)
             FA_RESET_STATE()
             FA_PASS(1)
         }
     } else {
         FA_PASS(1)
     }
-#undef FA_DMA_TILE
-#undef FA_TILE_BARRIER
-#undef FA_COMPUTE
-#undef FA_PASS
-#undef FA_RESET_STATE
-#undef FA_QK
-#undef FA_MAX_RESCALE
-#undef FA_SOFTMAX
-#undef FA_PV
-
-    FA_STAMP(st2_)
+    if (pass + 1 == n_pass) FA_STAMP(st2_)
+    if constexpr (PAIR) {
+        if (pass + 1 < n_pass) {
+            // the pair's second q tile: its Q rows go into the registers the loop has just released, its first K/V tile into
+            // buffer 0 (every wave is past the loop's last barrier); both land under the epilogue below
+            FA_LOAD_Q(qd)
+            FA_DMA_TILE(0, 0)
+            tile0_requested = true;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int b = 0; b < QB; ++b) asm volatile("" : "+v"(qf[b][ks]));
+        }
+    }
     // ---- split-KV: fold the other groups' (m, l, O) into group 0, one group at a time, through LDS (the K/V buffers are free
     // after the pass's last barrier).  The exchange area lies behind the epilogue's row slabs; a lane's values sit at
     // [value][lane], so writes and reads are conflict-free.  A group that saw no key of a row hands over m = -inf, l = 0,
     // O = 0: its weight 2^((m - m_new) c) is 0.
     if constexpr (SPLIT > 1) {
+    if (!dual) {
         constexpr int NVAL = QB * (DT * 16 + 2);
         float* xb = (float*)(smem_all + NWAVES * WQ * ROWB) + wave * (NVAL * 64) + lane;
         static_assert(NWAVES * WQ * ROWB + NWAVES * NVAL * 64 * 4 <= SPLIT * GROUP_B, "exchange area must fit the K/V buffers");
@@ -396,20 +491,24 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         }
         if (ws != 0) return;
     }
+    }
     // ---- epilogue: O /= l, staged through LDS so that every store instruction writes whole rows.
     // (A lane owns 8-byte pieces of ONE row at a 16-byte pitch; stored directly, one instruction touches
     // 32 rows x 2 pieces.)  The K buffers are free after the last barrier; each wave uses a private
     // 32-row slab [32][D] with the 16-byte chunk index XORed by the row, so writes and reads are
     // conflict-free and no workgroup barrier is needed.
-    if (!wave_active) return;
-    unsigned char* slab = smem_all + wave * (WQ * ROWB);
+    // Pairs: the slabs live in the K1 / V1 buffers (two waves each), K0 / V0 are receiving the next q tile's first K/V tile.
+    // (split workgroups: only wave group 0 gets here, smem == smem_all; dual workgroups: each group in its own buffers)
+    unsigned char* slab = PAIR ? smem_all + (wave < 2 ? KTILE_B + wave * (WQ * ROWB) : 2 * KTILE_B + VTILE_B + (wave - 2) * (WQ * ROWB))
+                               : smem + wave * (WQ * ROWB);
+    static_assert(!PAIR || (NWAVES <= 4 && 2 * WQ * ROWB <= KTILE_B && 2 * WQ * ROWB <= VTILE_B), "pair epilogue slabs must fit K1 / V1");
     constexpr int CPR = D / 8;   // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;   // rows per store instruction (8 at D=64, 4 at D=128)
-    T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
+    if (wave_active) {
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         const float lt = lsum[b][0];
-        const float inv = __builtin_amdgcn_rcpf(lt);
+        const float inv = EXTRA ? __builtin_amdgcn_rcpf(lt) * p.ex.drop_rp : __builtin_amdgcn_rcpf(lt);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -431,36 +530,67 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             if (orow < L && (FA_DMA_ABL != 6 || val.x == 0x12345u)) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
         }
     }
+    }   // wave_active
+    }   // pass
+#undef FA_DMA_TILE
+#undef FA_TILE_BARRIER
+#undef FA_COMPUTE
+#undef FA_PASS
+#undef FA_RESET_STATE
+#undef FA_QK
+#undef FA_MAX_RESCALE
+#undef FA_SOFTMAX
+#undef FA_PV
+
+#undef FA_LOAD_Q
 #ifdef FA_STAMPS
-    {
+    {   // stamps go to a buffer of their own (fa_debug_set_stamp_buffer), never to an output: 16 u64 per wave
         unsigned long long st3_;
         FA_STAMP(st3_)
-        if (p.lse != nullptr && lane == 0 && BQ >= 64 && qi * BQ + BQ <= L) {
-            unsigned long long* sp = (unsigned long long*)(p.lse + (int64_t)g * L + qi * BQ) + wave * (BQ / 2 / NWAVES);
-            sp[0] = st0_; sp[1] = st1_; sp[2] = st2_; sp[3] = st3_;
-            sp[10] = rt0_; sp[11] = __builtin_amdgcn_s_memrealtime();
-            if (BQ / 2 / NWAVES >= 8) {
-                unsigned hwid;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-                unsigned xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                sp[4] = ((unsigned long long)xcc << 32) | hwid;
-                sp[5] = (unsigned long long)n_tiles;
+        if (p.stamps != nullptr && lane == 0) {
+            unsigned long long* sp = p.stamps + (((int64_t)g * nslot + qd) * (NWAVES * SPLIT) + wave_all) * 16;
+            int tot_tiles = 0;   // kv tiles this workgroup streamed (both q tiles of a pair)
+            for (int ps = 0; ps < n_pass; ++ps) {
+                const int qi_ = ps == 0 ? nq - 1 - qd : qd;
+                const int ke_ = (causal && (qi_ + 1) * BQ < L) ? (qi_ + 1) * BQ : L;
+                tot_tiles += (ke_ + BK - 1) / BK;
             }
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            sp[0] = st0_; sp[1] = st1_; sp[2] = st2_; sp[3] = st3_;
+            sp[4] = ((unsigned long long)xcc << 32) | hwid;
+            sp[5] = (unsigned long long)tot_tiles;
+            sp[9] = (unsigned long long)blockIdx.x;
+            sp[10] = rt0_; sp[11] = __builtin_amdgcn_s_memrealtime();
         }
     }
 #endif
 }
 
-template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT>
-__global__ __launch_bounds__(NWAVES * SPLIT * 64) void fa_fwd_dma_kernel(const FwdParams p) {
-    fa_fwd_dma_body<T, D, NWAVES, SKIP, QB, SPLIT>(p);
+#ifndef FA_DMA_BODY_ONLY   /* fa_fwd_extra.hip includes this file for the body template alone */
+// (pairs at head_dim 64: held to 128 registers = 4 waves per SIMD like the unpaired kernel - allocated freely it takes 138)
+template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT, bool PAIR = false>
+__global__ __launch_bounds__(NWAVES * SPLIT * 64, (PAIR && D == 64) ? 4 : 1) void fa_fwd_dma_kernel(const FwdParams p) {
+    fa_fwd_dma_body<T, D, NWAVES, SKIP, QB, SPLIT, PAIR>(p);
 }
 
 template <typename T, int D, bool SKIP>
-static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, int split, hipStream_t stream) {
+static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, int split, int pair, hipStream_t stream) {
+    if (pair) {   // q-tile pairs (4 waves, one query block per wave, unsplit, causal): (nq + 1) / 2 workgroups per group
+        if (!(waves == 4 && qb == 1 && split == 1 && p.causal)) return hipErrorInvalidValue;
+        const int64_t pgrid = (int64_t)p.G8 * ((p.nq_tiles + 1) / 2);
+        return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 1, true>), dim3((unsigned)pgrid), dim3(256), 0, stream, p);
+    }
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
-    if (split == 2) return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 2>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    if (split == 2) {
+        int64_t g2 = grid;
+        if (p.nsplit >= 0) {   // MIXED: nsplit split workgroups + the other q tiles two per workgroup
+            const int ns = p.nsplit < p.nq_tiles ? p.nsplit : p.nq_tiles;
+            g2 = (int64_t)p.G8 * (ns + (p.nq_tiles - ns + 1) / 2);
+        }
+        return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 2>), dim3((unsigned)g2), dim3(512), 0, stream, p);
+    }
     if (split == 4) {   // 16 waves = 4 per SIMD: needs the 128-register kernel (head_dim 64)
         if constexpr (D == 64) {
             return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 4>), dim3((unsigned)grid), dim3(1024), 0, stream, p);
@@ -487,14 +617,16 @@ static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, int split,
 
 // waves = waves per kv split group (the workgroup has waves x split); qb = 32-row query blocks per wave (1, or 2 for head_dim 64
 // with 4 waves); split = kv split groups (1; 2 | 4 with 4 waves and qb 1).  The host sized p.nq_tiles for 32 waves qb rows.
-hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, int split, hipStream_t stream) {
+hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, int split, int pair, hipStream_t stream) {
     if (dtype == 1) {   // bf16: always skip-max
-        return p.D == 64 ? launch_dma_w<__bf16, 64, true>(p, waves, qb, split, stream) : launch_dma_w<__bf16, 128, true>(p, waves, qb, split, stream);
+        return p.D == 64 ? launch_dma_w<__bf16, 64, true>(p, waves, qb, split, pair, stream) : launch_dma_w<__bf16, 128, true>(p, waves, qb, split, pair, stream);
     }
     if (p.skipmax) {
-        return p.D == 64 ? launch_dma_w<_Float16, 64, true>(p, waves, qb, split, stream) : launch_dma_w<_Float16, 128, true>(p, waves, qb, split, stream);
+        return p.D == 64 ? launch_dma_w<_Float16, 64, true>(p, waves, qb, split, pair, stream) : launch_dma_w<_Float16, 128, true>(p, waves, qb, split, pair, stream);
     }
-    return p.D == 64 ? launch_dma_w<_Float16, 64, false>(p, waves, qb, split, stream) : launch_dma_w<_Float16, 128, false>(p, waves, qb, split, stream);
+    return p.D == 64 ? launch_dma_w<_Float16, 64, false>(p, waves, qb, split, pair, stream) : launch_dma_w<_Float16, 128, false>(p, waves, qb, split, pair, stream);
 }
+
+#endif  // FA_DMA_BODY_ONLY
 
 }  // namespace fa

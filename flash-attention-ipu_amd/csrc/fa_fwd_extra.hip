@@ -1,0 +1,25 @@
+// Forward with an attention mask / additive bias and / or dropout (fa_extras.h; SURVEY 8f-4: the modes
+// scaled_dot_product_attention.py:21-28 of the reference rejects).  The kernel IS fa_fwd_dma_body (fa_fwd_dma.hip: 4 waves x 32
+// query rows, 64-key tiles staged by LDS-DMA) instantiated with EXTRA = true and the exact-max arithmetic: the mask terms are
+// added to the score registers of every tile, the dropout decisions are taken on the P registers between the row sums and the
+// PV product.  16-bit operands, head_dim 64 / 128; causal or unmasked underneath.
+#define FA_DMA_BODY_ONLY 1
+#include "fa_fwd_dma.hip"
+
+namespace fa {
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void fa_fwd_extra_kernel(const FwdParams p) {
+    fa_fwd_dma_body<T, D, 4, false, 1, 1, false, true>(p);
+}
+
+hipError_t launch_fwd_extra(const FwdParams& p, int dtype, hipStream_t stream) {
+    const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles)), block(256);
+    if (dtype == 1)
+        return p.D == 64 ? launch1((const void*)(fa_fwd_extra_kernel<__bf16, 64>), grid, block, 0, stream, p)
+                         : launch1((const void*)(fa_fwd_extra_kernel<__bf16, 128>), grid, block, 0, stream, p);
+    return p.D == 64 ? launch1((const void*)(fa_fwd_extra_kernel<_Float16, 64>), grid, block, 0, stream, p)
+                     : launch1((const void*)(fa_fwd_extra_kernel<_Float16, 128>), grid, block, 0, stream, p);
+}
+
+}  // namespace fa

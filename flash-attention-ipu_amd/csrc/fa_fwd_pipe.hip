@@ -107,7 +107,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         g = (g0 + (rem - qd * bc)) * 8 + xcd;
     }
     if (g >= p.G) return;
-#ifdef FA_STAMPS   /* measurement build only (scripts/phase_times.py): phase time stamps overwrite the LSE rows */
+#ifdef FA_STAMPS   /* measurement build only (scripts/phase_times.py): phase time stamps, written to p.stamps at the end */
     const unsigned long long st0_ = __builtin_amdgcn_s_memtime();
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
     unsigned long long st1_ = 0, st2_ = 0, sta_ = 0, stb_ = 0, stc_ = 0;
@@ -641,8 +641,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         unsigned long long st3_;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FA_STAMP(st3_)
-        if (p.lse != nullptr && lane == 0 && BQ / 2 / NWAVES >= 8 && qi * BQ + BQ <= L) {
-            unsigned long long* sp = (unsigned long long*)(p.lse + (int64_t)g * L + qi * BQ) + wave * (BQ / 2 / NWAVES);
+        if (p.stamps != nullptr && lane == 0) {   // a buffer of their own (fa_debug_set_stamp_buffer), never an output: 16 u64 per wave
+            unsigned long long* sp = p.stamps + (((int64_t)g * p.nq_tiles + qi) * NWAVES + wave) * 16;
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -651,7 +651,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             sp[4] = ((unsigned long long)xcc << 32) | hwid;
             sp[5] = (unsigned long long)nh_wg;
             sp[6] = sta_; sp[7] = stb_;
-            if (BQ / 2 / NWAVES >= 16) sp[8] = stc_;
+            sp[8] = stc_;
+            sp[9] = (unsigned long long)blockIdx.x;
         }
     }
 #endif

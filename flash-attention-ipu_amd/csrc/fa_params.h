@@ -7,6 +7,18 @@
 
 namespace fa {
 
+// attention mask / bias and dropout (fa_extras.h); mask == nullptr and drop_thr == 0 in ordinary launches
+struct ExtraParams {
+    const void* mask;      // nullptr = none
+    int64_t m_sb, m_sh, m_sl;   // mask strides in elements: batch (outer group), head (inner group), row; unit key stride
+    int32_t mask_kind;     // 0 none, 1 boolean bytes (non-zero = keep), 2 additive bias in the operand dtype
+    int32_t mask_vec;      // 1 = four consecutive keys may be fetched with one aligned load
+    float inv_scale;       // 1 / softmax_scale (a bias is added to the RAW scores as bias / scale)
+    uint32_t drop_key0;    // seed and offset folded (fa_capi.cpp)
+    uint32_t drop_thr;     // floor(p * 2^32); 0 = no dropout
+    float drop_rp;         // 1 / (1 - p)
+};
+
 struct FwdParams {
     const void* q;
     const void* k;
@@ -30,6 +42,11 @@ struct FwdParams {
     int32_t skipmax;       // f16 only: 1 = reference max from the first tile + overflow-triggered redo
     float scale;           // softmax scale
     float scale_log2;      // scale * log2(e)
+    ExtraParams ex;
+    int32_t nsplit;        // >= 0 (2 kv split groups only): MIXED launch - the nsplit heaviest q tiles of a group are split, the others go two per workgroup
+    int32_t perm_n;        // > 0: the first perm_n slots of every XCD run the work item perm[slot] (fa_fwd_dma.hip; fa_capi.cpp balanced_order)
+    uint8_t perm[128];
+    unsigned long long* stamps;   // measurement builds only (-DFA_STAMPS, scripts/phase_times.py): 16 u64 per wave, else null
 };
 
 // backward (fa_bwd_kernels.hip)
@@ -49,6 +66,7 @@ struct BwdParams {
     int32_t sched;         // query groups per XCD bunch (dQ grid)
     int32_t sched_kv;      // K/V groups per XCD bunch (dK/dV grid)
     float scale, scale_log2;
+    ExtraParams ex;
 };
 // One launch, reporting ITS OWN status: hipLaunchKernel returns this launch's result, whereas hipGetLastError()
 // after a <<<>>> launch also returns (and clears) a stale error left on the thread by an unrelated earlier HIP
@@ -65,7 +83,9 @@ hipError_t launch_bwd_generic(const BwdParams& p, int dtype, hipStream_t stream)
 hipError_t launch_bwd_f32(const BwdParams& p, hipStream_t stream);   // fa_bwd_f32.hip: fp32, D in {64, 128}
 
 hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream);
-hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, int split, hipStream_t stream);
+hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, int split, int pair, hipStream_t stream);
+hipError_t launch_fwd_extra(const FwdParams& p, int dtype, hipStream_t stream);   // fa_fwd_extra.hip: mask / bias / dropout (16-bit, D in {64, 128})
+hipError_t launch_bwd_extra(const BwdParams& p, int dtype, hipStream_t stream);   // fa_bwd_extra.hip
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream);
 hipError_t launch_fwd_f32(const FwdParams& p, hipStream_t stream);   // fa_fwd_f32.hip
 

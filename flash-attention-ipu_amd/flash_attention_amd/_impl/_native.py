@@ -17,7 +17,7 @@ _LIB = None
 _LIB_PATH = None
 
 FA_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FaPlan(ctypes.Structure):
@@ -34,6 +34,9 @@ class FaPlan(ctypes.Structure):
         ("sched", ctypes.c_int32),
         ("skipmax", ctypes.c_int32),
         ("source", ctypes.c_int32),
+        ("pair", ctypes.c_int32),
+        ("nsplit", ctypes.c_int32),
+        ("balanced", ctypes.c_int32),
     ]
 
 
@@ -91,6 +94,13 @@ def _declare(lib):
                            i32, i32, i32, ctypes.c_float, i32, vp]
     lib.fa_bwd.restype = ctypes.c_int
     lib.fa_bwd.argtypes = [vp] * 10 + [i64, i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32, vp]
+    u64 = ctypes.c_uint64
+    lib.fa_fwd_ex.restype = ctypes.c_int
+    lib.fa_fwd_ex.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, p64, p64, p64, p64,
+                              i32, i32, i32, ctypes.c_float, i32, vp, i32, p64, ctypes.c_float, u64, u64, vp]
+    lib.fa_bwd_ex.restype = ctypes.c_int
+    lib.fa_bwd_ex.argtypes = [vp] * 10 + [i64, i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32,
+                                          vp, i32, p64, ctypes.c_float, u64, u64, vp]
     lib.fa_probe_clock.restype = ctypes.c_int
     lib.fa_probe_clock.argtypes = [ctypes.c_void_p, i32, ctypes.c_void_p]
     lib.fa_probe_mfma_peak.restype = ctypes.c_double
@@ -102,7 +112,9 @@ def _declare(lib):
 def _raise(rc):
     lib = load_native_library()
     msg = lib.fa_last_error().decode() or lib.fa_error_string(rc).decode()
-    if rc in (-2, -3, -4, -5, -7, -9, -11, -12):
+    if rc == -13:
+        raise NotImplementedError(f"flash_attention_amd: {msg}")
+    if rc in (-2, -3, -4, -5, -7, -9, -11, -12, -14, -15):
         raise ValueError(f"flash_attention_amd: {msg}")
     raise RuntimeError(f"flash_attention_amd: {msg} (code {rc})")
 
@@ -119,7 +131,8 @@ def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale: float = 1.0
 
 
 _KERNEL_CODE = {"auto": 0, "": 0, None: 0, "dma": ord("d"), "pipe": ord("p"), "pipe16": ord("x"), "tile": ord("t")}
-_OPTION_AUTO = {"kernel": 0, "qb": 0, "waves": 0, "sched": 0, "skipmax": -1, "f32_generic": 0, "table": 1, "split": 0}
+_OPTION_AUTO = {"kernel": 0, "qb": 0, "waves": 0, "sched": 0, "skipmax": -1, "f32_generic": 0, "table": 1, "split": 0, "pair": -1,
+                "balance": -1, "nsplit": -1}
 
 
 def set_debug_option(name: str, value) -> None:
@@ -251,5 +264,50 @@ def bwd(q, k, v, out, dout, lse, dq, dk, dv, G, L, D, heads, scale, causal: bool
                         dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(), G, L, D, heads,
                         heads if heads_kv is None else heads_kv,
                         ctypes.cast(arr, _P_I64x3), FA_DTYPE[q.dtype], float(scale), int(bool(causal)), stream)
+    if rc != 0:
+        _raise(rc)
+
+
+MASK_NONE, MASK_BOOL, MASK_BIAS = 0, 1, 2
+
+
+def _mask_args(mask, q):
+    """(pointer, kind, strides) of an attention mask already expanded to [B, H, L, L] (stride 0 = broadcast, unit stride on the
+    key dimension): torch.bool -> boolean bytes, the operand dtype -> additive bias."""
+    if mask is None:
+        return None, MASK_NONE, None
+    kind = MASK_BOOL if mask.dtype in (torch.bool, torch.uint8) else MASK_BIAS
+    if kind == MASK_BIAS and mask.dtype != q.dtype:
+        raise ValueError("a float attn_mask must have the dtype of the query")
+    return mask.data_ptr(), kind, _strides3((mask.stride(0), mask.stride(1), mask.stride(2)))
+
+
+def fwd_ex(q, k, v, out, lse, L, D, scale, causal, mask, dropout_p, seed, offset):
+    """fa_fwd_ex on [B, H, L, D] views (k, v may carry fewer heads); mask: None or a [B, H, L, L] view (see _mask_args)."""
+    lib = load_native_library()
+    B, H = q.shape[0], q.shape[1]
+    st = lambda t: _strides3((t.stride(0), t.stride(1), t.stride(2)))  # noqa: E731
+    mptr, kind, mst = _mask_args(mask, q)
+    with _on_device_of(q) as stream:
+        rc = lib.fa_fwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+                           B * H, L, D, H, k.shape[1], st(q), st(k), st(v), st(out), 1, 1, FA_DTYPE[q.dtype], float(scale),
+                           int(bool(causal)), mptr, kind, mst, float(dropout_p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), stream)
+    if rc != 0:
+        _raise(rc)
+
+
+def bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, L, D, scale, causal, mask, dropout_p, seed, offset):
+    """fa_bwd_ex on [B, H, L, D] views (k, v, dk, dv [B, H_kv, L, D])."""
+    lib = load_native_library()
+    B, H = q.shape[0], q.shape[1]
+    flat = [x for t in (q, k, v, out, dout, dq, dk, dv) for x in (t.stride(0), t.stride(1), t.stride(2))]
+    arr = _I64x24(*flat)
+    dsum = torch.empty((B * H, L), dtype=torch.float32, device=q.device)
+    mptr, kind, mst = _mask_args(mask, q)
+    with _on_device_of(q) as stream:
+        rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(), B * H, L, D, H, k.shape[1],
+                           ctypes.cast(arr, _P_I64x3), FA_DTYPE[q.dtype], float(scale), int(bool(causal)),
+                           mptr, kind, mst, float(dropout_p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), stream)
     if rc != 0:
         _raise(rc)

@@ -11,6 +11,7 @@ into the C ABI stays out of the traced graph.
 from typing import Tuple
 
 import torch
+from torch.autograd.function import once_differentiable
 from torch.library import custom_op
 
 from . import _native
@@ -262,9 +263,12 @@ class _AttentionFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable          # (the HIP backward builds no graph: a double backward raises instead of yielding nothing)
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = _bwd_impl(q, k, v, out, dout, lse, ctx.softmax_scale, ctx.causal, one_buffer=True)
+        # one [3, G, L, D] allocation when all three gradients are wanted (they are freed together); separate buffers otherwise,
+        # so that one leaf's .grad does not keep three tensors' worth of storage alive
+        dq, dk, dv = _bwd_impl(q, k, v, out, dout, lse, ctx.softmax_scale, ctx.causal, one_buffer=all(ctx.needs_input_grad[:3]))
         return dq, dk, dv, None, None, None, None
 
 
@@ -277,6 +281,7 @@ class _GqaAttentionFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
         dq, dk, dv = _bwd_gqa_impl(q, k, v, out, dout, lse, ctx.softmax_scale, ctx.causal)
@@ -291,6 +296,7 @@ class _PackedAttentionFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
         return _bwd_qkv_packed_impl(qkv, out, dout, lse), None, None
@@ -334,3 +340,62 @@ def attention_bhld(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=T
     if torch.compiler.is_compiling():
         return fwd_bhld(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)
     return _fwd_bhld_impl(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+
+
+# ---- attention mask / additive bias and dropout (fa_fwd_ex / fa_bwd_ex; eager only) ---------------------------------------
+# The two scaled_dot_product_attention modes the reference rejects (sdpa.py:21-28).  [B, H, L, D] query, [B, H_kv, L, D] key /
+# value; `mask` is None or a view expanded to [B, H, L, L] (boolean: True = the key takes part; float: added to the scaled
+# logits; no gradient flows to it); dropout decisions are a pure function of (seed, offset, group, row, key), so the backward
+# regenerates them from the two integers saved here.
+def supports_extra(q: torch.Tensor) -> bool:
+    """What the mask / dropout kernels take: f16 / bf16, head_dim 64 or 128, 16-byte aligned rows (the override lets stock SDPA
+    serve everything else)."""
+    return q.dtype in (torch.float16, torch.bfloat16) and q.shape[-1] in (64, 128)
+
+
+class _ExtraAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset):
+        q, k, v = _rows(q), _rows(k), _rows(v)
+        B, H, L, D = q.shape
+        out = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B * H, L), dtype=torch.float32, device=q.device)
+        if out.numel() > 0:
+            _native.fwd_ex(q, k, v, out, lse, L, D, softmax_scale, causal, mask, dropout_p, seed, offset)
+        ctx.save_for_backward(q, k, v, out, lse, *(() if mask is None else (mask,)))
+        ctx.args = (softmax_scale, causal, dropout_p, seed, offset, mask is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors[:5]
+        softmax_scale, causal, dropout_p, seed, offset, has_mask = ctx.args
+        mask = ctx.saved_tensors[5] if has_mask else None
+        B, H, L, D = q.shape
+        dout = _rows(dout)
+        dq = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
+        dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+        dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+        if dq.numel() > 0:
+            _native.bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, L, D, softmax_scale, causal, mask, dropout_p, seed, offset)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+def attention_extra(q, k, v, mask, softmax_scale, causal, dropout_p=0.0, seed=0, offset=0):
+    """[B, H, L, D] attention with an attention mask / bias and / or dropout -> out [B, H, L, D], differentiable in q, k, v."""
+    return _ExtraAttentionFn.apply(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset)
+
+
+def next_dropout_seed(device, numel: int):
+    """(seed, offset) for one dropout launch, drawn from torch's generator of `device` the way its own dropout kernels do: the
+    generator's seed and its running offset, which is advanced past the `numel` decisions of this launch - so torch.manual_seed
+    makes runs repeatable and successive calls see different masks."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    seed = gen.initial_seed()
+    try:
+        offset = gen.get_offset()
+        gen.set_offset(offset + ((numel + 3) // 4) * 4)
+    except RuntimeError:    # (a generator without offsets: fall back to one draw from it)
+        offset = int(torch.randint(0, 2 ** 62, (1,), generator=gen, device=device).item())
+    return seed, offset

@@ -8,7 +8,12 @@ Same mechanism, guards, messages and chunk heuristic as the reference override
     reached through `torch.library` custom ops (ops.py), so autograd and torch.compile see opaque ops;
   * `attn_mask is not None` replaces the reference's `if attn_mask:` (which raises RuntimeError for
     multi-element masks instead of NotImplementedError);
-  * the modern `scale=` / `enable_gqa=` keywords are accepted so current callers do not break.
+  * the modern `scale=` / `enable_gqa=` keywords are accepted so current callers do not break;
+  * on the GPU the four modes the reference rejects (sdpa.py:21-37) are served instead of raising: is_causal=False, grouped
+    K/V heads (with enable_gqa=True, as stock SDPA demands), `attn_mask` (boolean or additive, anything broadcastable to
+    [B, H, L, L]) and `dropout_p > 0` - the last two by the mask / dropout kernels (fa_fwd_ex / fa_bwd_ex) for f16 / bf16 at
+    head_dim 64 / 128, by stock SDPA (`orig_fn`) for everything those kernels do not take.  Off the GPU they raise exactly
+    like the reference.
 """
 
 from math import ceil, floor, log2
@@ -32,6 +37,46 @@ def _gqa_ok(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor) -> bool
             and query.shape[2:] == key.shape[2:] and key.shape[1] >= 1 and query.shape[1] % key.shape[1] == 0)
 
 
+def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale):
+    """attn_mask and / or dropout through the mask / dropout kernels; None when this call is not one they take (the caller then
+    hands it to stock SDPA): operands other than f16 / bf16 at head_dim 64 / 128, more than two batch dimensions, a mask that
+    wants a gradient or does not broadcast to [B, H, L, L], attn_mask together with is_causal (torch's own error), tracing."""
+    if not ops.supports_extra(query) or query.ndim not in (3, 4) or torch.compiler.is_compiling():
+        return None
+    if attn_mask is not None and (is_causal or attn_mask.requires_grad or not attn_mask.is_cuda):
+        return None
+    if not (0.0 <= dropout_p < 1.0):
+        return None
+    q4, k4, v4 = (t.unsqueeze(1) if t.ndim == 3 else t for t in (query, key, value))
+    B, H, L, D = q4.shape
+    if q4.numel() == 0 or k4.numel() == 0:
+        return None
+    mask = None
+    if attn_mask is not None:
+        m = attn_mask
+        if m.dtype != torch.bool:
+            if not m.dtype.is_floating_point:
+                return None
+            m = m.to(query.dtype)
+        if m.ndim > 4 or (query.ndim == 3 and m.ndim > 3):
+            return None
+        if m.ndim >= 1 and m.stride(-1) != 1 and m.shape[-1] > 1:
+            m = m.contiguous()
+        if query.ndim == 3 and m.ndim == 3:
+            m = m.unsqueeze(1)
+        try:
+            m = m.expand(B, H, L, L)
+        except RuntimeError:
+            return None
+        if m.stride(-1) != 1:      # (a mask broadcast along the keys: materialise that row once)
+            m = m.contiguous()
+        mask = m.view(torch.uint8) if m.dtype == torch.bool else m
+    softmax_scale = D ** -0.5 if scale is None else scale
+    seed, offset = ops.next_dropout_seed(query.device, B * H * L * L) if dropout_p > 0.0 else (0, 0)
+    out = ops.attention_extra(q4, k4, v4, mask, softmax_scale, bool(is_causal), float(dropout_p), seed, offset)
+    return out.squeeze(1) if query.ndim == 3 else out
+
+
 @patch_function(torch.nn.functional.scaled_dot_product_attention, [torch.nn.functional])
 def _scaled_dot_product_attention_amd(
     orig_fn: Callable,
@@ -49,14 +94,16 @@ def _scaled_dot_product_attention_amd(
     # The reference's guards, same order and messages (sdpa.py:21-41).  Two of them are WIDENED on the GPU
     # (SURVEY 8f-4): is_causal=False and grouped-/multi-query shapes are served by the HIP kernels instead of
     # raising; off the GPU they raise exactly like the reference.
-    if attn_mask is not None:
+    if attn_mask is not None and not on_device:
         raise NotImplementedError("flash_attention_ipu does not currently support passing attn_mask")
-    if dropout_p > 0.0:
+    if dropout_p > 0.0 and not on_device:
         raise NotImplementedError("flash_attention_ipu does not currently support non-zero dropout_p")
     if not is_causal and not on_device:
         raise NotImplementedError("flash_attention_ipu does not currently support is_causal=False")
     gqa = query.shape != key.shape
-    if gqa and not (on_device and _gqa_ok(query, key, value)):
+    # (grouped K/V heads are served only when the caller asks for them, as stock SDPA does: without enable_gqa=True a
+    # query.shape != key.shape call raises like the reference instead of silently computing something stock SDPA rejects)
+    if gqa and not (on_device and enable_gqa and _gqa_ok(query, key, value)):
         raise NotImplementedError(
             "flash_attention_ipu does not currently support Grouped- or Multi-query \
              attention (query.shape != key.shape)"
@@ -73,6 +120,11 @@ def _scaled_dot_product_attention_amd(
     # else is stock SDPA's business
     if on_device and scale is not None and not (scale > 0.0 and scale < float("inf")):
         on_device = False
+    if on_device and (attn_mask is not None or dropout_p > 0.0):
+        out = _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale)
+        if out is not None:
+            return out
+        on_device = False       # (a combination the mask / dropout kernels do not take: stock SDPA serves it)
     if on_device:
         L, D = query.shape[-2:]
         batch_shape = query.shape[:-2]

@@ -47,7 +47,8 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 3   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V) */
+#define FA_ABI_VERSION 4   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
+                              fa_fwd_ex / fa_bwd_ex (attention mask or bias, dropout) */
 
 /* element types (reference allows FLOAT16 and FLOAT, FA.cpp:609; bf16 is new here) */
 enum { FA_DTYPE_F16 = 0, FA_DTYPE_BF16 = 1, FA_DTYPE_F32 = 2 };
@@ -67,7 +68,10 @@ enum {
     FA_ERR_BAD_STRIDE = -9,
     FA_ERR_TOO_LARGE = -10,         /* grid or offsets exceed what the kernel indexes */
     FA_ERR_BAD_SCALE = -11,         /* softmax_scale must be finite and > 0 */
-    FA_ERR_BAD_OPTION = -12         /* fa_debug_set_option: unknown name or value out of range */
+    FA_ERR_BAD_OPTION = -12,        /* fa_debug_set_option: unknown name or value out of range */
+    FA_ERR_UNSUPPORTED = -13,       /* fa_fwd_ex / fa_bwd_ex with a mask or dropout on operands the MFMA kernels do not take */
+    FA_ERR_BAD_MASK = -14,          /* mask_kind out of range, or mask pointer and mask_kind disagree */
+    FA_ERR_BAD_DROPOUT = -15        /* dropout_p outside [0, 1) */
 };
 
 /* hardware tile the request was mapped to (fa_plan) */
@@ -90,6 +94,10 @@ typedef struct fa_plan_t {
                             (bf16 always; f16 when softmax_scale <= 0.25), 0 = per-tile row max with lazy rescale */
     int32_t source;      /* 0 = built-in rules, 1 = a row of the measured tuning table (fa_tuning_table.h),
                             2 = a debug override was in force (fa_debug_set_option / FA_AMD_* at load) */
+    int32_t pair;        /* 1 = a workgroup owns two q tiles, (n - 1 - i) then i, one after the other (causal, 64-key tiles) [ABI 4] */
+    int32_t nsplit;      /* >= 0: MIXED launch of 2-group workgroups - that many of a group's heaviest q tiles have their kv loop split, the
+                            others go two per workgroup, one per wave group (causal grids of about one round of slots); -1 otherwise [ABI 4] */
+    int32_t balanced;    /* 1 = placement-balanced block order (a causal grid below one round of the chip's workgroup slots) [ABI 4] */
 } fa_plan_t;
 
 int fa_abi_version(void);
@@ -134,9 +142,17 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  *   "qb"      0 auto | 1 | 2        "waves"  0 auto | 1 | 2 | 4 | 8        "sched"  0 auto | n >= 1
  *   "skipmax" -1 auto | 0 | 1       "f32_generic" 0 | 1                    "table"  1 use the tuning table | 0 rules only
  *   "split"   0 auto | 1 | 2 | 4    kv split groups per workgroup ('d' kernel, 4 waves x 32 rows per group)
+ *   "pair"    -1 auto | 0 | 1       q-tile pairs (n - 1 - i, i) per workgroup ('d' kernel, causal, 4 waves)
+ *   "balance" -1 auto | 0 | 1       placement-balanced block order of a causal grid below one round of workgroup slots
+ *   "nsplit"  -1 auto | n >= 0      MIXED launch ('d' kernel, 2 wave groups per workgroup) with the n heaviest q tiles of a group split
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
 int fa_debug_set_option(const char* name, int32_t value);
 int fa_debug_get_option(const char* name, int32_t* value);
+
+/* MEASUREMENT BUILDS ONLY (-DFA_STAMPS, scripts/phase_times.py): a device buffer of its own for the in-kernel phase
+ * stamps - 16 uint64 per wave of a forward launch, record ((g * q_tiles + q_tile) * waves + wave); never an output
+ * tensor.  The shipped library accepts the call and writes nothing.  (NULL, 0) clears it.  (No reference counterpart.) */
+int fa_debug_set_stamp_buffer(void* device_buffer, int64_t bytes);
 
 /*
  * Forward on three strided views.  All pointers are device pointers.
@@ -181,6 +197,42 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
            void* dq, void* dk, void* dv, float* dsum_workspace,
            int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
            int32_t dtype, float softmax_scale, int32_t causal, void* stream);
+
+/* mask_kind of fa_fwd_ex / fa_bwd_ex */
+#define FA_MASK_NONE 0
+#define FA_MASK_BOOL 1   /* bytes, non-zero = the key takes part (torch's boolean attn_mask) */
+#define FA_MASK_BIAS 2   /* additive term on the scaled logits, in the operand dtype (torch's float attn_mask) */
+
+/*
+ * fa_fwd / fa_bwd with an attention mask or additive bias and / or dropout - the two modes of scaled_dot_product_attention
+ * that the reference rejects (flash_attention_ipu/_impl/scaled_dot_product_attention.py:21-28: `attn_mask`, `dropout_p > 0`;
+ * SURVEY 8f-4).  [ABI 4]  Everything before `mask` is as in fa_fwd / fa_bwd.
+ *   mask          : device pointer or NULL (mask_kind FA_MASK_NONE).  Element (g, row, key) at
+ *                   mask[(g / heads) * mask_strides[0] + (g % heads) * mask_strides[1] + row * mask_strides[2] + key]
+ *                   (strides in ELEMENTS of the mask's type; 0 broadcasts that dimension - e.g. a [L, L] mask has strides
+ *                   {0, 0, L}, a key-padding mask [B, 1, 1, L] has {L, 0, 0}; the key dimension is contiguous).
+ *                   FA_MASK_BOOL: bytes, non-zero = the key takes part;  FA_MASK_BIAS: values of the operand dtype, added to
+ *                   softmax_scale * (q . k) - use -inf to exclude a key.  A row that excludes every key returns NaN (as torch
+ *                   does) and lse = -inf.  May be combined with causal = 1.  No gradient is computed for a bias.
+ *   dropout_p     : probability in [0, 1) of dropping an attention weight (0 = off); kept weights are scaled by 1 / (1 - p).
+ *                   The decision for (g, row, key) is a pure function of (dropout_seed, dropout_offset, g, row, key)
+ *                   (csrc/fa_extras.h), so fa_bwd_ex given the same three values regenerates the forward's mask.
+ * Served by MFMA kernels only: f16 / bf16 operands, head_dim 64 or 128, 16-byte aligned rows - otherwise FA_ERR_UNSUPPORTED
+ * (the Python override then lets stock SDPA serve the call).  With mask = NULL and dropout_p = 0 they ARE fa_fwd / fa_bwd.
+ */
+int fa_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
+              int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,
+              const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
+              const int64_t o_strides[3],
+              int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, float softmax_scale, int32_t causal,
+              const void* mask, int32_t mask_kind, const int64_t mask_strides[3],
+              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, void* stream);
+int fa_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+              void* dq, void* dk, void* dv, float* dsum_workspace,
+              int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
+              int32_t dtype, float softmax_scale, int32_t causal,
+              const void* mask, int32_t mask_kind, const int64_t mask_strides[3],
+              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, void* stream);
 
 /* Forward on a contiguous packed qkv [3,G,L,D] -> out [G,L,D] (scale 1, causal). */
 int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,

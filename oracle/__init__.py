@@ -19,3 +19,4 @@ from .dense_attention import (  # noqa: F401
     sdpa_chunk_heuristic,
     frozen_randn,
 )
+from .dropout import dense_attention_extra, dropout_keep, dropout_key0, dropout_threshold  # noqa: F401,E402

@@ -3,7 +3,7 @@
 usage: python scripts/sweep.py [cfg] SPEC [SPEC ...]
   SPEC = "[lib:]K=pipe,W=4,S=4"   lib = name of build/variants/libfa_<lib>.so (default: the shipped library)
          K kernel (tile|dma|pipe|pipe16), W waves per workgroup, S groups per L2 bunch, Q 32-row query blocks per wave (1|2),
-         P kv split groups per workgroup (dma: 2|4)
+         P kv split groups per workgroup (dma: 2|4), R q-tile pairs per workgroup (dma: 0|1, default auto), B placement-balanced order (0|1, default auto), M MIXED launch with that many split q tiles per group
 Each timing = N back-to-back launches between two events; rounds are interleaved across specs.
 """
 import ctypes, os, sys, pathlib, statistics
@@ -16,7 +16,9 @@ CFG = {"cfg2": (128, 4096, 64, torch.bfloat16, 8, 8), "cfg2h": (128, 4096, 64, t
        "cfg5": (256, 8192, 64, torch.bfloat16, 16, 8), "short": (512, 1024, 64, torch.bfloat16, 4, 4), "l1k": (2048, 1024, 64, torch.bfloat16, 8, 8), "g8l4k": (8, 4096, 64, torch.bfloat16, 8, 8), "g8l8k": (8, 8192, 64, torch.bfloat16, 8, 8), "g4l8kd128": (4, 8192, 128, torch.bfloat16, 8, 8), "g32l2k": (32, 2048, 64, torch.bfloat16, 8, 8),
        "small1": (8, 2048, 64, torch.bfloat16, 1, 1), "small2": (16, 1024, 64, torch.bfloat16, 1, 1),
        "small3": (32, 4096, 64, torch.bfloat16, 1, 1), "small4": (12, 1024, 64, torch.bfloat16, 1, 1),
-       "gpt": (96, 1024, 64, torch.bfloat16, 1, 1), "long64": (16, 32768, 64, torch.bfloat16, 16, 16), "g64l8k": (64, 8192, 64, torch.bfloat16, 8, 8), "g32l16k": (32, 16384, 64, torch.bfloat16, 8, 8), "g32l4k": (32, 4096, 64, torch.bfloat16, 8, 8), "g256l2k": (256, 2048, 64, torch.bfloat16, 8, 8), "d128l2k": (128, 2048, 128, torch.bfloat16, 8, 8), "d128l8k": (32, 8192, 128, torch.bfloat16, 8, 8), "d128g16": (16, 4096, 128, torch.bfloat16, 8, 8), "d128h": (64, 4096, 128, torch.float16, 8, 8), "g64l4k": (64, 4096, 64, torch.bfloat16, 8, 8), "small5": (4, 8192, 128, torch.bfloat16, 1, 1)}
+       "gpt": (96, 1024, 64, torch.bfloat16, 1, 1), "long64": (16, 32768, 64, torch.bfloat16, 16, 16), "g64l8k": (64, 8192, 64, torch.bfloat16, 8, 8), "g32l16k": (32, 16384, 64, torch.bfloat16, 8, 8), "g32l4k": (32, 4096, 64, torch.bfloat16, 8, 8), "g256l2k": (256, 2048, 64, torch.bfloat16, 8, 8), "d128l2k": (128, 2048, 128, torch.bfloat16, 8, 8), "d128l8k": (32, 8192, 128, torch.bfloat16, 8, 8), "d128g16": (16, 4096, 128, torch.bfloat16, 8, 8), "d128h": (64, 4096, 128, torch.float16, 8, 8), "g64l4k": (64, 4096, 64, torch.bfloat16, 8, 8), "small5": (4, 8192, 128, torch.bfloat16, 1, 1),
+       "g64l1k": (64, 1024, 64, torch.bfloat16, 1, 1), "g48l2k": (48, 2048, 64, torch.bfloat16, 1, 1), "g24l4k": (24, 4096, 64, torch.bfloat16, 1, 1),
+       "g96l1kd128": (96, 1024, 128, torch.bfloat16, 1, 1), "g128l1k": (128, 1024, 64, torch.bfloat16, 1, 1), "g192l1k": (192, 1024, 64, torch.bfloat16, 1, 1)}
 args = sys.argv[1:]
 cfg = "cfg2"
 if args and args[0] in CFG:
@@ -47,11 +49,11 @@ def parse(spec):
 
 def setknobs(lib, rest):
     """knobs go through fa_debug_set_option of THAT library (the environment is only read once, at load)"""
-    want = {"kernel": 0, "waves": 0, "sched": 0, "qb": 0, "split": 0}
+    want = {"kernel": 0, "waves": 0, "sched": 0, "qb": 0, "split": 0, "pair": -1, "balance": -1, "nsplit": -1}
     for kv in rest.split(","):
         if kv:
             k, val = kv.split("=")
-            name = {"K": "kernel", "W": "waves", "S": "sched", "Q": "qb", "P": "split"}[k]
+            name = {"K": "kernel", "W": "waves", "S": "sched", "Q": "qb", "P": "split", "R": "pair", "B": "balance", "M": "nsplit"}[k]
             want[name] = (ord("x") if val in ("pipe16", "x") else ord(val[0])) if name == "kernel" else int(val)
     for name, val in want.items():
         assert lib.fa_debug_set_option(name.encode(), val) == 0, (name, val)

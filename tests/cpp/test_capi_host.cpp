@@ -91,6 +91,13 @@ int main() {
     EXPECT(fa_fwd_qkv_packed(nullptr, p, nullptr, 1, 8, 64, 1, 1, FA_DTYPE_BF16, nullptr) == FA_ERR_NULL_POINTER);
     EXPECT(fa_fwd_qkv_packed(p, p, nullptr, 0, 8, 64, 1, 1, FA_DTYPE_BF16, nullptr) == FA_ERR_BAD_SHAPE);
     EXPECT(fa_fwd_qkv_packed(p, p, nullptr, 1, 8, 64, 1, 1, 5, nullptr) == FA_ERR_BAD_DTYPE);
+    // sizes are bounded before the packed pointer arithmetic (G * L * D * es must not overflow: UBSan would trap here)
+    EXPECT(fa_fwd_qkv_packed(p, p, nullptr, 1ll << 62, 8, 64, 1, 1, FA_DTYPE_BF16, nullptr) == FA_ERR_TOO_LARGE);
+    EXPECT(fa_fwd_qkv_packed(p, p, nullptr, 1, 1ll << 62, 64, 1, 1, FA_DTYPE_BF16, nullptr) == FA_ERR_TOO_LARGE);
+    EXPECT(fa_fwd_qkv_packed(p, p, nullptr, 1, 8, 1ll << 62, 1, 1, FA_DTYPE_F32, nullptr) == FA_ERR_TOO_LARGE);
+    EXPECT(fa_fwd_qkv_packed(p, p, nullptr, 1ll << 30, 1ll << 30, 1ll << 20, 1, 1, FA_DTYPE_F32, nullptr) == FA_ERR_TOO_LARGE);   // every size in range, the product not
+    EXPECT(fa_debug_set_stamp_buffer(nullptr, 8) == FA_ERR_BAD_OPTION && fa_debug_set_stamp_buffer(buf + 1, 64) == FA_ERR_MISALIGNED);
+    EXPECT(fa_debug_set_stamp_buffer(buf, 64) == FA_OK && fa_debug_set_stamp_buffer(nullptr, 0) == FA_OK);
     EXPECT(g_stub_launches == launches0 + 5);
     int64_t st8[8][3];
     for (auto& r : st8) { r[0] = 128 * 64; r[1] = 0; r[2] = 64; }
@@ -104,6 +111,31 @@ int main() {
     EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 3, 128, 64, 2, 2, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_SHAPE);
     EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 6, 128, 64, 6, 4, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_SHAPE);   // heads % heads_kv
     EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 8, 128, 64, 4, 2, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'B');   // grouped-query
+    // ---- mask / bias / dropout entry points (ABI 4): argument checks, routing, what the plain entry points still do
+    {
+        const int64_t ms[3] = {0, 0, 128}, ms_neg[3] = {0, -1, 128};
+        const int n0 = g_stub_launches;
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last == 'E');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F16, 0.125f, 0, p, FA_MASK_BIAS, ms, 0.25f, 7, 9, nullptr) == FA_OK && g_stub_last == 'E');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.1f, 1ull << 63, ~0ull, nullptr) == FA_OK && g_stub_last == 'E');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last != 'E');   // nothing extra = fa_fwd
+        EXPECT(g_stub_launches == n0 + 4);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_NONE, ms, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_MASK);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_MASK);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, 3, ms, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_MASK);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, nullptr, 0.0f, 0, 0, nullptr) == FA_ERR_NULL_POINTER);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms_neg, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_STRIDE);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, buf + 1, FA_MASK_BIAS, ms, 0.0f, 0, 0, nullptr) == FA_ERR_MISALIGNED);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 1.0f, 0, 0, nullptr) == FA_ERR_BAD_DROPOUT);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, -0.5f, 0, 0, nullptr) == FA_ERR_BAD_DROPOUT);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 0.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr) == FA_ERR_BAD_SCALE);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr) == FA_ERR_UNSUPPORTED);   // fp32
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 80, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_ERR_UNSUPPORTED);      // head_dim 80
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BIAS, ms, 0.1f, 3, 4, nullptr) == FA_OK && g_stub_last == 'e');
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last == 'B');
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.3f, 0, 0, nullptr) == FA_ERR_UNSUPPORTED);
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 2.0f, 0, 0, nullptr) == FA_ERR_BAD_DROPOUT);
+    }
     st8[3][1] = -5;
     EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_STRIDE);
     // ---- thread-local error text; concurrent plan + option calls (ThreadSanitizer-style smoke under ASan/UBSan)
@@ -119,7 +151,7 @@ int main() {
         });
     for (auto& x : th) x.join();
     fa_debug_set_option("sched", 0);
-    for (int code = 1; code >= -14; --code) EXPECT(fa_error_string(code) != nullptr && std::strlen(fa_error_string(code)) > 0);
+    for (int code = 1; code >= -17; --code) EXPECT(fa_error_string(code) != nullptr && std::strlen(fa_error_string(code)) > 0);
     std::printf(fails ? "FAILED (%d)\n" : "PASSED\n", fails);
     return fails ? 1 : 0;
 }

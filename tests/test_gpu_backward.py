@@ -202,3 +202,41 @@ def test_eager_fast_path_and_custom_ops_agree_bitwise():
         assert torch.equal(o3, o4) and torch.equal(g3, g4)
     q4 = qkv[0].view(1, 3, 300, 64)
     assert torch.equal(ops.attention_bhld(q4, q4, q4, 0.125, 1, 1, True), ops.fwd_bhld(q4, q4, q4, 0.125, 1, 1, True))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gradients_from_the_kernels_lse_vs_the_oracles_lse(dtype):
+    """The forward's logsumexp stash is formed from the sum of the 16-bit-rounded P (the denominator the PV product really used):
+    up to 2^-8 relative (bf16) away from the reference definition m + log(l) (FA.cpp:316).  The backward recomputes P = exp(S - lse)
+    from it, so this quantifies what that costs: gradients computed by the SAME backward kernels from the kernel's stash and from
+    the fp64 oracle's logsumexp, both against autograd through the oracle.  The stash's error must not be what bounds them."""
+    import flash_attention_amd as fa
+    from flash_attention_amd._impl import _native
+    from flash_attention_amd._impl.flash_attention_qkv_packed import flash_attention_qkv_packed_with_lse
+    from oracle import dense_causal_attention_lse, frozen_randn
+
+    G, L, D = 4, 1024, 64
+    qkv = (frozen_randn(SEED + 77, (3, G, L, D)) * 0.5).to(dtype)
+    dout = frozen_randn(SEED + 78, (G, L, D)).to(dtype)
+    _, ref_grad = _oracle_grads(qkv, dout, 1.0)
+    _, ref_lse = dense_causal_attention_lse(qkv, scale=1.0)
+    x = qkv.cuda()
+    out, lse = flash_attention_qkv_packed_with_lse(x, 1, 1)
+    lse_err = (lse.cpu().double() - ref_lse).abs().max().item()
+    grads = {}
+    for name, stash in (("kernel", lse), ("oracle", ref_lse.float().cuda())):
+        dqkv = torch.empty_like(x)
+        _native.bwd(x[0], x[1], x[2], out, dout.cuda(), stash, dqkv[0], dqkv[1], dqkv[2], G, L, D, 1, 1.0, True)
+        grads[name] = dqkv.cpu().double()
+    scale = ref_grad.abs().max().item()
+    e_k = (grads["kernel"] - ref_grad).abs().max().item() / scale
+    e_o = (grads["oracle"] - ref_grad).abs().max().item() / scale
+    rms_k = ((grads["kernel"] - ref_grad).square().mean().sqrt() / ref_grad.square().mean().sqrt()).item()
+    rms_o = ((grads["oracle"] - ref_grad).square().mean().sqrt() / ref_grad.square().mean().sqrt()).item()
+    print(f"\\n{dtype}: max|dLSE| = {lse_err:.2e}; gradient error / max|grad|: kernel stash {e_k:.3e} (rms {rms_k:.3e}), oracle stash {e_o:.3e} (rms {rms_o:.3e})")
+    assert lse_err <= (6e-3 if dtype == torch.bfloat16 else 2e-3)
+    # the gradients' own 16-bit rounding dominates: the kernel's stash may cost at most a quarter on top of the exact stash's error
+    assert rms_k <= 1.25 * rms_o + 1e-4, (rms_k, rms_o)
+    assert e_k <= 1.5 * e_o + 1e-3, (e_k, e_o)
+    for i, n in enumerate("qkv"):
+        _close(grads["kernel"][i].to(dtype), ref_grad[i], f"d{n} from the kernel's stash")

@@ -1,0 +1,218 @@
+"""GPU tests of attention masks / additive biases and dropout (the `attn_mask` and `dropout_p` modes of
+scaled_dot_product_attention that the reference rejects, flash_attention_ipu/_impl/scaled_dot_product_attention.py:21-28).
+
+There is no reference behaviour to restate, so the yardstick is torch's own definition of the op evaluated densely in fp64 on
+the same 16-bit-rounded inputs (oracle.dense_attention_extra), with the dropout decisions taken by the numpy restatement of the
+kernels' counter-based generator (oracle/dropout.py) - forward AND gradients (autograd through the oracle).  Tolerances are the
+forward's (|d| <= 1e-2 + 1e-2 |ref|, t_fa.py:78-79) and the backward's (tests/test_gpu_backward.py).
+"""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+SEED = 1123581321
+TOL = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2}
+LSE_ATOL = 6e-3
+
+
+def _fwd_close(out, ref, what):
+    out = out.detach().cpu().double()
+    nan_ref = torch.isnan(ref)
+    assert torch.equal(torch.isnan(out), nan_ref), f"{what}: NaN rows differ (rows without any admitted key must be NaN, no others)"
+    err = (out - ref).abs()[~nan_ref]
+    bad = err > (1e-2 + 1e-2 * ref.abs()[~nan_ref])
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} elements out of tolerance, max|delta|={err.max().item():.3e}"
+
+
+def _grad_close(got, ref, what):
+    tol = TOL[got.dtype]
+    got = got.detach().cpu().double()
+    err = (got - ref).abs()
+    floor = tol * max(1e-3, ref.abs().max().item())
+    bad = err > floor + 2e-2 * ref.abs()
+    assert torch.isfinite(got).all(), what
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max|d|={err.max().item():.3e}, ref max {ref.abs().max().item():.2f}"
+
+
+def _masks(kind, B, H, L, dtype, gen):
+    """attn_mask variants a caller may pass (each row keeps at least one key unless the variant says otherwise)."""
+    if kind == "bool_LL":            # one [L, L] boolean mask for every group: a random pattern with the diagonal kept
+        m = torch.rand(L, L, generator=gen) < 0.7
+        return m | torch.eye(L, dtype=torch.bool)
+    if kind == "bool_padding":       # key-padding mask [B, 1, 1, L]: each batch entry sees a prefix of the keys
+        lens = torch.randint(1, L + 1, (B,), generator=gen)
+        return (torch.arange(L)[None, :] < lens[:, None]).view(B, 1, 1, L)
+    if kind == "bool_BHLL_dead_rows":     # per-head masks, some rows admit NO key at all (-> NaN rows, as torch)
+        m = torch.rand(B, H, L, L, generator=gen) < 0.5
+        m[:, :, ::7] = False
+        m[:, :, 3] = True
+        return m
+    if kind == "bias_BHLL":          # additive bias per head (ALiBi-like slopes + noise), a few -inf entries
+        pos = torch.arange(L)
+        b = -(pos[:, None] - pos[None, :]).abs().float()[None, None] * torch.linspace(0.01, 0.2, H)[None, :, None, None]
+        b = b + 0.5 * torch.randn(B, H, L, L, generator=gen)
+        b[:, :, :, 1::5] = float("-inf")
+        b[:, :, :, 0] = 0.0
+        return b.to(dtype)
+    if kind == "bias_1HLL":          # the same bias for every batch entry (stride 0 on the batch)
+        return (0.7 * torch.randn(1, H, L, L, generator=gen)).to(dtype)
+    if kind == "bias_row":           # [L] bias along the keys, broadcast over rows
+        return torch.randn(L, generator=gen).to(dtype)
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("kind", ["bool_LL", "bool_padding", "bool_BHLL_dead_rows", "bias_BHLL", "bias_1HLL", "bias_row"])
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.float16, 128)])
+@pytest.mark.parametrize("B,H,Hkv,L", [(2, 3, 3, 200), (1, 4, 2, 256), (2, 2, 1, 333), (1, 2, 2, 1024)])
+def test_masked_forward_and_backward_vs_oracle(kind, dtype, D, B, H, Hkv, L):
+    """attn_mask through fa_fwd_ex / fa_bwd_ex: boolean and additive masks, every broadcast pattern, aligned (one vector load per
+    four keys) and unaligned (L = 200, 333: element loads) strides, grouped K/V heads, rows without any admitted key."""
+    from flash_attention_amd._impl import ops
+    from oracle import dense_attention_extra, frozen_randn
+
+    gen = torch.Generator().manual_seed(SEED + L + H)
+    q = (frozen_randn(SEED + L, (B, H, L, D)) * 0.6).to(dtype)
+    k = (frozen_randn(SEED + L + 1, (B, Hkv, L, D)) * 0.6).to(dtype)
+    v = (frozen_randn(SEED + L + 2, (B, Hkv, L, D)) * 0.6).to(dtype)
+    g = frozen_randn(SEED + L + 3, (B, H, L, D)).to(dtype)
+    mask = _masks(kind, B, H, L, dtype, gen)
+    scale = D ** -0.5
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, ref_lse = dense_attention_extra(qr, kr, vr, scale, False, mask)
+    ok_rows = ~torch.isnan(ref.detach()).any(-1, keepdim=True)
+    torch.where(ok_rows, ref, torch.zeros_like(ref)).backward(g.double())      # (NaN rows carry no gradient in the comparison)
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    mc = mask.cuda().expand(B, H, L, L)
+    mc = mc.view(torch.uint8) if mc.dtype == torch.bool else mc
+    if mc.stride(-1) != 1:
+        mc = mc.contiguous()
+    out = ops.attention_extra(qc, kc, vc, mc, scale, False)
+    _fwd_close(out, ref.detach(), f"masked forward {kind} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
+    torch.where(ok_rows.cuda(), out, torch.zeros_like(out)).backward(g.cuda())
+    if "dead_rows" not in kind:          # (a dead row's P is 0 in the kernels and NaN in the dense formula: compare live masks only)
+        for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
+            _grad_close(got, want, f"{name} {kind} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("p", [0.1, 0.5])
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.float16, 64), (torch.bfloat16, 128)])
+@pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 2, 130), (2, 4, 2, 384), (1, 3, 3, 1000)])
+def test_dropout_forward_and_backward_vs_oracle(causal, p, dtype, D, B, H, Hkv, L):
+    """dropout_p through fa_fwd_ex / fa_bwd_ex: the kernels' keep decisions are the numpy restatement's (same seed / offset /
+    group / row / key), so out, logsumexp and all three gradients match the dense formula; with and without the causal mask."""
+    from flash_attention_amd._impl import ops
+    from oracle import dense_attention_extra, frozen_randn
+
+    seed, offset = 0x1234_5678_9ABC_DEF0 + L, 4096 * L + 12
+    q = (frozen_randn(SEED + L, (B, H, L, D)) * 0.6).to(dtype)
+    k = (frozen_randn(SEED + L + 1, (B, Hkv, L, D)) * 0.6).to(dtype)
+    v = (frozen_randn(SEED + L + 2, (B, Hkv, L, D)) * 0.6).to(dtype)
+    g = frozen_randn(SEED + L + 3, (B, H, L, D)).to(dtype)
+    scale = D ** -0.5
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, _ = dense_attention_extra(qr, kr, vr, scale, causal, None, p, seed, offset)
+    ref.backward(g.double())
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = ops.attention_extra(qc, kc, vc, None, scale, causal, p, seed, offset)
+    _fwd_close(out, ref.detach(), f"dropout forward p={p} causal={causal} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
+    out.backward(g.cuda())
+    for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
+        _grad_close(got, want, f"{name} dropout p={p} causal={causal} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
+    out2 = ops.attention_extra(qc.detach(), kc.detach(), vc.detach(), None, scale, causal, p, seed, offset + 1)
+    assert not torch.equal(out2, out.detach()), "another offset must give another mask"
+    out3 = ops.attention_extra(qc.detach(), kc.detach(), vc.detach(), None, scale, causal, p, seed, offset)
+    assert torch.equal(out3, out.detach()), "the same (seed, offset) must reproduce the result bit for bit"
+
+
+def test_mask_and_dropout_together_with_lse():
+    """Both at once, plus the causal mask underneath, and the logsumexp stash (which ignores dropout: it is the softmax's)."""
+    from flash_attention_amd._impl import _native
+    from oracle import dense_attention_extra, frozen_randn
+
+    B, H, L, D, dtype, p = 2, 2, 320, 64, torch.bfloat16, 0.2
+    gen = torch.Generator().manual_seed(5)
+    q, k, v = ((frozen_randn(SEED + i, (B, H, L, D)) * 0.6).to(dtype) for i in range(3))
+    mask = _masks("bias_BHLL", B, H, L, dtype, gen)
+    ref, ref_lse = dense_attention_extra(q, k, v, D ** -0.5, True, mask, p, 11, 22)
+    out = torch.empty(B, H, L, D, dtype=dtype, device="cuda")
+    lse = torch.empty(B * H, L, dtype=torch.float32, device="cuda")
+    _native.fwd_ex(q.cuda(), k.cuda(), v.cuda(), out, lse, L, D, D ** -0.5, True, mask.cuda(), p, 11, 22)
+    _fwd_close(out, ref, "mask + dropout + causal")
+    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
+def test_sdpa_override_serves_attn_mask_and_dropout():
+    """`import flash_attention_amd.auto`: F.scaled_dot_product_attention(attn_mask=..., dropout_p=...) no longer raises on the GPU
+    (the reference raises NotImplementedError, sdpa.py:21-28): masks agree with stock SDPA and the oracle, dropout is repeatable
+    under torch.manual_seed, keeps ~(1 - p) of the weights, and combinations the kernels do not take go to stock SDPA."""
+    import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl import ops
+    from oracle import dense_attention_extra, frozen_randn
+
+    patched = F.scaled_dot_product_attention
+    stock = patched.__wrapped__
+    B, H, L, D, dtype = 2, 4, 256, 64, torch.bfloat16
+    q, k, v = ((frozen_randn(SEED + 50 + i, (B, H, L, D)) * 0.6).to(dtype).cuda() for i in range(3))
+    gen = torch.Generator().manual_seed(9)
+    calls = []
+    real = ops.attention_extra
+    ops.attention_extra = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    try:
+        for kind in ("bool_LL", "bool_padding", "bias_BHLL", "bias_row"):
+            mask = _masks(kind, B, H, L, dtype, gen)
+            ref, _ = dense_attention_extra(q.cpu(), k.cpu(), v.cpu(), D ** -0.5, False, mask)
+            n = len(calls)
+            _fwd_close(patched(q, k, v, attn_mask=mask.cuda()), ref, f"override attn_mask {kind}")
+            assert len(calls) == n + 1, "the mask kernels must have served this call"
+            _fwd_close(stock(q, k, v, attn_mask=mask.cuda()), ref, f"stock attn_mask {kind}")      # same yardstick
+        # a float32 mask on bf16 operands is converted; a 3-d [B*H, L, D] call is served too
+        m32 = _masks("bias_1HLL", B, H, L, torch.float32, gen)
+        ref, _ = dense_attention_extra(q.cpu(), k.cpu(), v.cpu(), D ** -0.5, False, m32.to(dtype))
+        _fwd_close(patched(q, k, v, attn_mask=m32.cuda()), ref, "override fp32 bias")
+        q3, k3, v3 = (t.reshape(B * H, L, D) for t in (q, k, v))
+        ref3, _ = dense_attention_extra(q3.cpu()[:, None], k3.cpu()[:, None], v3.cpu()[:, None], D ** -0.5, False, _masks("bool_LL", 1, 1, L, dtype, torch.Generator().manual_seed(3)))
+        _fwd_close(patched(q3, k3, v3, attn_mask=_masks("bool_LL", 1, 1, L, dtype, torch.Generator().manual_seed(3)).cuda())[:, None], ref3, "override 3-d")
+        # dropout: repeatable under manual_seed, different on the next call, ~(1 - p) kept (v = ones: out = sum of kept weights / (1 - p))
+        n = len(calls)
+        torch.manual_seed(123)
+        a = patched(q, k, v, dropout_p=0.3, is_causal=True)
+        b = patched(q, k, v, dropout_p=0.3, is_causal=True)
+        torch.manual_seed(123)
+        c = patched(q, k, v, dropout_p=0.3, is_causal=True)
+        assert len(calls) == n + 3 and torch.equal(a, c) and not torch.equal(a, b)
+        ones = torch.ones_like(v)
+        kept = patched(q, k, ones, dropout_p=0.3)[..., 0].float().mean().item()      # E = 1
+        assert abs(kept - 1.0) < 0.02, kept
+        # training through the override with a mask and dropout
+        qg = q.clone().requires_grad_(True)
+        patched(qg, k, v, attn_mask=_masks("bool_padding", B, H, L, dtype, gen).cuda(), dropout_p=0.1).float().square().sum().backward()
+        assert torch.isfinite(qg.grad).all() and qg.grad.abs().max() > 0
+        # not the kernels' business: fp32 operands, head_dim 80, a mask that wants a gradient -> stock SDPA (no raise)
+        n = len(calls)
+        patched(q.float(), k.float(), v.float(), attn_mask=_masks("bool_LL", B, H, L, dtype, gen).cuda())
+        q80 = torch.randn(1, 2, 64, 80, device="cuda", dtype=dtype)
+        patched(q80, q80, q80, dropout_p=0.1)
+        bias = torch.zeros(L, L, device="cuda", dtype=dtype, requires_grad=True)
+        patched(q, k, v, attn_mask=bias).sum().backward()
+        assert bias.grad is not None and len(calls) == n
+        with pytest.raises(RuntimeError):          # torch's own error for attn_mask together with is_causal
+            patched(q, k, v, attn_mask=torch.ones(L, L, dtype=torch.bool, device="cuda"), is_causal=True)
+    finally:
+        ops.attention_extra = real
+    # off the GPU the reference's guards still stand
+    with pytest.raises(NotImplementedError, match="attn_mask"):
+        patched(q.cpu(), k.cpu(), v.cpu(), attn_mask=torch.ones(L, L, dtype=torch.bool))
+    with pytest.raises(NotImplementedError, match="dropout_p"):
+        patched(q.cpu(), k.cpu(), v.cpu(), dropout_p=0.1, is_causal=True)
+
+
+def test_c_abi_reports_what_the_mask_kernels_do_not_take():
+    from flash_attention_amd._impl import _native
+
+    q = torch.randn(1, 2, 64, 64, device="cuda")
+    out = torch.empty_like(q)
+    with pytest.raises(NotImplementedError, match="mask / dropout"):
+        _native.fwd_ex(q, q, q, out, None, 64, 64, 0.125, True, None, 0.5, 1, 2)

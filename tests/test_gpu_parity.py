@@ -184,6 +184,102 @@ def test_split_kv_inside_the_workgroup(knobs, D, split, dtype, scale, G, L):
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 0.125), (torch.float16, 1.0), (torch.float16, 0.125)])
+@pytest.mark.parametrize("G,L", [(3, 129), (2, 256), (9, 384), (2, 1000), (10, 1024), (1, 2049), (17, 640)])
+def test_q_tile_pairs_per_workgroup(knobs, D, dtype, scale, G, L):
+    """fa_fwd_dma_kernel with q-tile pairs (a workgroup runs q tile n-1-i, then i, the second tile's Q rows and first K/V tile
+    requested under the first tile's epilogue): odd tile counts (a middle tile alone), ragged last tiles, two-tile sequences,
+    skip-max and exact-max arithmetic - out and logsumexp against the oracle, and bit for bit against the unpaired kernel (the
+    arithmetic of a row is the same program either way)."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    x = (frozen_randn(SEED + 23 * L + G + D, (3, G, L, D)) * (0.5 if dtype == torch.float16 and scale == 1.0 else 1.0)).to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale)
+    q, k, v = x.cuda()
+    st = (L * D, 0, D)
+    res = {}
+    for pair in (1, 0):
+        knobs.set("kernel", "dma")
+        knobs.set("waves", 4)
+        knobs.set("pair", pair)
+        knobs.set("balance", 0)
+        p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale)
+        nq = (L + 127) // 128
+        assert (p.kernel, p.waves, p.qb, p.block_q, p.pair) == (0, 4, 1, 128, pair)
+        assert p.grid == (G + 7) // 8 * 8 * ((nq + 1) // 2 if pair else nq)
+        out = torch.empty_like(q)
+        lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+        native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, scale)
+        res[pair] = (out, lse)
+    _check(res[1][0], ref, dtype, f"pairs {dtype} scale={scale:.3g} {G}x{L}x{D}")
+    torch.testing.assert_close(res[1][1].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+    assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1]), "paired and unpaired kernels must agree bit for bit"
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("nsplit", [0, 1, 3, 4, 100])
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 0.125), (torch.float16, 1.0)])
+@pytest.mark.parametrize("G,L", [(3, 129), (2, 384), (9, 1000), (10, 1024), (2, 640)])
+def test_mixed_launch_split_and_dual_workgroups(knobs, D, nsplit, dtype, scale, G, L):
+    """MIXED launch of fa_fwd_dma_kernel's 2-group workgroups: the nsplit heaviest q tiles of a group have their kv loop split
+    over the two wave groups (merge through LDS), the other q tiles go two per workgroup, one per wave group (a middle tile
+    alone when their number is odd).  nsplit 0 = dual workgroups only, >= q tiles = split workgroups only; ragged last tiles,
+    skip-max (bf16) and exact-max (unscaled f16) arithmetic: out and logsumexp against the oracle."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    knobs.set("kernel", "dma")
+    knobs.set("waves", 4)
+    knobs.set("nsplit", nsplit)
+    p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale)
+    nq = (L + 127) // 128
+    ns = min(nsplit, nq)
+    assert (p.kernel, p.waves, p.qb, p.block_q, p.nsplit) == (0, 8, 1, 128, nsplit)
+    assert p.grid == (G + 7) // 8 * 8 * (ns + (nq - ns + 1) // 2)
+    x = (frozen_randn(SEED + 31 * L + G + D, (3, G, L, D)) * (0.5 if dtype == torch.float16 and scale == 1.0 else 1.0)).to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale)
+    q, k, v = x.cuda()
+    out = torch.full_like(q, float("nan"))
+    lse = torch.full((G, L), float("nan"), device="cuda", dtype=torch.float32)
+    st = (L * D, 0, D)
+    native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, scale)
+    _check(out, ref, dtype, f"mixed nsplit={nsplit} {dtype} scale={scale:.3g} {G}x{L}x{D}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("G,L,D", [(96, 1024, 64), (40, 1024, 64), (24, 2048, 64), (48, 1024, 128), (96, 1000, 64)])
+def test_placement_balanced_block_order(knobs, G, L, D):
+    """Grids below one round of workgroup slots run their blocks in a placement-balanced order (a permutation of the XCD's
+    slots in the kernel argument block): every (group, q tile) must still be computed exactly once - bit-identical output and
+    logsumexp with the order on and off, and the oracle on sampled groups."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    dtype = torch.bfloat16
+    x = frozen_randn(SEED + 29 * L + G, (3, G, L, D)).to(dtype)
+    q, k, v = x.cuda()
+    st = (L * D, 0, D)
+    res = {}
+    for bal in (1, 0):
+        knobs.set("kernel", "dma")
+        knobs.set("waves", 4)
+        knobs.set("pair", 0)
+        knobs.set("balance", bal)
+        p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=D ** -0.5)
+        assert p.balanced == bal, (p.balanced, p.grid)
+        out = torch.full_like(q, float("nan"))
+        lse = torch.full((G, L), float("nan"), device="cuda", dtype=torch.float32)
+        native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, D ** -0.5)
+        res[bal] = (out, lse)
+    assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1])
+    for g in (0, G // 2, G - 1):
+        ref, ref_lse = _oracle(x[:, g:g + 1], scale=D ** -0.5)
+        _check(res[1][0][g:g + 1], ref, dtype, f"balanced order group {g}")
+        torch.testing.assert_close(res[1][1][g:g + 1].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("qb", [1, 2])
 @pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 64 ** -0.5), (torch.float16, 64 ** -0.5)])
 @pytest.mark.parametrize("G,L", [(2, 32), (3, 100), (2, 257), (2, 1000), (1, 4608), (9, 600), (2, 2049)])
@@ -444,22 +540,31 @@ def test_full_size_properties_config2(knobs, dtype):
         _check(out[gidx:gidx + 1], ref, dtype, f"config2 group {gidx}")
 
 
-def test_long_context_config3_sampled():
-    """BASELINE config 3 shape family (L=32768, D=128): 2 groups, rows sampled against the oracle."""
-    fa, _, _ = _mods()
-    G, L, D = 2, 32768, 128
-    gen = torch.Generator(device="cuda").manual_seed(1)
-    qkv = torch.randn(3, G, L, D, device="cuda", generator=gen).to(torch.bfloat16)
-    out = fa.flash_attention_qkv_packed(qkv, 16, 16)
-    assert torch.equal(out[:, 0], qkv[2, :, 0])
-    rows = torch.tensor([1, 63, 64, 4095, 4096, 20000, 32767], device="cuda")
-    q = qkv[0][:, rows].double()
-    s = q @ qkv[1].double().transpose(1, 2)
-    mask = torch.arange(L, device="cuda")[None, :] > rows[:, None]
-    s = s.masked_fill(mask[None], float("-inf"))
-    ref = torch.softmax(s, dim=-1) @ qkv[2].double()
-    err = (out[:, rows].double() - ref).abs()
-    assert bool((err <= 1e-2 + 1e-2 * ref.abs()).all()), err.max().item()
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_notebook_longest_context_65536(dtype):
+    """The reference's longest demonstrated context (demo/flash-attention-ipu-demo.ipynb:939, :952-963): qkv [3, 8, 65536, 64]
+    fp16 through flash_attention_qkv_packed with num_chunks_q = num_chunks_kv = 64, and its bf16 twin: the whole launch - 1024
+    kv tiles per last row; unscaled fp16 runs the per-tile-max arithmetic, bf16 the pipelined skip-max kernel - row 0, convexity,
+    and the CPU oracle (dense_causal_attention_rows: fa.py:48-53 restricted to sampled rows) with logsumexp on every group."""
+    fa, native, with_lse = _mods()
+    from oracle import dense_causal_attention_rows
+
+    G, L, D = 8, 65536, 64
+    plan = native.plan(G, L, D, dtype, 64, 64)
+    assert plan.kernel in (0, 2, 4) and plan.chunk_q == 1024 and plan.chunk_kv == 1024
+    gen = torch.Generator(device="cuda").manual_seed(65536)
+    qkv = torch.randn(3, G, L, D, device="cuda", generator=gen).to(dtype)
+    out, lse = with_lse(qkv, 64, 64)
+    assert torch.isfinite(out).all() and torch.isfinite(lse).all()
+    assert torch.equal(out[:, 0], qkv[2, :, 0])                             # row 0 sees key 0 only
+    v32 = qkv[2].float()
+    lo, hi = torch.cummin(v32, dim=1).values, torch.cummax(v32, dim=1).values
+    assert bool(((out.float() >= lo - 2e-2) & (out.float() <= hi + 2e-2)).all())   # convexity
+    del v32, lo, hi
+    rows = [1, 63, 64, 1023, 1024, 4097, 16383, 32768, 50001, 65534, 65535]
+    ref, ref_lse = dense_causal_attention_rows(qkv.cpu(), rows)
+    _check(out[:, rows], ref, dtype, f"notebook shape [3,8,65536,64] {dtype}")
+    torch.testing.assert_close(lse[:, rows].cpu().double(), ref_lse, atol=LSE_ATOL if dtype == torch.bfloat16 else 2e-3, rtol=1e-4)
 
 
 def test_long_context_config3_full_groups_vs_oracle_rows():
@@ -648,21 +753,3 @@ def test_graft_entry_smoke_runs():
     import __graft_entry__
 
     __graft_entry__.smoke()
-
-
-def test_bench_short_timed_region_is_not_slower_than_a_long_one():
-    """bench.py's headline must not depend on K: a 20-step timed region (the driver's round-1 setting) against a 200-step one,
-    both after the untimed ramp that carries the device past its one-time stall ~0.5 s after load onset (bench.py --ramp-ms)."""
-    import json
-    import pathlib
-    import subprocess
-    import sys
-
-    root = pathlib.Path(__file__).resolve().parent.parent
-    vals = {}
-    for k in (20, 200):
-        res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", str(k), "--warmup", "5",
-                              "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
-        assert res.returncode == 0, res.stderr[-2000:]
-        vals[k] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])["value"]
-    assert vals[20] >= 0.90 * vals[200], vals      # (850 vs 1030 = 0.83 when the stall lands in the short region)

@@ -43,13 +43,13 @@ def test_library_exports_every_declared_symbol(native):
     lib = native.load_native_library()
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/flash_attention_amd.h but not exported"
-    assert lib.fa_abi_version() == 3
+    assert lib.fa_abi_version() == 4
     assert native.library_path().name == "libflash_attention.so"
 
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 3;}\n')
+    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 4;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
 
 

@@ -117,3 +117,31 @@ def test_lse_definition():
     mask = torch.ones(33, 33, dtype=torch.bool).tril()
     ref = torch.logsumexp(s.masked_fill(~mask, float("-inf")), dim=-1)
     torch.testing.assert_close(lse, ref, atol=1e-10, rtol=0)
+
+
+def test_dropout_generator_restatement_statistics():
+    """oracle/dropout.py restates the kernels' counter-based dropout generator (csrc/fa_extras.h): the keep rate is 1 - p, the
+    decisions of neighbouring rows / keys / groups / offsets are uncorrelated, the function is deterministic and the 65536-window
+    key makes positions beyond 2^16 differ from their low-16-bit aliases."""
+    import numpy as np
+
+    from oracle import dropout_keep, dropout_key0, dropout_threshold
+
+    assert dropout_threshold(0.0) == 0 and dropout_threshold(0.5) == 2 ** 31 and dropout_threshold(0.999999999) == 2 ** 32 - 1
+    assert dropout_key0(1, 2) != dropout_key0(2, 1) != dropout_key0(1, 2 + 2 ** 32)
+    for p in (0.1, 0.5, 0.9):
+        k = dropout_keep(7, 11, range(8), range(512), range(512), p).numpy()
+        n = k.size
+        assert abs(k.mean() - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n) + 1e-4, (p, k.mean())
+        x = k.astype(np.float64) - k.mean()
+        var = (x * x).mean()
+        for a, b in ((x[:, :, :-1], x[:, :, 1:]), (x[:, :-1], x[:, 1:]), (x[:-1], x[1:])):       # neighbours along keys, rows, groups
+            assert abs((a * b).mean() / var) < 5 / np.sqrt(a.size), (p, (a * b).mean() / var)
+        k2 = dropout_keep(7, 12, range(8), range(512), range(512), p).numpy()
+        x2 = k2.astype(np.float64) - k2.mean()
+        assert abs((x * x2).mean() / var) < 5 / np.sqrt(n)                                           # next offset
+        assert np.array_equal(k, dropout_keep(7, 11, range(8), range(512), range(512), p).numpy())
+    lo = dropout_keep(3, 4, [0], range(64), range(64), 0.5).numpy()
+    hi = dropout_keep(3, 4, [0], range(65536, 65536 + 64), range(64), 0.5).numpy()
+    hi2 = dropout_keep(3, 4, [0], range(64), range(65536, 65536 + 64), 0.5).numpy()
+    assert not np.array_equal(lo, hi) and not np.array_equal(lo, hi2) and not np.array_equal(hi, hi2)

@@ -148,32 +148,36 @@ def fuzz(cases, seed, log=print):
           bad += 1
           log(f"MISMATCH backward case {case}: G={G} L={L} D={D} {dt} scale={scale:.3g} causal={causal} max|d|={(gr - want).abs().max().item():.3e} (ref max {want.abs().max().item():.2f})")
   # backward with grouped-query K/V heads (dK / dV of a shared head summed inside the kernels) against oracle autograd
-  ops.GQA_NATIVE_MIN_WORKGROUPS = 0          # (small shapes: force the kernels' own head mapping)
-  for case in range(max(2, cases // 8)):
-      D = rng.choice([64, 128, rng.choice([8, 24, 40, 96])])
-      L = rng.choice([rng.randint(1, 130), rng.randint(1, 420)])
-      B, Hkv, rep = rng.randint(1, 2), rng.randint(1, 3), rng.choice([2, 3, 4])
-      H = Hkv * rep
-      dt = rng.choice([torch.bfloat16, torch.float16, torch.float32])
-      scale = rng.choice([1.0, D ** -0.5])
-      causal = rng.random() < 0.7
-      torch.manual_seed(30_000 + case)
-      q0 = (torch.randn(B, H, L, D) * 0.6).to(dt)
-      k0, v0 = ((torch.randn(B, Hkv, L, D) * 0.6).to(dt) for _ in range(2))
-      g = torch.randn(B, H, L, D).to(dt)
-      qr, kr, vr = (t.double().requires_grad_(True) for t in (q0, k0, v0))
-      ref, _ = dense_attention_lse(qr, kr, vr, scale=scale, causal=causal)
-      ref.backward(g.double())
-      qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
-      ops.attention_gqa(qc, kc, vc, scale, 1, 1, causal).backward(g.cuda())
-      torch.cuda.synchronize()
-      tol = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2, torch.float32: 1e-5}[dt]
-      for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
-          got = got.cpu().double()
-          floor = tol * max(1e-3, want.abs().max().item())
-          if not (bool(torch.isfinite(got).all()) and bool(((got - want).abs() <= floor + 2e-2 * want.abs()).all())):
-              bad += 1
-              log(f"MISMATCH grouped-query backward case {case} {name}: B={B} H={H}/{Hkv} L={L} D={D} {dt} scale={scale:.3g} causal={causal} max|d|={(got - want).abs().max().item():.3e}")
+  saved_gqa_threshold = ops.GQA_NATIVE_MIN_WORKGROUPS
+  ops.GQA_NATIVE_MIN_WORKGROUPS = 0          # (small shapes: force the kernels' own head mapping)   restored below: later tests of the same process must see the product's route selection
+  try:
+    for case in range(max(2, cases // 8)):
+        D = rng.choice([64, 128, rng.choice([8, 24, 40, 96])])
+        L = rng.choice([rng.randint(1, 130), rng.randint(1, 420)])
+        B, Hkv, rep = rng.randint(1, 2), rng.randint(1, 3), rng.choice([2, 3, 4])
+        H = Hkv * rep
+        dt = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+        scale = rng.choice([1.0, D ** -0.5])
+        causal = rng.random() < 0.7
+        torch.manual_seed(30_000 + case)
+        q0 = (torch.randn(B, H, L, D) * 0.6).to(dt)
+        k0, v0 = ((torch.randn(B, Hkv, L, D) * 0.6).to(dt) for _ in range(2))
+        g = torch.randn(B, H, L, D).to(dt)
+        qr, kr, vr = (t.double().requires_grad_(True) for t in (q0, k0, v0))
+        ref, _ = dense_attention_lse(qr, kr, vr, scale=scale, causal=causal)
+        ref.backward(g.double())
+        qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
+        ops.attention_gqa(qc, kc, vc, scale, 1, 1, causal).backward(g.cuda())
+        torch.cuda.synchronize()
+        tol = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2, torch.float32: 1e-5}[dt]
+        for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
+            got = got.cpu().double()
+            floor = tol * max(1e-3, want.abs().max().item())
+            if not (bool(torch.isfinite(got).all()) and bool(((got - want).abs() <= floor + 2e-2 * want.abs()).all())):
+                bad += 1
+                log(f"MISMATCH grouped-query backward case {case} {name}: B={B} H={H}/{Hkv} L={L} D={D} {dt} scale={scale:.3g} causal={causal} max|d|={(got - want).abs().max().item():.3e}")
+  finally:
+      ops.GQA_NATIVE_MIN_WORKGROUPS = saved_gqa_threshold
   return bad, len(variants)
 
 
