@@ -211,11 +211,15 @@ def secondary_attention(name, dev, steps=20, warmup=5, backward=False):
     """One of the other single-GPU configs through the same op (or fa_bwd): value + roofline (kernel-only)."""
     G, L, D, dname, (nq, nk) = CONFIGS[name]
     fn, flops, kname, desc, plan = make_op(name, dev, backward=backward)
-    ms = time_kernel(fn, steps, warmup, ramp_ms=60.0)
+    mean_ms = time_kernel(fn, steps, warmup, ramp_ms=60.0)
     med, mn = per_step_ms(fn, steps)
+    # a secondary record is the MEDIAN step: each one starts from a chip that idled while the previous record's tensors were built,
+    # and ~0.35-0.5 s after load onset the device stalls once for ~40 ms (DESIGN.md 3.8) - a 20-step mean that catches it is off by 2-10x
+    ms = med
     tf = flops / (ms * 1e-3) / 1e12
     rec = {"metric": f"{'bwd' if backward else 'fwd'}_attention_tflops_causal_L{L}_D{D}", "value": round(tf, 2), "unit": "TFLOP/s", "dtype": dname,
            "config": {"workload": desc}, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "median_ms": round(med, 4), "min_ms": round(mn, 4),
+           "mean_ms": round(mean_ms, 4), "value_note": "from the median step (HIP events between consecutive steps)",
            "roofline": roofline_record(tf, ms, kname, name + ("_bwd" if backward else ""), plan, (8 if backward else 4) * G * L * D * 2)}
     if backward:
         rec["flops_convention"] = "5*G*L^2*D (the kernels execute 7: scores are recomputed in both)"
@@ -252,40 +256,22 @@ def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             return model(idx)
 
-    def run(n, instrument):
-        F.scaled_dot_product_attention = timed_sdpa if instrument else patched
+    def run(n, sdpa):
+        """median step time (HIP events between consecutive steps: robust against the device's one-time stall)"""
+        F.scaled_dot_product_attention = sdpa
         try:
             for _ in range(warmup):
                 fwd()
             spans.clear()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(n):
-                fwd()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / n
+            return per_step_ms(fwd, n)[0]
         finally:
             F.scaled_dot_product_attention = patched
 
-    step_ms = run(steps, False)
-    run(steps, True)
-    attn_ms = sum(a.elapsed_time(b) for a, b in spans) / steps
-    F.scaled_dot_product_attention = patched.__wrapped__
-    try:
-        for _ in range(warmup):
-            fwd()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(steps):
-            fwd()
-        e1.record()
-        torch.cuda.synchronize()
-        stock_ms = e0.elapsed_time(e1) / steps
-    finally:
-        F.scaled_dot_product_attention = patched
+    step_ms = run(steps, patched)
+    run(steps, timed_sdpa)
+    per_call = sorted(a.elapsed_time(b) for a, b in spans)
+    attn_ms = layers * per_call[len(per_call) // 2]          # 12 calls per step x the median call
+    stock_ms = run(steps, patched.__wrapped__)
     flops = layers * 2.0 * batch * H * T * T * hs
     tf = flops / (attn_ms * 1e-3) / 1e12
     from flash_attention_amd._impl import _native
@@ -305,8 +291,8 @@ def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
                          "traffic_note": "per attention launch, from the PMC passes of the same call timed alone (secondary.cfg4_attn)",
                          "kernel": f"{kernel_name(plan)} (12 launches per step, "
                          f"[{batch},12,1024,64] head-inner views)", "avg_launch_ms": round(attn_ms / layers, 4),
-                         "avg_launch_note": "HIP events around each of the 12 calls inside the model step (event and launch gaps included; "
-                                            "the same call back to back: secondary.cfg4_attn)",
+                         "avg_launch_note": "median over the HIP-event pairs around each of the 12 calls of every timed step, inside the model step "
+                                            "(event and launch gaps included; the same call back to back: secondary.cfg4_attn)",
                          "algorithmic_bytes": 4 * batch * H * T * hs * 2}}
 
 
@@ -379,13 +365,41 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # FA_BENCH_REHEARSE=1: developer rehearsal of the N>1 control flow on a ONE-GPU box (all ranks on
     # cuda:0, gloo instead of RCCL).  Never set by the driver; the numbers it prints mean nothing.
-    rehearse = os.environ.get("FA_BENCH_REHEARSE") == "1"
+    # FA_BENCH_REHEARSE=cpu: the same control flow with NO GPU at all - CPU tensors of a tiny fp32 config through the op's own CPU
+    # branch (the reference's device dispatch, fa.py:47-53), gloo exchanges, wall-clock "events": what tests/test_distributed.py
+    # runs at world size 2 to check the N > 1 launch path and the JSON line's schema.  Its numbers mean nothing either.
+    rehearse_cpu = os.environ.get("FA_BENCH_REHEARSE") == "cpu"
+    rehearse = os.environ.get("FA_BENCH_REHEARSE") == "1" or rehearse_cpu
     if rehearse:
         local_rank = 0
-    if not torch.cuda.is_available():
-        raise SystemExit(f"bench.py needs a GPU (the HIP path has no fallback) [rank {rank} of {world}]")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if rehearse_cpu:
+        CONFIGS["tiny"] = (4, 64, 16, "f32", (2, 2))
+        CONFIGS["tiny_strong"] = (16, 64, 16, "f32", (2, 2))
+        STRONG.add("tiny_strong")
+        args.config = "tiny_strong" if args.config in STRONG else "tiny"
+        args.no_probes = args.no_secondary = args.no_cpu_baseline = True
+        args.ramp_ms = min(args.ramp_ms, 20.0)
+        dev = torch.device("cpu")
+
+        class Ev:      # wall-clock stand-in for a HIP event
+            def record(self):
+                self.t = time.perf_counter()
+
+            def elapsed_time(self, other):
+                return (other.t - self.t) * 1e3
+
+        def sync():
+            return None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit(f"bench.py needs a GPU (the HIP path has no fallback) [rank {rank} of {world}]")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+        def Ev():
+            return torch.cuda.Event(enable_timing=True)
+
+        sync = torch.cuda.synchronize
     if world > 1:
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -397,7 +411,7 @@ def main():
     from flash_attention_amd.distributed import SlabGather, gather_output
 
     assert _native.library_path() is not None
-    DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+    DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
     Gc, L, D, dname, (nq, nk) = CONFIGS[args.config]
     strong = args.config in STRONG
     if strong and Gc % (world * args.slabs) != 0:
@@ -420,7 +434,7 @@ def main():
         flops_step = op_flops
 
     do_gather = world > 1 and not args.no_gather
-    use_gloo = rehearse
+    use_gloo = rehearse and not rehearse_cpu      # (one-GPU rehearsal: no exchange at all; the CPU rehearsal exchanges CPU tensors over gloo)
     launches_per_step = args.slabs if strong else 1
     kernel_events = []                             # (start, end) per launch inside the timed region (N > 1)
     record = [False]
@@ -430,9 +444,9 @@ def main():
 
         def step(i):
             if record[0]:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = Ev(), Ev()
                 e0.record()
-            out = sg.run(qkv, nq, nk)
+            out = sg.run(qkv, nq, nk, wait=False)      # its last exchanges run under the next step's first kernels
             if record[0]:
                 e1.record()
                 kernel_events.append((e0, e1))
@@ -449,7 +463,7 @@ def main():
             if gathered is not None and pending[b] is not None:
                 pending[b][1].wait()           # buffer b is free again (gather of step i-2 done)
             if record[0]:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = Ev(), Ev()
                 e0.record()
             out = op_fn() if op_fn is not None else fa.flash_attention_qkv_packed(qkv, nq, nk)
             if record[0]:
@@ -469,7 +483,7 @@ def main():
     ramp_info = None
     step(0)                      # first call pays one-off host costs (library load, op registration)
     drain()
-    torch.cuda.synchronize()
+    sync()
     # untimed ramp: bring the chip to its sustained clock.  Every rank must issue the SAME number of steps (each step
     # carries a collective), so with N > 1 the count is agreed first: 3 steps are timed, the slowest rank's time decides.
     if world > 1:
@@ -477,28 +491,28 @@ def main():
         for i in range(3):
             step(i)
         drain()
-        torch.cuda.synchronize()
+        sync()
         est = torch.tensor([(time.perf_counter() - t_est) / 3 * 1e3], dtype=torch.float64, device="cpu" if use_gloo else dev)
         dist.all_reduce(est, op=dist.ReduceOp.MAX)
         n_ramp = int(min(2000, max(1, args.ramp_ms / max(est.item(), 1e-3))))
         for i in range(n_ramp):
             step(i)
             if (i + 1) % 16 == 0:
-                torch.cuda.synchronize()
+                sync()
     else:
         # groups of 16 steps between events: the slowest group stays visible in the JSON line (`ramp`): the idle -> sustained
         # clock transition of the device, including the one-time stall DESIGN.md 3.8 describes, happens here and not in the timed region
         t_ramp = time.perf_counter()
         i_ramp = 0
-        g_ev = [(0.0, torch.cuda.Event(enable_timing=True))]
+        g_ev = [(0.0, Ev())]
         g_ev[0][1].record()
         while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
             step(i_ramp)
             i_ramp += 1
             if i_ramp % 16 == 0:
-                e = torch.cuda.Event(enable_timing=True)
+                e = Ev()
                 e.record()
-                torch.cuda.synchronize()
+                sync()
                 g_ev.append(((time.perf_counter() - t_ramp) * 1e3, e))
         if len(g_ev) > 1:
             durs = [(g_ev[i][1].elapsed_time(g_ev[i + 1][1]) / 16, g_ev[i + 1][0]) for i in range(len(g_ev) - 1)]
@@ -508,27 +522,27 @@ def main():
                          "slowest_group_ms_per_step": round(slow[0], 4), "slowest_group_ended_at_ms": round(slow[1], 1),
                          "first_group_ms_per_step": round(durs[0][0], 4)}
     drain()
-    torch.cuda.synchronize()
+    sync()
     for i in range(args.warmup):
         step(i)
     drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
 
     record[0] = world > 1 and not strong          # per-launch events only where a collective shares the stream
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = Ev(), Ev()
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
         step(i)
     ev1.record()
     drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     record[0] = False
     if kernel_events:      # N > 1, weak: kernel-only = events right around each launch (the waits on gathers sit before them)
@@ -540,8 +554,66 @@ def main():
     if strong and do_gather:
         # kernel-only for the slab pipeline: the same slabs, no gather, a few untimed-region repeats
         sgk = SlabGather(G, L, D, dtype, dev, slabs=args.slabs, gather=False)
-        kernel_ms = time_kernel(lambda: sgk.run(qkv, nq, nk), max(3, args.steps // 4), 2) / args.slabs
+        n_k = max(3, args.steps // 4)
+        sgk.run(qkv, nq, nk)
+        sync()
+        ek0, ek1 = Ev(), Ev()
+        ek0.record()
+        for _ in range(n_k):
+            sgk.run(qkv, nq, nk)
+        ek1.record()
+        sync()
+        kernel_ms = ek0.elapsed_time(ek1) / n_k / args.slabs
         kernel_note = "HIP events over a gather-free repeat of the same slab launches"
+
+    # ---- N > 1: the three ways to move O, measured in THIS launch after the headline (one driver run tells the whole story):
+    # per mode the exchange alone (a fixed shard, no kernel: what the links deliver) and kernel + exchange per step, overlapped the
+    # way the headline overlaps them.  Every rank runs the same sequence; times are the maximum over ranks.
+    gather_modes = None
+    shard_bytes = G * L * D * qkv.element_size() if world > 1 else 0
+    if do_gather and not use_gloo and not strong:
+        from flash_attention_amd.distributed import GATHER_MODES
+
+        gather_modes = {}
+        n_x = max(2, min(args.steps, 10))
+        shard = fa.flash_attention_qkv_packed(qkv, nq, nk)
+        bufs = [torch.empty(world * G, L, D, dtype=dtype, device=dev) for _ in range(2)]
+        for mode in GATHER_MODES:
+            gather_output(shard, out=bufs[0], mode=mode)               # warm-up (connections, first-use setup)
+            sync()
+            dist.barrier()
+            t_x = time.perf_counter()
+            for _ in range(n_x):
+                gather_output(shard, out=bufs[0], mode=mode)
+            sync()
+            x_ms = (time.perf_counter() - t_x) / n_x * 1e3
+            dist.barrier()
+            pend = [None, None]
+            t_s = time.perf_counter()
+            for i in range(n_x):                                        # kernel of step i + 1 over the exchange of step i
+                b = i & 1
+                if pend[b] is not None:
+                    pend[b][1].wait()
+                o_ = fa.flash_attention_qkv_packed(qkv, nq, nk)
+                pend[b] = (o_, gather_output(o_, out=bufs[b], async_op=True, mode=mode)[1])
+            for pb in pend:
+                if pb is not None:
+                    pb[1].wait()
+            sync()
+            s_ms = (time.perf_counter() - t_s) / n_x * 1e3
+            tm = torch.tensor([x_ms, s_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            x_ms, s_ms = tm[0].item(), tm[1].item()
+            recv = (world - 1) * shard_bytes if mode != "root" else (world - 1) * shard_bytes       # the busiest rank's receive volume
+            gather_modes[mode] = {
+                "exchange_only_ms": round(x_ms, 4), "ms_per_step": round(s_ms, 4),
+                "value_tflops": round(world * flops_step / (s_ms * 1e-3) / 1e12, 2),
+                "received_bytes_busiest_rank": recv,
+                "achieved_GBps_per_link": round(shard_bytes / (x_ms * 1e-3) / 1e9, 2),
+                "note": "one shard per link and direction when every pair of GPUs has its own xGMI link (direct, root); a ring all-gather "
+                        "forwards W-1 shards over each link, so its per-link rate is (W-1) x this figure" if mode != "allgather" else
+                        "per-link figure = shard bytes / exchange time (what a direct exchange would need); the library's own algorithm decides what the links carry",
+            }
 
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1 and not use_gloo:
@@ -580,7 +652,7 @@ def main():
                 probe_fn()
                 if i == 8:                                                          # the load is running: start sampling
                     lib_.fa_probe_clock(buf.data_ptr(), 15000, side.cuda_stream)   # ~30-40 ms
-            torch.cuda.synchronize()
+            sync()
             cyc, ticks = (int(x) for x in buf.tolist())
             clock_mhz = round(cyc / ticks * 100.0) if ticks > 0 else None
 
@@ -617,9 +689,13 @@ def main():
                        "plan_source": {0: "built-in rules", 1: "measured tuning table", 2: "debug override"}.get(plan.source),
                        "exchange": exchange,
                        "flops_per_step_per_gpu": flops_step,
-                       "device": {"name": torch.cuda.get_device_name(dev),
+                       "device": {"name": "cpu (FA_BENCH_REHEARSE=cpu: numbers are meaningless)"} if rehearse_cpu else
+                                 {"name": torch.cuda.get_device_name(dev),
                                   "compute_units": torch.cuda.get_device_properties(dev).multi_processor_count,
                                   "clock_mhz": getattr(torch.cuda.get_device_properties(dev), "clock_rate", 0) // 1000 or None}},
+            "exchange_bytes_per_rank": {"sent": shard_bytes if do_gather else 0,
+                                        "received": ((world - 1) * shard_bytes if args.gather != "root" or rank == 0 else 0) if do_gather else 0,
+                                        "note": "per step; with --gather root only rank 0 receives"} if world > 1 else None,
             "pct_mfma_peak": round(100.0 * total_tflops / (world * PEAK_TFLOPS), 2),
             "kernel_only_value": round(world * achieved, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -637,6 +713,8 @@ def main():
                          "flops_per_launch": flops_launch,
                          "algorithmic_bytes": 4 * g_launch * L * D * 2},
         }
+        if gather_modes is not None:
+            line["secondary"] = {"gather_modes": gather_modes}
         if world == 1 and not args.no_secondary and not strong:
             sec = {}
             for name in ("cfg3", "cfg5_shard", "small_grid", "l1024", "cfg4_attn", "nb_65536"):

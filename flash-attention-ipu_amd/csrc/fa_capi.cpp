@@ -47,7 +47,6 @@ struct Options {
     std::atomic<int> split{0};      // 0 auto, 1 | 2 | 4 kv split groups per workgroup (fa_fwd_dma.hip)
     std::atomic<int> pair{-1};      // -1 auto, 0 | 1 q-tile pairs per workgroup (fa_fwd_dma.hip, causal)
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
-    std::atomic<int> nsplit{-1};    // -1 auto, n >= 0: MIXED launch of 2-group workgroups with the n heaviest q tiles of a group split (fa_fwd_dma.hip)
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -73,7 +72,6 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_TABLE")) { if (*e) g_opt.table = atoi(e); }
         if (const char* e = getenv("FA_AMD_PAIR")) { if (*e) g_opt.pair = atoi(e); }
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
-        if (const char* e = getenv("FA_AMD_NSPLIT")) { if (*e) g_opt.nsplit = atoi(e); }
     });
     return g_opt;
 }
@@ -116,7 +114,6 @@ struct Selection {
     char which;      // 'd' | 'p' | 't' | 'g' generic | 'f' fp32 MFMA
     int split;       // kv split groups per workgroup ('d' only; plan.waves counts all of the workgroup's waves)
     int pair;        // 'd' only: 1 = a workgroup owns q tiles (nq - 1 - i) and i, one after the other
-    int nsplit;      // 'd' with split 2 only: >= 0 = MIXED launch, that many of a group's heaviest q tiles are split, the rest go two per workgroup
     int perm_n;      // 'd' only: > 0 = placement-balanced order of the XCD's first perm_n slots
     uint8_t perm[128];
 };
@@ -169,7 +166,6 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     sel->split = 1;
     sel->pair = 0;
     sel->perm_n = 0;
-    sel->nsplit = -1;
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
     const int64_t g8 = (G + 7) / 8 * 8;
@@ -185,7 +181,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         const bool pipe_ok = skip != 0;                   // (the pipelined kernels implement the skip-max arithmetic only)
         const bool want32 = ck < 64;                      // a kv chunk below 64 keys is served by 32-key steps
         char which = 'd';
-        int waves = wmax, qb = 1, sched = 0, source = 0, split = 1;
+        int waves = wmax, qb = 1, sched = 0, source = 0, split = 1, table_pair = 0;
         // ---- built-in rules (round-1 measurements)
         const int64_t wgs256 = g8 * ((L + 255) / 256);
         if (D == 64 && pipe_ok && waves == 4 && cq >= 256 && L >= 4096 && wgs256 >= 1024) { which = 'p'; qb = 2; }
@@ -203,13 +199,14 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
                 if (r.kernel == 'x' && D == 64 && r.waves != 4) continue;
                 which = r.kernel; waves = r.waves; qb = r.qb; sched = r.sched; source = 1;
                 split = r.split > 1 ? r.split : 1;
+                table_pair = r.pair;
                 break;
             }
         }
         // ---- debug overrides
         const int fk = opt.kernel, fw = opt.waves, fq = opt.qb, fs = opt.split;
         if (fk || fw || fq || fs || opt.sched > 0 || (dtype == FA_DTYPE_F16 && opt.skipmax >= 0)) source = 2;
-        if (fk || fw || fq) split = 1;                     // (a forced tile drops the table's split unless split is forced too)
+        if (fk || fw || fq) { split = 1; table_pair = 0; } // (a forced tile drops the table's split / pairs unless forced too)
         if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
         if (fk == 't') { which = 't'; qb = 1; }
         else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
@@ -237,22 +234,15 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
             // (L <= 2048) and the paired grid still fills at least one round of the chip's slots
             // measured (profiles/r03_short/sweep_*.txt): pairs LOSE 2..10 % at L = 1024 .. 4096 (4 resident workgroups per CU already hide each
             // other's prologues; the pair's second tile waits for the first tile's stores at its first barrier) - built-in rule: off
+            if (table_pair && pair_ok && source == 1) pair = 1;          // (a measured row may switch them on)
             if (opt.pair >= 0) { pair = (opt.pair != 0 && pair_ok) ? 1 : 0; source = 2; }
         }
         sel->pair = pair;
-        // MIXED launch (fa_fwd_dma.hip): 8-wave workgroups, the heaviest q tiles split, the others two per workgroup
-        if (which == 'd' && causal && waves == 4 && qb == 1 && !pair && (split == 1 || split == 2)) {
-            int ns = -1;
-            if (opt.nsplit >= 0) { ns = opt.nsplit; source = 2; }
-            if (ns >= 0) { split = 2; sel->nsplit = ns; }
-        }
         sel->perm_n = 0;
-        if (which == 'd' && causal && !pair && qb == 1 && waves == 4 && (split == 1 || (split == 2 && sel->nsplit >= 0)) && opt.balance != 0) {
+        if (which == 'd' && causal && !pair && qb == 1 && waves == 4 && split == 1 && opt.balance != 0) {
             const int64_t nqt = (L + 32 * waves - 1) / (32 * waves), ng = g8 / 8;
-            const bool mixed = split == 2;
-            const int64_t ns = mixed ? (sel->nsplit < nqt ? sel->nsplit : nqt) : 0;
-            const int64_t nitem = mixed ? ns + (nqt - ns + 1) / 2 : nqt;                       // workgroups per group
-            const int64_t slots_per_xcd = (D == 64 ? 4 : 2) * kCusPerXcd / (mixed ? 2 : 1);    // resident workgroups per XCD
+            const int64_t nitem = nqt;                                                          // workgroups per group
+            const int64_t slots_per_xcd = (D == 64 ? 4 : 2) * kCusPerXcd;                       // resident workgroups per XCD
             if (ng * nitem <= slots_per_xcd && ng * nitem <= 128) {
                 int bunch_sz = (int)((8ll << 20) / (2 * L * D * es));
                 if (sched > 0) bunch_sz = sched;
@@ -265,9 +255,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
                     const int per_bunch = bunch_sz * (int)nitem, b_ = s_ / per_bunch, rem = s_ - b_ * per_bunch;
                     const int g0 = b_ * bunch_sz, bc = (ng - g0) < bunch_sz ? (int)(ng - g0) : bunch_sz;
                     const int64_t qd = rem / bc;
-                    if (!mixed) weight[s_] = tiles_of(nqt - 1 - qd);
-                    else if (qd < ns) weight[s_] = (tiles_of(nqt - 1 - qd) + 1) / 2;              // split: half the kv tiles per wave group
-                    else weight[s_] = tiles_of(nqt - ns - 1 - (qd - ns));                         // dual: as long as its heavier q tile
+                    weight[s_] = tiles_of(nqt - 1 - qd);
                 }
                 sel->perm_n = balanced_order((int)(ng * nitem), weight, sel->perm);
             }
@@ -283,11 +271,6 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         plan->source = source;
         plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
         if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
-        plan->nsplit = sel->nsplit;
-        if (sel->nsplit >= 0) {
-            const int64_t nqt = (L + plan->block_q - 1) / plan->block_q, ns = sel->nsplit < nqt ? sel->nsplit : nqt;
-            plan->grid = g8 * (ns + (nqt - ns + 1) / 2);
-        }
         plan->lds_bytes = which == 'x' ? 8 * 32 * D * 2 + 16
                           : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
                                        : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
@@ -342,7 +325,7 @@ const OptionName kOptionNames[] = {
     {"kernel", &Options::kernel, 0, 127}, {"qb", &Options::qb, 0, 2}, {"waves", &Options::waves, 0, 8},
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
-    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"nsplit", &Options::nsplit, -1, 1 << 20},
+    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1},
 };
 
 }  // namespace
@@ -541,7 +524,6 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.skipmax = plan.skipmax;
-    p.nsplit = sel.nsplit;
     p.perm_n = sel.perm_n;
     if (sel.perm_n > 0) memcpy(p.perm, sel.perm, sizeof(p.perm));
     p.stamps = nullptr;
@@ -549,7 +531,7 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
         if (plan.grid * plan.waves * 16 * 8 <= g_stamp_bytes.load()) p.stamps = static_cast<unsigned long long*>(sb);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (extra) { p.nsplit = -1; p.perm_n = 0; p.skipmax = 0; }
+    if (extra) { p.perm_n = 0; p.skipmax = 0; }
     hipError_t e = extra              ? fa::launch_fwd_extra(p, dtype, st)
                    : sel.which == 'g' ? fa::launch_fwd_generic(p, dtype, st)
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)

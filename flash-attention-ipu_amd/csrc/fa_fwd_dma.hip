@@ -37,13 +37,6 @@ namespace fa {
 // loop of a q tile, the critical path of a launch with fewer workgroups than slots, shrinks SPLIT-fold with no second
 // kernel and no partial results in HBM.
 //
-// MIXED (SPLIT == 2, p.nsplit >= 0; causal grids of about one round of slots, e.g. GPT-2 small's attention call): such a launch lasts
-// as long as its heaviest workgroup's serial chain of kv tiles (profiles/r03_cfg4: 16 tiles x ~0.95 us, whatever else the CU holds),
-// so only the heaviest q tiles want their kv loop split - splitting all of them doubles the launch's waves past one round of slots.
-// The 8-wave workgroups of one launch then come in two kinds: the p.nsplit heaviest q tiles of a group are split as above; the
-// others are taken two per workgroup, wave group 0 on the heavier and wave group 1 on the lighter one ("dual": private K/V buffers
-// as before, but each group streams EVERY kv tile of ITS q tile, no merge, both groups run the epilogue).
-//
 // PAIR (causal, SPLIT == 1, QB == 1): the workgroup owns TWO q tiles, (nq - 1 - i) then i, one after the other.  Every workgroup
 // of a group then streams the same number of kv tiles (nq + 1 of 128-row q tiles: no light and heavy workgroups, no tail), the
 // dispatcher refills half as many slots, and the second tile's prologue disappears: its Q rows and its first K/V tile are requested
@@ -78,8 +71,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 
     static_assert(!PAIR || (SPLIT == 1 && QB == 1), "q-tile pairs: unsplit workgroups with one query block per wave");
     const int nq = p.nq_tiles;
-    const int nsplit = (SPLIT == 2 && p.nsplit >= 0) ? (p.nsplit < nq ? p.nsplit : nq) : -1;   // MIXED: q tiles nq-1 .. nq-nsplit are split
-    const int nslot = PAIR ? (nq + 1) >> 1 : nsplit >= 0 ? nsplit + ((nq - nsplit + 1) >> 1) : nq;      // workgroups per group
+    const int nslot = PAIR ? (nq + 1) >> 1 : nq;      // workgroups per group
     int g, qd;
     {
         int b = blockIdx.x;
@@ -113,9 +105,8 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base -> M0)
     const int ws = SPLIT == 1 ? 0 : wave_all / NWAVES;               // kv split group of this wave
     const int wave = SPLIT == 1 ? wave_all : wave_all - ws * NWAVES; // its row block inside the group
-    const bool dual = nsplit >= 0 && qd >= nsplit;                   // MIXED: this workgroup's two wave groups own two different q tiles
-    const int tfirst = (SPLIT == 1 || dual) ? 0 : ws;                // the group's first kv tile ...
-    const int tstride = (SPLIT == 1 || dual) ? 1 : SPLIT;            // ... and the distance to its next one
+    constexpr int tstride = SPLIT;                                   // a wave group streams the kv tiles ws, ws + SPLIT, ...
+    const int tfirst = ws;
     unsigned char* const smem = smem_all + ws * GROUP_B;
     unsigned char* const smem_v = smem + 2 * KTILE_B;
     const int r = lane & 31, h = lane >> 5;
@@ -379,32 +370,15 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
 #pragma nounroll
     for (int pass = 0; pass < n_pass; ++pass) {
-    // the q tile of this wave: unsplit / split workgroups: nq-1-qd (heaviest first); pairs: then qd; MIXED dual workgroups: the
-    // q tiles below the split ones, wave group 0 the heavier (nrem-1-k), wave group 1 the lighter (k) - none if they coincide
-    int qi = pass == 0 ? nq - 1 - qd : qd;
-    bool group_idle = false;
-    int n_rounds_other = 0;                      // MIXED dual: kv tiles of the OTHER wave group's q tile
-    if constexpr (SPLIT == 2) {
-        if (dual) {
-            const int k_ = qd - nsplit, nrem = nq - nsplit;
-            const int qa = nrem - 1 - k_, qb_ = k_;
-            qi = ws == 0 ? qa : qb_;
-            group_idle = ws == 1 && qa == qb_;
-            const int qo = ws == 0 ? qb_ : qa;
-            const int ke_o = (causal && (qo + 1) * BQ < L) ? (qo + 1) * BQ : L;
-            n_rounds_other = (ws == 0 && qa == qb_) ? 0 : (ke_o + BK - 1) / BK;
-        }
-    }
+    const int qi = pass == 0 ? nq - 1 - qd : qd;     // heaviest first; pairs: then the light partner
     const int q_row0 = qi * BQ + wave * WQ;
     const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
-    const bool wave_active = q_row0 < L && !group_idle;
+    const bool wave_active = q_row0 < L;
     // causal: keys up to the workgroup's last row; otherwise every key.  `klim`: the last key a row may see is
     // min(row, L - 1) under the causal mask and L - 1 without it (rows past L are clamped duplicates, never stored)
     const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
-    const int n_tiles = group_idle ? 0 : (kv_end + BK - 1) / BK;
-    // rounds of the workgroup's lock-step loop (uniform over ALL its waves): every group must see its last tile
-    const int n_rounds = (SPLIT == 1) ? n_tiles : dual ? (n_tiles > n_rounds_other ? n_tiles : n_rounds_other)
-                                                       : (n_tiles + SPLIT - 1) / SPLIT;
+    const int n_tiles = (kv_end + BK - 1) / BK;
+    const int n_rounds = (n_tiles + SPLIT - 1) / SPLIT;   // rounds of the workgroup's lock-step loop (uniform over all its waves)
     const int wave_last = causal ? q_row0 : L - 1;      // a tile reaching past this key carries a mask for the wave
     const int wave_kv_last = causal ? q_row0 + WQ - 1 : L - 1;   // tiles starting after it hold nothing for the wave
     FA_RESET_STATE()
@@ -453,7 +427,6 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // [value][lane], so writes and reads are conflict-free.  A group that saw no key of a row hands over m = -inf, l = 0,
     // O = 0: its weight 2^((m - m_new) c) is 0.
     if constexpr (SPLIT > 1) {
-    if (!dual) {
         constexpr int NVAL = QB * (DT * 16 + 2);
         float* xb = (float*)(smem_all + NWAVES * WQ * ROWB) + wave * (NVAL * 64) + lane;
         static_assert(NWAVES * WQ * ROWB + NWAVES * NVAL * 64 * 4 <= SPLIT * GROUP_B, "exchange area must fit the K/V buffers");
@@ -491,16 +464,14 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         }
         if (ws != 0) return;
     }
-    }
     // ---- epilogue: O /= l, staged through LDS so that every store instruction writes whole rows.
     // (A lane owns 8-byte pieces of ONE row at a 16-byte pitch; stored directly, one instruction touches
     // 32 rows x 2 pieces.)  The K buffers are free after the last barrier; each wave uses a private
     // 32-row slab [32][D] with the 16-byte chunk index XORed by the row, so writes and reads are
     // conflict-free and no workgroup barrier is needed.
     // Pairs: the slabs live in the K1 / V1 buffers (two waves each), K0 / V0 are receiving the next q tile's first K/V tile.
-    // (split workgroups: only wave group 0 gets here, smem == smem_all; dual workgroups: each group in its own buffers)
     unsigned char* slab = PAIR ? smem_all + (wave < 2 ? KTILE_B + wave * (WQ * ROWB) : 2 * KTILE_B + VTILE_B + (wave - 2) * (WQ * ROWB))
-                               : smem + wave * (WQ * ROWB);
+                               : smem_all + wave * (WQ * ROWB);
     static_assert(!PAIR || (NWAVES <= 4 && 2 * WQ * ROWB <= KTILE_B && 2 * WQ * ROWB <= VTILE_B), "pair epilogue slabs must fit K1 / V1");
     constexpr int CPR = D / 8;   // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;   // rows per store instruction (8 at D=64, 4 at D=128)
@@ -583,14 +554,7 @@ static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, int split,
         return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 1, true>), dim3((unsigned)pgrid), dim3(256), 0, stream, p);
     }
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
-    if (split == 2) {
-        int64_t g2 = grid;
-        if (p.nsplit >= 0) {   // MIXED: nsplit split workgroups + the other q tiles two per workgroup
-            const int ns = p.nsplit < p.nq_tiles ? p.nsplit : p.nq_tiles;
-            g2 = (int64_t)p.G8 * (ns + (p.nq_tiles - ns + 1) / 2);
-        }
-        return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 2>), dim3((unsigned)g2), dim3(512), 0, stream, p);
-    }
+    if (split == 2) return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 2>), dim3((unsigned)grid), dim3(512), 0, stream, p);
     if (split == 4) {   // 16 waves = 4 per SIMD: needs the 128-register kernel (head_dim 64)
         if constexpr (D == 64) {
             return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 4>), dim3((unsigned)grid), dim3(1024), 0, stream, p);

@@ -43,7 +43,6 @@ struct FwdParams {
     float scale;           // softmax scale
     float scale_log2;      // scale * log2(e)
     ExtraParams ex;
-    int32_t nsplit;        // >= 0 (2 kv split groups only): MIXED launch - the nsplit heaviest q tiles of a group are split, the others go two per workgroup
     int32_t perm_n;        // > 0: the first perm_n slots of every XCD run the work item perm[slot] (fa_fwd_dma.hip; fa_capi.cpp balanced_order)
     uint8_t perm[128];
     unsigned long long* stamps;   // measurement builds only (-DFA_STAMPS, scripts/phase_times.py): 16 u64 per wave, else null

@@ -102,7 +102,14 @@ class SlabGather:
     Ownership is slab-cyclic so that the gathered buffer IS the global group order: with Gs = G_local / slabs
     groups per slab, global group g belongs to rank (g // Gs) % W, slab g // (Gs * W); the gathered tensor is
     [slabs * W * Gs, L, D] = [G, L, D].  (Groups are independent - FA.cpp:186 - so any partition is valid.)
-    Buffers are allocated once; `run` may be called repeatedly (a step of bench.py)."""
+    Buffers are allocated once; `run` may be called repeatedly (a step of bench.py).
+
+    Stream contract: the kernels run on the caller's current stream, the exchanges on the backend's.  `run()` by default makes
+    the current stream wait for every exchange it started before it returns (`Work.wait()` on an RCCL work orders the CURRENT
+    STREAM behind the collective; it does not block the host), so whatever the caller enqueues next on that stream sees the
+    complete result.  `run(wait=False)` returns while the last exchanges are still in flight - for a caller that overlaps them
+    with its own next kernels (bench.py) - and the result must then not be read before `wait()`.  The gathered result lives in one
+    of TWO buffers used alternately: a tensor returned by `run` stays valid until the run after the next one starts."""
 
     def __init__(self, groups_local: int, L: int, D: int, dtype, device, slabs: int = 4, group=None,
                  mode: str = "allgather", gather: bool = True):
@@ -113,7 +120,8 @@ class SlabGather:
         self.gather = gather and self.world > 1
         self.gs = groups_local // slabs
         self.local = torch.empty((slabs, self.gs, L, D), dtype=dtype, device=device)
-        self.full = torch.empty((slabs, self.world * self.gs, L, D), dtype=dtype, device=device) if self.gather else None
+        self.fulls = [torch.empty((slabs, self.world * self.gs, L, D), dtype=dtype, device=device) for _ in range(2)] if self.gather else None
+        self.turn = 0
         self.pending = [None] * slabs
 
     def owned_groups(self, rank: int) -> torch.Tensor:
@@ -122,11 +130,13 @@ class SlabGather:
         i = torch.arange(self.gs)[None, :]
         return ((s * self.world + rank) * self.gs + i).reshape(-1)
 
-    def run(self, qkv_local: torch.Tensor, num_chunks_q: int, num_chunks_kv: int) -> torch.Tensor:
+    def run(self, qkv_local: torch.Tensor, num_chunks_q: int, num_chunks_kv: int, wait: bool = True) -> torch.Tensor:
         """qkv_local: contiguous [3, G_local, L, D] on this rank's GPU.  Returns [G, L, D] (every rank, or rank 0
-        with mode "root"), or this rank's [G_local, L, D] when there is nothing to gather.  The kernels are
-        enqueued on the current stream, the exchanges on the backend's; the caller synchronises (or calls wait())."""
+        with mode "root"), or this rank's [G_local, L, D] when there is nothing to gather.  See the class docstring for
+        the stream contract (`wait`)."""
         _, gl, L, D = qkv_local.shape
+        full = self.fulls[self.turn] if self.gather else None
+        self.turn ^= 1
         gs = self.gs
         q, k, v = qkv_local[0], qkv_local[1], qkv_local[2]
         st = (L * D, 0, D)
@@ -141,9 +151,11 @@ class SlabGather:
             else:                   # CPU tensors: the op's own CPU branch (fa.py:47-53), as in the packed op
                 self.local[s].copy_(flash_attention_qkv_packed(qkv_local[:, sl], num_chunks_q, num_chunks_kv))
             if self.gather:
-                _, self.pending[s] = gather_output(self.local[s], group=self.group, out=self.full[s], async_op=True,
+                _, self.pending[s] = gather_output(self.local[s], group=self.group, out=full[s], async_op=True,
                                                    mode=self.mode)
-        return self.full.view(-1, L, D) if self.gather else self.local.view(gl, L, D)
+        if wait:
+            self.wait()
+        return full.view(-1, L, D) if self.gather else self.local.view(gl, L, D)
 
     def wait(self):
         for s in range(self.slabs):

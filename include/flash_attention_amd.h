@@ -95,8 +95,6 @@ typedef struct fa_plan_t {
     int32_t source;      /* 0 = built-in rules, 1 = a row of the measured tuning table (fa_tuning_table.h),
                             2 = a debug override was in force (fa_debug_set_option / FA_AMD_* at load) */
     int32_t pair;        /* 1 = a workgroup owns two q tiles, (n - 1 - i) then i, one after the other (causal, 64-key tiles) [ABI 4] */
-    int32_t nsplit;      /* >= 0: MIXED launch of 2-group workgroups - that many of a group's heaviest q tiles have their kv loop split, the
-                            others go two per workgroup, one per wave group (causal grids of about one round of slots); -1 otherwise [ABI 4] */
     int32_t balanced;    /* 1 = placement-balanced block order (a causal grid below one round of the chip's workgroup slots) [ABI 4] */
 } fa_plan_t;
 
@@ -144,7 +142,6 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  *   "split"   0 auto | 1 | 2 | 4    kv split groups per workgroup ('d' kernel, 4 waves x 32 rows per group)
  *   "pair"    -1 auto | 0 | 1       q-tile pairs (n - 1 - i, i) per workgroup ('d' kernel, causal, 4 waves)
  *   "balance" -1 auto | 0 | 1       placement-balanced block order of a causal grid below one round of workgroup slots
- *   "nsplit"  -1 auto | n >= 0      MIXED launch ('d' kernel, 2 wave groups per workgroup) with the n heaviest q tiles of a group split
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
 int fa_debug_set_option(const char* name, int32_t value);
 int fa_debug_get_option(const char* name, int32_t* value);

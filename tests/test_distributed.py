@@ -55,10 +55,12 @@ def _worker(rank, world, port, G, L, D, q):
         for mode in ("allgather", "direct"):
             sg = SlabGather(G // world, L, D, torch.float32, "cpu", slabs=G // world, mode=mode)
             mine = sg.owned_groups(rank)
-            for _ in range(2):    # twice: the second call waits for the first call's exchanges per slab
-                got = sg.run(qkv[:, mine].contiguous(), 2, 2)
+            first = sg.run(qkv[:, mine].contiguous(), 2, 2)                  # (default: complete on return)
+            ok = ok and torch.allclose(first, ref, atol=1e-6)
+            got = sg.run(qkv[:, mine].contiguous(), 2, 2, wait=False)      # second call: waits for the first call's exchanges per slab
             sg.wait()
             ok = ok and got.shape == (G, L, D) and torch.allclose(got, ref, atol=1e-6)
+            ok = ok and got.data_ptr() != first.data_ptr() and torch.allclose(first, ref, atol=1e-6)   # two result buffers, used alternately
         owners = torch.cat([SlabGather(G // world, L, D, torch.float32, "cpu", slabs=G // world).owned_groups(r) for r in range(world)])
         ok = ok and sorted(owners.tolist()) == list(range(G))
         q.put((rank, bool(ok)))
@@ -107,3 +109,38 @@ def test_bench_self_launches_rank_processes_before_touching_the_gpu():
     # (the launcher stops the surviving rank as soon as the first one fails, so at least one of them reports)
     assert "bench.py needs a GPU" in res.stderr and " of 2]" in res.stderr, res.stderr[-2000:]
     assert "but WORLD_SIZE" not in res.stderr
+
+
+@pytest.mark.parametrize("config,extra", [("cfg2", []), ("cfg2", ["--gather", "direct"]), ("cfg5", ["--slabs", "2"])])
+def test_bench_n2_control_flow_and_json_schema_on_cpu(config, extra):
+    """`FA_BENCH_REHEARSE=cpu python bench.py --gpus 2`: the WHOLE N > 1 path of the benchmark with no GPU - self-launch of the two
+    rank processes, gloo process group, agreed ramp step count, double-buffered exchange under the next step's op (weak) or slab
+    pipeline (strong), max-over-ranks timing, rank 0's one JSON line - on CPU tensors of a tiny config through the op's own CPU
+    branch.  Checks the launch path and the line's schema (incl. the all-gather / direct / root comparison measured in the same
+    launch); the numbers mean nothing."""
+    import json
+    import pathlib
+    import subprocess
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FA_BENCH_REHEARSE"] = "cpu"
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", config] + extra,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]           # rank 0 alone prints
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "kernel_only_value", "exchange_bytes_per_rank"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["value"] >= 0 and line["ms_per_step"] > 0
+    assert line["scaling"] == ("strong" if config == "cfg5" else "weak")
+    assert line["kernel_only_value"] >= 0 and line["roofline"]["avg_launch_ms"] > 0
+    assert line["exchange_bytes_per_rank"]["sent"] > 0 and line["exchange_bytes_per_rank"]["received"] > 0
+    assert "workload" in line["config"] and "exchange" in line["config"]
+    if config != "cfg5":
+        modes = line["secondary"]["gather_modes"]
+        assert set(modes) == {"allgather", "direct", "root"}
+        for m in modes.values():
+            assert m["exchange_only_ms"] > 0 and m["ms_per_step"] > 0 and m["achieved_GBps_per_link"] >= 0 and m["value_tflops"] >= 0

@@ -218,37 +218,6 @@ def test_q_tile_pairs_per_workgroup(knobs, D, dtype, scale, G, L):
     assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1]), "paired and unpaired kernels must agree bit for bit"
 
 
-@pytest.mark.parametrize("D", [64, 128])
-@pytest.mark.parametrize("nsplit", [0, 1, 3, 4, 100])
-@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 0.125), (torch.float16, 1.0)])
-@pytest.mark.parametrize("G,L", [(3, 129), (2, 384), (9, 1000), (10, 1024), (2, 640)])
-def test_mixed_launch_split_and_dual_workgroups(knobs, D, nsplit, dtype, scale, G, L):
-    """MIXED launch of fa_fwd_dma_kernel's 2-group workgroups: the nsplit heaviest q tiles of a group have their kv loop split
-    over the two wave groups (merge through LDS), the other q tiles go two per workgroup, one per wave group (a middle tile
-    alone when their number is odd).  nsplit 0 = dual workgroups only, >= q tiles = split workgroups only; ragged last tiles,
-    skip-max (bf16) and exact-max (unscaled f16) arithmetic: out and logsumexp against the oracle."""
-    _, native, _ = _mods()
-    from oracle import frozen_randn
-
-    knobs.set("kernel", "dma")
-    knobs.set("waves", 4)
-    knobs.set("nsplit", nsplit)
-    p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale)
-    nq = (L + 127) // 128
-    ns = min(nsplit, nq)
-    assert (p.kernel, p.waves, p.qb, p.block_q, p.nsplit) == (0, 8, 1, 128, nsplit)
-    assert p.grid == (G + 7) // 8 * 8 * (ns + (nq - ns + 1) // 2)
-    x = (frozen_randn(SEED + 31 * L + G + D, (3, G, L, D)) * (0.5 if dtype == torch.float16 and scale == 1.0 else 1.0)).to(dtype)
-    ref, ref_lse = _oracle(x, scale=scale)
-    q, k, v = x.cuda()
-    out = torch.full_like(q, float("nan"))
-    lse = torch.full((G, L), float("nan"), device="cuda", dtype=torch.float32)
-    st = (L * D, 0, D)
-    native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, scale)
-    _check(out, ref, dtype, f"mixed nsplit={nsplit} {dtype} scale={scale:.3g} {G}x{L}x{D}")
-    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
-
-
 @pytest.mark.parametrize("G,L,D", [(96, 1024, 64), (40, 1024, 64), (24, 2048, 64), (48, 1024, 128), (96, 1000, 64)])
 def test_placement_balanced_block_order(knobs, G, L, D):
     """Grids below one round of workgroup slots run their blocks in a placement-balanced order (a permutation of the XCD's
