@@ -110,6 +110,20 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned lds_base, unsi
         : "s"(lds_base), "v"(voffset), "s"(rsrc)
         : "memory");
 }
+// the same without saving / restoring M0 around the load (two scalar instructions fewer per piece: the software-pipelined kernels
+// are bound by instruction issue).  M0 is a RESERVED register for hipcc on gfx9 ("inline asm clobber list contains
+// reserved registers: m0" if named as a clobber): the register allocator never holds a value in it, and the compiler's own users of
+// M0 (movrel, sendmsg, its LDS-DMA builtin - none of them in these kernels) load it immediately in front of the instruction that
+// reads it, so nothing can depend on M0 surviving this statement; gfx9 LDS instructions do not read M0.
+__device__ __forceinline__ void lds_dma_b128_m0(i32x4 rsrc, unsigned lds_base, unsigned voffset) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, 0 offen lds"
+        :
+        : "s"(lds_base), "v"(voffset), "s"(rsrc)
+        : "memory");
+}
 __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_offset(const void* p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;

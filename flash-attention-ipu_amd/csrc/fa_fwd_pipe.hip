@@ -57,8 +57,19 @@
 #ifndef FA_PIPE_PVFIRST
 #define FA_PIPE_PVFIRST 1
 #endif
+// The step barrier.  __syncthreads() is fence + s_barrier + fence: hipcc puts `s_waitcnt lgkmcnt(0)` in front of the s_barrier, which
+// drains the NEXT step's V^T fragment reads that the hand-ordered step requests near its end so that they fly across the barrier.
+// A bare s_barrier would be enough here (the DMA'd slots' visibility rests on the issuing wave's own vmcnt wait; the slots a DMA
+// issued after this barrier overwrites were last read a full step earlier, reads still in flight are of slots overwritten two
+// barriers later) and -DFA_PIPE_BARE_BARRIER=1 builds it; measured in-process (profiles/r03_step_anatomy): +-0.5 % at every
+// shape - with two waves per SIMD the partner issues while this wave drains - so the fenced form stays.
+#ifndef FA_PIPE_BARE_BARRIER
+#define FA_PIPE_BARE_BARRIER 0
+#endif
 #if FA_PIPE_ABL == 1
 #define FA_PIPE_BARRIER() asm volatile("" ::: "memory")
+#elif FA_PIPE_BARE_BARRIER
+#define FA_PIPE_BARRIER() asm volatile("s_barrier" ::: "memory")
 #else
 #define FA_PIPE_BARRIER() __syncthreads()
 #endif
@@ -111,9 +122,19 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     const unsigned long long st0_ = __builtin_amdgcn_s_memtime();
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
     unsigned long long st1_ = 0, st2_ = 0, sta_ = 0, stb_ = 0, stc_ = 0;
+    unsigned long long body_sum_ = 0, sync_sum_ = 0, step_prev_ = 0, step_cnt_ = 0;   // -DFA_STAMPS=2: inside the hand-ordered steps
+    (void)step_prev_;
 #define FA_STAMP(V_) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); V_ = __builtin_amdgcn_s_memtime(); }
+#if FA_STAMPS == 2   /* where does a hand-ordered step go: its body (issue -> last MFMA / vector item issued) vs its publish (DMA wait + barrier) */
+#define FA_STEP_STAMP_A() { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (step_prev_) body_sum_ += t_ - step_prev_; step_prev_ = t_; }
+#define FA_STEP_STAMP_B() { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sync_sum_ += t_ - step_prev_; step_prev_ = t_; ++step_cnt_; }
+#endif
 #else
 #define FA_STAMP(V_) {}
+#endif
+#ifndef FA_STEP_STAMP_A
+#define FA_STEP_STAMP_A() {}
+#define FA_STEP_STAMP_B() {}
 #endif
 
     const int L = p.L;
@@ -159,6 +180,31 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
     const unsigned smem_lds = lds_offset(smem);
 
+#ifndef FA_PIPE_LEAN
+#define FA_PIPE_LEAN 0   /* 1: ~35 fewer scalar instructions per step - one buffer descriptor per operand for the whole workgroup (a step's
+                            rows are reached through the lane offset; reads past the operand's extent still return zeros), M0 not saved /
+                            restored, and the hand-ordered steps issue their two DMAs and their counted vmcnt wait unconditionally (a ring
+                            slot beyond the workgroup's last step receives rows nobody reads).  Measured in-process against 0
+                            (profiles/r03_step_anatomy/lean_ab.txt): L = 4096 .. 32768 at head_dim 64 -0.5 .. -0.9 %, L = 1024 / 2048 +3.4 /
+                            +0.9 %, head_dim 128 +0.5 .. +0.9 %: scalar instructions issue beside the partner wave's vector
+                            instructions, they were never what bounds the step - off */
+#endif
+#if FA_PIPE_LEAN
+    const i32x4 kr0_ = make_raw_rsrc((const char*)kg, k_bytes);
+    const i32x4 vr0_ = make_raw_rsrc((const char*)vg, v_bytes);
+#define FA_DMA_K(J_, SLOT_)                                                                        \
+    {                                                                                              \
+        const unsigned ko_ = (unsigned)(J_) * HK * k_slb;                                          \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
+            lds_dma_b128_m0(kr0_, smem_lds + (SLOT_) * KH_B + k_dst[j], k_vo[j] + ko_);            \
+    }
+#define FA_DMA_V(J_, SLOT_)                                                                        \
+    {                                                                                              \
+        const unsigned vo_ = (unsigned)(J_) * HK * v_slb;                                          \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
+            lds_dma_b128_m0(vr0_, smem_lds + NS * KH_B + (SLOT_) * VH_B + v_dst[j], v_vo[j] + vo_); \
+    }
+#else
 #define FA_DMA_K(J_, SLOT_)                                                                        \
     {                                                                                              \
         const unsigned ko_ = (unsigned)(J_) * HK * k_slb;                                          \
@@ -173,6 +219,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
             lds_dma_b128(vr_, smem_lds + NS * KH_B + (SLOT_) * VH_B + v_dst[j], v_vo[j]);          \
     }
+#endif
 
     int k_rd[KS];
     {
@@ -372,9 +419,19 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // KN_ / VP_ / KI_ / VI_: ring slots of K(I_+1), V(I_-1) and of the DMA targets K(I_+3), V(I_+2) - compile-time
     // constants in the 4-step groups, i-dependent values in the ragged steps; MASK_: mask mode (above);
     // QK_: a next step exists
+#if FA_PIPE_LEAN
+#define FA_ISSUE_FAST(I_, KSLOT_, VSLOT_)                                                          \
+        if (FA_PIPE_ABL != 2) { FA_DMA_K((I_) + NS - 1, KSLOT_) FA_DMA_V((I_) + NS - 2, VSLOT_) }
+#define FA_PUBLISH_FAST()                                                                          \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NS - 3)) : "memory");                  \
+        FA_PIPE_BARRIER();
+#else
+#define FA_ISSUE_FAST(I_, KSLOT_, VSLOT_) FA_ISSUE(I_, KSLOT_, VSLOT_)
+#define FA_PUBLISH_FAST() FA_PUBLISH()
+#endif
 #define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_)                             \
     {                                                                                              \
-        FA_ISSUE(I_, KI_, VI_)                                                                     \
+        FA_ISSUE_FAST(I_, KI_, VI_)                                                                \
         constexpr int NK = (QK_) ? KS : 0, NM = NK + 2 * DT, NMF = NM * QB, NV = 8 * QB;           \
         constexpr int PF_ = FA_PIPE_PF < NM ? FA_PIPE_PF : NM;                                     \
         const unsigned char* kb_ = smem + (KN_) * KH_B;                                            \
@@ -430,7 +487,9 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                barrier, in front of the PV that needs it) */                                      \
             asm volatile("" : "+v"(PC_[b][0]), "+v"(PC_[b][1]), "+v"(l[b]));                       \
         }                                                                                          \
-        FA_PUBLISH()                                                                               \
+        FA_STEP_STAMP_A()                                                                          \
+        FA_PUBLISH_FAST()                                                                          \
+        FA_STEP_STAMP_B()                                                                          \
     }
 #define FA_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                      \
     FA_FAST(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, 0, true)
@@ -579,6 +638,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #undef FA_KLIM
 #undef FA_ISSUE
 #undef FA_PUBLISH
+#undef FA_ISSUE_FAST
+#undef FA_PUBLISH_FAST
 #undef FA_STEADY
 #undef FA_FAST
 #undef FA_RAGGED
@@ -652,6 +713,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             sp[5] = (unsigned long long)nh_wg;
             sp[6] = sta_; sp[7] = stb_;
             sp[8] = stc_;
+            sp[12] = body_sum_; sp[13] = sync_sum_; sp[14] = step_cnt_;
             sp[9] = (unsigned long long)blockIdx.x;
         }
     }

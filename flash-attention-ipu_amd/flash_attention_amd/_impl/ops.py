@@ -310,19 +310,29 @@ def attention(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
 
 
 # The dK / dV kernel of the grouped-query backward runs one workgroup per (K/V head, 128 keys) that sweeps ALL query heads of
-# the group: with fewer than 512 such workgroups the chip is under-filled and the expanded route (more, shorter workgroups)
-# is faster (measured, scripts/bench_gqa.py: 256-384 workgroups 0.56-0.92x, 512 and more 1.02-1.17x, and 28 % less memory).
+# the group: with fewer than 512 such workgroups the chip is under-filled and one workgroup per (QUERY head, 128 keys) is faster
+# (measured, scripts/bench_gqa.py: 256-384 workgroups 0.56-0.92x, 512 and more 1.02-1.17x).
 GQA_NATIVE_MIN_WORKGROUPS = 512
 
 
 def attention_gqa(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
-    """[B, H, L, D] query with [B, H_kv, L, D] key / value (H a multiple of H_kv) -> out [B, H, L, D], differentiable."""
+    """[B, H, L, D] query with [B, H_kv, L, D] key / value (H a multiple of H_kv) -> out [B, H, L, D], differentiable.
+    K and V are never copied on either route."""
     B, H, L, D = q.shape
-    if k.shape[0] * k.shape[1] * ((L + 127) // 128) < GQA_NATIVE_MIN_WORKGROUPS and k.shape[1] != H:
-        rep = H // k.shape[1]       # small K/V grid: expanded heads through the multi-head kernels, autograd sums the copies
-        ke, ve = k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1)
-        return attention(q.reshape(-1, L, D), ke.reshape(-1, L, D), ve.reshape(-1, L, D),
-                         softmax_scale, num_chunks_q, num_chunks_kv, causal).view(B, H, L, D)
+    Hkv = k.shape[1]
+    if B * Hkv * ((L + 127) // 128) < GQA_NATIVE_MIN_WORKGROUPS and Hkv != H:
+        # small K/V grid: the multi-head kernels on VIEWS - the batch axis becomes (batch, K/V head), the head axis the `rep` query
+        # heads of one group, and K / V are read through a head stride of 0 (round 3: no repeat_interleave copies of K and V, neither
+        # for the forward nor kept for the backward; only dK / dV exist per query head until autograd's expand-backward sums them)
+        rep = H // Hkv
+        q5 = q.reshape(B * Hkv, rep, L, D)
+        k5 = k.reshape(B * Hkv, 1, L, D).expand(B * Hkv, rep, L, D)
+        v5 = v.reshape(B * Hkv, 1, L, D).expand(B * Hkv, rep, L, D)
+        if torch.compiler.is_compiling():
+            out = fwd_gqa(q5, k5, v5, softmax_scale, num_chunks_q, num_chunks_kv, causal)[0]
+        else:
+            out = _GqaAttentionFn.apply(q5, k5, v5, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+        return out.view(B, H, L, D)
     if torch.compiler.is_compiling():
         return fwd_gqa(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)[0]
     return _GqaAttentionFn.apply(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)

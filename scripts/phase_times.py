@@ -28,13 +28,14 @@ ap.add_argument("D", type=int)
 ap.add_argument("--kernel", default=None)
 ap.add_argument("--waves", type=int, default=None)
 ap.add_argument("--qb", type=int, default=None)
+ap.add_argument("--balance", type=int, default=None, help="0 | 1: placement-balanced block order off / on (default: the library's rule)")
 ap.add_argument("--lib", default=str(ROOT / "flash-attention-ipu_amd" / "build" / "variants" / "libfa_stamps.so"))
 a = ap.parse_args()
 
 lib = ctypes.CDLL(a.lib)
 _native._declare(lib)
 G, L, D = a.G, a.L, a.D
-for name, val in (("kernel", a.kernel), ("waves", a.waves), ("qb", a.qb)):
+for name, val in (("kernel", a.kernel), ("waves", a.waves), ("qb", a.qb), ("balance", a.balance)):
     if val is not None:
         v = _native._KERNEL_CODE[val] if name == "kernel" else int(val)
         assert lib.fa_debug_set_option(name.encode(), v) == 0
@@ -124,6 +125,11 @@ if kern == "pipe":
     nst = np.maximum(nsteps[..., w_last][ok] - 1 - 2 * plan.qb, 1)
     stat("  ... per step (approx)", steady / nst)
     stat("ragged + diagonal steps, last wave", (tc - tb)[..., w_last][ok])
+    cnt = st[..., 14].astype(np.int64)
+    if cnt.max() > 0:    # -DFA_STAMPS=2 build: inside the hand-ordered steps (body = issue of the step's MFMAs and vector items; publish = DMA wait + barrier)
+        sel = cnt > 0
+        stat("hand-ordered step: body (ticks per step)", st[..., 12].astype(np.int64)[sel] / cnt[sel])
+        stat("hand-ordered step: publish (wait + barrier)", st[..., 13].astype(np.int64)[sel] / cnt[sel])
     stat("drain", (t2 - tc)[..., w_last][ok])
 for w_ in range(W):
     stat(f"loop, wave {w_}", (t2 - t1)[..., w_][live[..., w_]])

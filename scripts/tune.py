@@ -209,7 +209,7 @@ def emit(args):
     import subprocess
     sha = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--print-csrc-fingerprint"], capture_output=True, text=True).stdout.strip()
     head = TABLE.read_text().split("// generated on:")[0]
-    body = [f"// generated on: {stamp}, {dev}, {props.multi_processor_count} CUs, nominal {getattr(props, 'clock_rate', 0) // 1000} MHz, "
+    body = [f"// generated on: {stamp}, {dev}, {props.multi_processor_count} CUs, "
             f"{clock_under_load()} MHz held under the headline kernel while tuning, {len(out_rows)} rows, by scripts/tune.py --emit{' --quick' if args.quick else ''}",
             f"// kernel sources (sha256/16 over csrc/*.hip, *.h, *.cpp BEFORE this table was rewritten): {sha}",
             "// a row exists only where its plan beat the built-in rules' own choice by >= 2 % in >= 4 of 5 interleaved rounds (scripts/tune.py)",

@@ -20,6 +20,32 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "demo"))
 from model import CausalSelfAttention, TinyGPT  # noqa: E402  (demo/model.py: the GPT-2-small-shaped model)
 
 
+def test_config4_attention_call_vs_oracle():
+    """BASELINE config 4's attention call as bench.py's `secondary.cfg4_gpt2_fwd` / `cfg4_attn` issue it: batch 8, 12 heads, T = 1024,
+    head_dim 64 - q, k, v the head-inner views `[8, 12, 1024, 64]` of one fused `[B, T, 3C]` projection, bf16, through the patched
+    F.scaled_dot_product_attention (G = 96: 768 workgroups, below one round of slots -> the placement-balanced block order).
+    The whole launch, groups sampled against the oracle (dense fp64 on the same bf16 values, scale D^-0.5), row 0 = V[0] everywhere."""
+    import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl import _native
+    from flash_attention_amd._impl.scaled_dot_product_attention import chunk_heuristic
+    from oracle import dense_attention_lse, frozen_randn
+
+    B, H, T, D = 8, 12, 1024, 64
+    plan = _native.plan(B * H, T, D, torch.bfloat16, *chunk_heuristic(T, D), softmax_scale=D ** -0.5)
+    assert plan.kernel == 0 and plan.grid == 768 and plan.balanced == 1, (plan.kernel, plan.grid, plan.balanced)
+    proj = frozen_randn(20260101, (B, T, 3 * H * D)).to(torch.bfloat16)
+    q, k, v = (t.view(B, T, H, D).transpose(1, 2) for t in proj.cuda().split(H * D, dim=2))
+    with torch.no_grad():
+        out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+    assert out.shape == (B, H, T, D) and torch.isfinite(out).all()
+    assert torch.equal(out[:, :, 0], v[:, :, 0])
+    qc, kc, vc = (t.view(B, T, H, D).transpose(1, 2) for t in proj.split(H * D, dim=2))
+    for b, h in ((0, 0), (3, 7), (7, 11), (5, 4)):
+        ref, _ = dense_attention_lse(qc[b:b + 1, h:h + 1], kc[b:b + 1, h:h + 1], vc[b:b + 1, h:h + 1], scale=D ** -0.5, causal=True)
+        err = (out[b:b + 1, h:h + 1].cpu().double() - ref).abs()
+        assert bool((err <= 1e-2 + 1e-2 * ref.abs()).all()), f"config 4 attention call, batch {b} head {h}: max|delta|={err.max().item():.3e}"
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gpt2_small_forward_through_override(dtype):
     import flash_attention_amd.auto  # noqa: F401

@@ -54,6 +54,9 @@ def fuzz(cases, seed, log=print):
       for kern in ("dma", "pipe"):
           for qb in (1, 2):
               variants.append({"kernel": kern, "qb": qb, "waves": rng.choice([1, 2, 4, 4, 8]), "sched": rng.choice([1, 2, 8])})
+      if causal:        # q-tile pairs per workgroup, and the placement-balanced block order (applies to grids below one round of slots)
+          variants.append({"kernel": "dma", "waves": 4, "pair": 1, "sched": rng.choice([1, 2, 8])})
+          variants.append({"kernel": "dma", "waves": 4, "pair": 0, "balance": rng.choice([0, 1])})
       if D == 128:      # the pipelined kernel on 16x16x32 MFMAs: 4- and 8-wave workgroups at head_dim 128,
           variants.append({"kernel": "pipe16", "waves": rng.choice([4, 8]), "sched": rng.choice([1, 2, 8])})
       else:             # 32 or 64 query rows per wave at head_dim 64
@@ -178,6 +181,63 @@ def fuzz(cases, seed, log=print):
                 log(f"MISMATCH grouped-query backward case {case} {name}: B={B} H={H}/{Hkv} L={L} D={D} {dt} scale={scale:.3g} causal={causal} max|d|={(got - want).abs().max().item():.3e}")
   finally:
       ops.GQA_NATIVE_MIN_WORKGROUPS = saved_gqa_threshold
+  # attention masks / biases and dropout (fa_fwd_ex / fa_bwd_ex) against the dense fp64 formula with the numpy restatement of the generator
+  from flash_attention_amd._impl import ops
+  from oracle import dense_attention_extra
+  for case in range(max(2, cases // 4)):
+      D = rng.choice([64, 128])
+      L = rng.choice([rng.randint(1, 140), rng.randint(1, 420)])
+      B, Hkv, rep = rng.randint(1, 2), rng.randint(1, 2), rng.choice([1, 1, 2, 3])
+      H = Hkv * rep
+      dt = rng.choice([torch.bfloat16, torch.float16])
+      scale = rng.choice([D ** -0.5, 0.5 * D ** -0.5])
+      causal = rng.random() < 0.4
+      p = rng.choice([0.0, 0.0, 0.15, 0.5])
+      kind = rng.choice(["none", "bool_full", "bool_pad", "bias_full", "bias_head", "bias_row"])
+      gen = torch.Generator().manual_seed(40_000 + case)
+      if kind == "none":
+          mask = None
+      elif kind == "bool_full":
+          mask = (torch.rand(B, H, L, L, generator=gen) < 0.6) | torch.eye(L, dtype=torch.bool)
+      elif kind == "bool_pad":
+          mask = (torch.arange(L)[None, :] < torch.randint(1, L + 1, (B,), generator=gen)[:, None]).view(B, 1, 1, L)
+      elif kind == "bias_full":
+          mask = torch.randn(B, H, L, L, generator=gen).to(dt)
+      elif kind == "bias_head":
+          mask = torch.randn(1, H, L, L, generator=gen).to(dt)
+      else:
+          mask = torch.randn(L, generator=gen).to(dt)
+      if mask is None and p == 0.0:
+          p = 0.25
+      seed_, off_ = rng.getrandbits(64), rng.getrandbits(40)
+      torch.manual_seed(50_000 + case)
+      q0 = (torch.randn(B, H, L, D) * 0.6).to(dt)
+      k0, v0 = ((torch.randn(B, Hkv, L, D) * 0.6).to(dt) for _ in range(2))
+      g = torch.randn(B, H, L, D).to(dt)
+      qr, kr, vr = (t.double().requires_grad_(True) for t in (q0, k0, v0))
+      ref, _ = dense_attention_extra(qr, kr, vr, scale, causal, mask, p, seed_, off_)
+      ref.backward(g.double())
+      qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
+      mc = None
+      if mask is not None:
+          mc = mask.cuda().expand(B, H, L, L)
+          mc = mc.view(torch.uint8) if mc.dtype == torch.bool else mc
+          mc = mc if mc.stride(-1) == 1 or L == 1 else mc.contiguous()
+      out = ops.attention_extra(qc, kc, vc, mc, scale, causal, p, seed_, off_)
+      out.backward(g.cuda())
+      torch.cuda.synchronize()
+      what = f"extra case {case}: B={B} H={H}/{Hkv} L={L} D={D} {dt} mask={kind} p={p} causal={causal}"
+      o = out.detach().cpu().double()
+      if not (bool(torch.isfinite(o).all()) and bool(((o - ref.detach()).abs() <= 1e-2 + 1e-2 * ref.detach().abs()).all())):
+          bad += 1
+          log(f"MISMATCH forward {what}: max|d|={(o - ref.detach()).abs().max().item():.3e}")
+      tol = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2}[dt]
+      for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
+          got = got.cpu().double()
+          floor = tol * max(1e-3, want.abs().max().item())
+          if not (bool(torch.isfinite(got).all()) and bool(((got - want).abs() <= floor + 2e-2 * want.abs()).all())):
+              bad += 1
+              log(f"MISMATCH {name} {what}: max|d|={(got - want).abs().max().item():.3e} (ref max {want.abs().max().item():.2f})")
   return bad, len(variants)
 
 
