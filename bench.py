@@ -211,15 +211,18 @@ def secondary_attention(name, dev, steps=20, warmup=5, backward=False):
     """One of the other single-GPU configs through the same op (or fa_bwd): value + roofline (kernel-only)."""
     G, L, D, dname, (nq, nk) = CONFIGS[name]
     fn, flops, kname, desc, plan = make_op(name, dev, backward=backward)
-    mean_ms = time_kernel(fn, steps, warmup, ramp_ms=60.0)
+    # a secondary record is the MEDIAN of three `steps`-long timed regions: each record starts from a chip that idled while the previous
+    # record's tensors were built, and ~0.35-0.5 s after load onset the device stalls once for ~40 ms (DESIGN.md 3.8) - a single 20-step
+    # mean that catches it is off by 2-10x.  (Per-step events, reported beside it, add ~4 us of event gap to every step of a short kernel.)
+    means = sorted([time_kernel(fn, steps, warmup, ramp_ms=60.0)] + [time_kernel(fn, steps, 0) for _ in range(2)])
+    mean_ms = means[1]
     med, mn = per_step_ms(fn, steps)
-    # a secondary record is the MEDIAN step: each one starts from a chip that idled while the previous record's tensors were built,
-    # and ~0.35-0.5 s after load onset the device stalls once for ~40 ms (DESIGN.md 3.8) - a 20-step mean that catches it is off by 2-10x
-    ms = med
+    ms = mean_ms
     tf = flops / (ms * 1e-3) / 1e12
     rec = {"metric": f"{'bwd' if backward else 'fwd'}_attention_tflops_causal_L{L}_D{D}", "value": round(tf, 2), "unit": "TFLOP/s", "dtype": dname,
            "config": {"workload": desc}, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "median_ms": round(med, 4), "min_ms": round(mn, 4),
-           "mean_ms": round(mean_ms, 4), "value_note": "from the median step (HIP events between consecutive steps)",
+           "timed_regions_ms": [round(x, 4) for x in means],
+           "value_note": "median of three timed regions of `steps` launches each; median_ms / min_ms: per-step HIP events (a pass of its own)",
            "roofline": roofline_record(tf, ms, kname, name + ("_bwd" if backward else ""), plan, (8 if backward else 4) * G * L * D * 2)}
     if backward:
         rec["flops_convention"] = "5*G*L^2*D (the kernels execute 7: scores are recomputed in both)"
@@ -316,7 +319,8 @@ def profiled_traffic(config, plan, kname=None):
     if rec.get("csrc_sha256_16") != csrc_fingerprint():
         return None, f"PMC record is for kernel sources {rec.get('csrc_sha256_16')}, this build is {csrc_fingerprint()}: re-run scripts/profile.sh"
     kname = kname or kernel_name(plan)
-    if rec.get("kernel") and not kname.startswith(rec["kernel"].split(" ")[0]):
+    names = lambda t: sorted(x.split(" ")[0] for x in t.split(" + "))  # noqa: E731
+    if rec.get("kernel") and names(rec["kernel"]) != names(kname):
         return None, f"PMC record is for {rec.get('kernel')}, this run launched {kname}"
     return rec.get("hbm_bytes_per_launch"), f"rocprofv3 PMC passes ({rec.get('source', 'profiles/')}), FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE"
 

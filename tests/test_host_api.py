@@ -117,13 +117,13 @@ def test_measured_tuning_table_is_consulted_and_bounded_by_the_chunks(native):
     import re
 
     text = (ROOT / "flash-attention-ipu_amd" / "csrc" / "fa_tuning_table.h").read_text()
-    rows = re.findall(r"\{\s*(\d+), (\d), (\d),\s*(\d+),\s*(\d+),\s*(\d+)ll,\s*(\d+)ll, '(\w)', (\d), (\d),\s*(\d+)(?:, (\d))?\}", text)
+    rows = re.findall(r"\{\s*(\d+), (\d), (\d),\s*(\d+),\s*(\d+),\s*(\d+)ll,\s*(\d+)ll, '(\w)', (\d), (\d),\s*(\d+), (\d), (\d)\}", text)
     rows = [r for r in rows if int(r[0]) != 0]
     if not rows:
         pytest.skip("no measured rows in this build")
-    assert "generated on:" in text and len(rows) >= 20
+    assert "generated on:" in text and "CUs" in text and "kernel sources (sha256/16" in text and len(rows) >= 20    # device and source stamps (round 3)
     checked = 0
-    for D, skip, causal, L_lo, L_hi, wg_lo, wg_hi, kern, waves, qb, sched, split in rows[::7]:
+    for D, skip, causal, L_lo, L_hi, wg_lo, wg_hi, kern, waves, qb, sched, split, pair in rows[::5]:
         split = max(1, int(split or 1))      # (kv split groups: plan.waves counts all of the workgroup's waves)
         D, L_lo, L_hi, wg_lo, wg_hi, waves, qb = int(D), int(L_lo), int(L_hi), int(wg_lo), int(wg_hi), int(waves), int(qb)
         L = 128 * ((max(L_lo, 256) + 127) // 128)
@@ -134,7 +134,7 @@ def test_measured_tuning_table_is_consulted_and_bounded_by_the_chunks(native):
             continue
         dt = torch.bfloat16 if skip == "1" else torch.float16
         p = native.plan(G, L, D, dt, 1, 1, causal=causal == "1")
-        assert p.source == 1 and (p.kernel, p.waves, p.qb) == ({"p": 2, "x": 4, "d": 0}[kern], waves * split, qb), (D, skip, causal, L, G)
+        assert p.source == 1 and (p.kernel, p.waves, p.qb, p.pair) == ({"p": 2, "x": 4, "d": 0}[kern], waves * split, qb, int(pair)), (D, skip, causal, L, G)
         with native.debug_options(table=0):
             assert native.plan(G, L, D, dt, 1, 1, causal=causal == "1").source == 0
         checked += 1
