@@ -408,7 +408,10 @@ def main():
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            import datetime
+            # (a collective that never completes is aborted by the watchdog after 3 minutes instead of the default 10: the exchange
+            # paths have only ever run at world size 1 on hardware)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=180))
 
     import flash_attention_amd as fa
     from flash_attention_amd._impl import _native
@@ -570,55 +573,6 @@ def main():
         kernel_ms = ek0.elapsed_time(ek1) / n_k / args.slabs
         kernel_note = "HIP events over a gather-free repeat of the same slab launches"
 
-    # ---- N > 1: the three ways to move O, measured in THIS launch after the headline (one driver run tells the whole story):
-    # per mode the exchange alone (a fixed shard, no kernel: what the links deliver) and kernel + exchange per step, overlapped the
-    # way the headline overlaps them.  Every rank runs the same sequence; times are the maximum over ranks.
-    gather_modes = None
-    shard_bytes = G * L * D * qkv.element_size() if world > 1 else 0
-    if do_gather and not use_gloo and not strong:
-        from flash_attention_amd.distributed import GATHER_MODES
-
-        gather_modes = {}
-        n_x = max(2, min(args.steps, 10))
-        shard = fa.flash_attention_qkv_packed(qkv, nq, nk)
-        bufs = [torch.empty(world * G, L, D, dtype=dtype, device=dev) for _ in range(2)]
-        for mode in GATHER_MODES:
-            gather_output(shard, out=bufs[0], mode=mode)               # warm-up (connections, first-use setup)
-            sync()
-            dist.barrier()
-            t_x = time.perf_counter()
-            for _ in range(n_x):
-                gather_output(shard, out=bufs[0], mode=mode)
-            sync()
-            x_ms = (time.perf_counter() - t_x) / n_x * 1e3
-            dist.barrier()
-            pend = [None, None]
-            t_s = time.perf_counter()
-            for i in range(n_x):                                        # kernel of step i + 1 over the exchange of step i
-                b = i & 1
-                if pend[b] is not None:
-                    pend[b][1].wait()
-                o_ = fa.flash_attention_qkv_packed(qkv, nq, nk)
-                pend[b] = (o_, gather_output(o_, out=bufs[b], async_op=True, mode=mode)[1])
-            for pb in pend:
-                if pb is not None:
-                    pb[1].wait()
-            sync()
-            s_ms = (time.perf_counter() - t_s) / n_x * 1e3
-            tm = torch.tensor([x_ms, s_ms], dtype=torch.float64, device=dev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            x_ms, s_ms = tm[0].item(), tm[1].item()
-            recv = (world - 1) * shard_bytes if mode != "root" else (world - 1) * shard_bytes       # the busiest rank's receive volume
-            gather_modes[mode] = {
-                "exchange_only_ms": round(x_ms, 4), "ms_per_step": round(s_ms, 4),
-                "value_tflops": round(world * flops_step / (s_ms * 1e-3) / 1e12, 2),
-                "received_bytes_busiest_rank": recv,
-                "achieved_GBps_per_link": round(shard_bytes / (x_ms * 1e-3) / 1e9, 2),
-                "note": "one shard per link and direction when every pair of GPUs has its own xGMI link (direct, root); a ring all-gather "
-                        "forwards W-1 shards over each link, so its per-link rate is (W-1) x this figure" if mode != "allgather" else
-                        "per-link figure = shard bytes / exchange time (what a direct exchange would need); the library's own algorithm decides what the links carry",
-            }
-
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1 and not use_gloo:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -627,6 +581,62 @@ def main():
         dist.all_reduce(tc, op=dist.ReduceOp.MAX)
         t = tc
     elapsed, kernel_ms = t[0].item(), t[1].item()
+
+    # ---- N > 1: the three ways to move O, measured in THIS launch after the headline (one driver run tells the whole story):
+    # per mode the exchange alone (a fixed shard, no kernel: what the links deliver) and kernel + exchange per step, overlapped the
+    # way the headline overlaps them.  Every rank runs the same sequence; times are the maximum over ranks.
+    gather_modes = None
+    compare_failed = False
+    shard_bytes = G * L * D * qkv.element_size() if world > 1 else 0
+    if do_gather and not use_gloo and not strong:
+        from flash_attention_amd.distributed import GATHER_MODES
+
+        gather_modes = {}
+        try:     # (the comparison must never cost the headline: any failure is recorded and the line is still printed)
+            n_x = max(2, min(args.steps, 10))
+            shard = fa.flash_attention_qkv_packed(qkv, nq, nk)
+            bufs = [torch.empty(world * G, L, D, dtype=dtype, device=dev) for _ in range(2)]
+            for mode in GATHER_MODES:
+                gather_output(shard, out=bufs[0], mode=mode)               # warm-up (connections, first-use setup)
+                sync()
+                dist.barrier()
+                t_x = time.perf_counter()
+                for _ in range(n_x):
+                    gather_output(shard, out=bufs[0], mode=mode)
+                sync()
+                x_ms = (time.perf_counter() - t_x) / n_x * 1e3
+                dist.barrier()
+                pend = [None, None]
+                t_s = time.perf_counter()
+                for i in range(n_x):                                        # kernel of step i + 1 over the exchange of step i
+                    b = i & 1
+                    if pend[b] is not None:
+                        pend[b][1].wait()
+                    o_ = fa.flash_attention_qkv_packed(qkv, nq, nk)
+                    pend[b] = (o_, gather_output(o_, out=bufs[b], async_op=True, mode=mode)[1])
+                for pb in pend:
+                    if pb is not None:
+                        pb[1].wait()
+                sync()
+                s_ms = (time.perf_counter() - t_s) / n_x * 1e3
+                tm = torch.tensor([x_ms, s_ms], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                x_ms, s_ms = tm[0].item(), tm[1].item()
+                recv = (world - 1) * shard_bytes if mode != "root" else (world - 1) * shard_bytes       # the busiest rank's receive volume
+                gather_modes[mode] = {
+                    "exchange_only_ms": round(x_ms, 4), "ms_per_step": round(s_ms, 4),
+                    "value_tflops": round(world * flops_step / (s_ms * 1e-3) / 1e12, 2),
+                    "received_bytes_busiest_rank": recv,
+                    "achieved_GBps_per_link": round(shard_bytes / (x_ms * 1e-3) / 1e9, 2),
+                    "note": "one shard per link and direction when every pair of GPUs has its own xGMI link (direct, root); a ring all-gather "
+                            "forwards W-1 shards over each link, so its per-link rate is (W-1) x this figure" if mode != "allgather" else
+                            "per-link figure = shard bytes / exchange time (what a direct exchange would need); the library's own algorithm decides what the links carry",
+                }
+
+        except Exception as e:  # noqa: BLE001
+            gather_modes["error"] = f"{type(e).__name__}: {e}"
+            compare_failed = True
+
 
     rc = 0
     median_ms = min_ms = None
@@ -742,6 +752,9 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if world > 1:
+        if compare_failed:          # (no further collective after a failed exchange: the line is out, leave)
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
     return rc
