@@ -3,8 +3,9 @@ demo (demo/train.py:139-321 trains nanoGPT's `shakespeare_char` config; the note
 flash attention at block 256 - 6.52 vs 7.16 it/s, same loss curve, nb:826-878 - and at block 1024, where standard
 attention runs out of memory on the IPU, nb:736).
 
-Here: the same model family (nanoGPT `shakespeare_char` shape: 6 layers, 6 heads, n_embd 384, dropout 0 - the override
-rejects dropout like the reference's), AdamW, bf16 autocast, on one MI355X, for
+Here: the same model family (nanoGPT `shakespeare_char` shape: 6 layers, 6 heads, n_embd 384; `--dropout 0.2` is that config's own
+setting - the reference's override raises for attention dropout, sdpa.py:25-28, this one serves it with its dropout kernels; the
+default 0 keeps the three modes' loss curves comparable step by step), AdamW, bf16 autocast, on one MI355X, for
     (a) `import flash_attention_amd.auto`  -> HIP forward + backward of this repository,
     (b) the override undone                 -> stock torch SDPA (ROCm's own fused backend),
     (c) the override undone, math backend   -> dense softmax(QK^T)V, what the reference's "standard attention" is,
@@ -16,7 +17,7 @@ There is no network here, so instead of tiny-shakespeare the corpus is ~1 MB of 
 this image has: the sources of Python's standard library (read as bytes, vocab 256); if that is missing, a seeded
 synthetic text.
 
-    python demo/train_char_gpt.py [--block 256] [--batch 64] [--steps 200] [--modes override,stock,math]
+    python demo/train_char_gpt.py [--block 256] [--batch 64] [--steps 200] [--modes override,stock,math] [--dropout 0.2]
 """
 import argparse
 import contextlib
@@ -63,7 +64,7 @@ def get_batch(data, block, batch, gen, device):
     return x.to(device, non_blocking=True), y.to(device, non_blocking=True)
 
 
-def train(mode="override", block=256, batch=64, steps=200, seed=1337, lr=1e-3, log=None, n_layer=6, n_head=6, n_embd=384):
+def train(mode="override", block=256, batch=64, steps=200, seed=1337, lr=1e-3, log=None, n_layer=6, n_head=6, n_embd=384, dropout=0.0):
     """Returns {"losses": [...], "it_per_s": ..., "peak_mib": ...}.  mode: override | stock | math."""
     import flash_attention_amd.auto  # noqa: F401  (patches F.scaled_dot_product_attention; undone below for the baselines)
 
@@ -73,7 +74,8 @@ def train(mode="override", block=256, batch=64, steps=200, seed=1337, lr=1e-3, l
     data = load_corpus()
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed)
-    model = gpt2_init_(TinyGPT(vocab=256, block=block, n_layer=n_layer, n_head=n_head, n_embd=n_embd)).to(dev)
+    model = gpt2_init_(TinyGPT(vocab=256, block=block, n_layer=n_layer, n_head=n_head, n_embd=n_embd, dropout=dropout)).to(dev)
+    model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=(0.9, 0.99), weight_decay=0.1)
     ctx = (lambda: sdpa_kernel(SDPBackend.MATH)) if mode == "math" else contextlib.nullcontext
     if mode != "override":
@@ -112,11 +114,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--modes", default="override,stock,math")
     ap.add_argument("--json", default="")
+    ap.add_argument("--dropout", type=float, default=0.0, help="attention / residual / embedding dropout (nanoGPT shakespeare_char: 0.2)")
     a = ap.parse_args()
     results = []
     for mode in a.modes.split(","):
         try:
-            results.append(train(mode, a.block, a.batch, a.steps, log=print))
+            results.append(train(mode, a.block, a.batch, a.steps, log=print, dropout=a.dropout))
         except torch.OutOfMemoryError:
             results.append({"mode": mode, "block": a.block, "batch": a.batch, "steps": a.steps, "losses": [], "it_per_s": float("nan"),
                             "peak_mib": float("nan"), "oom": True})

@@ -192,3 +192,30 @@ def test_char_level_training_curves_with_and_without_the_override(block, batch, 
     assert abs(mo - ms) < 0.08 * ms, (mo, ms)                                                 # and stay together
     assert ours["peak_mib"] <= 1.05 * dense["peak_mib"], (ours["peak_mib"], dense["peak_mib"])
     assert ours["it_per_s"] > 0 and stock["it_per_s"] > 0
+
+
+def test_char_level_training_with_attention_dropout_through_the_override():
+    """nanoGPT's `shakespeare_char` config trains with dropout 0.2 (attention dropout inside scaled_dot_product_attention): the
+    reference's override raises for it (sdpa.py:25-28), this one serves it with the dropout kernels (fa_fwd_ex / fa_bwd_ex).
+    demo/train_char_gpt.py --dropout 0.2 at reduced steps: the override's run must learn, must have used the dropout kernels, must
+    repeat itself under the same seed, and must end near the stock-SDPA run (other random masks: same distribution, not same values)."""
+    from flash_attention_amd._impl import ops
+    from train_char_gpt import train
+
+    calls = []
+    real = ops.attention_extra
+    ops.attention_extra = lambda *a, **kw: (calls.append(a[6]), real(*a, **kw))[1]      # a[6] = dropout_p
+    try:
+        ours = train("override", 256, 32, 40, dropout=0.2)
+        again = train("override", 256, 32, 8, dropout=0.2)
+    finally:
+        ops.attention_extra = real
+    stock = train("stock", 256, 32, 40, dropout=0.2)
+    lo, ls = ours["losses"], stock["losses"]
+    assert len(calls) >= 40 * 6 and all(abs(p - 0.2) < 1e-6 for p in calls), "the dropout kernels must have served every attention call"
+    assert all(x == x for x in lo), "NaN loss"
+    assert again["losses"] == lo[:8], "same seed -> same dropout masks -> same losses"
+    assert lo[-1] < 0.8 * lo[0] and ls[-1] < 0.8 * ls[0], (lo[0], lo[-1], ls[-1])
+    tail = 10
+    mo, ms = sum(lo[-tail:]) / tail, sum(ls[-tail:]) / tail
+    assert abs(mo - ms) < 0.10 * ms, (mo, ms)
