@@ -5,6 +5,7 @@
 // gradient is summed across workgroups here either.
 
 #include "fa_device.h"
+#include "fa_extras.h"
 
 namespace fa {
 
@@ -44,6 +45,10 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dq_kernel(const Bwd
     for (int d = tid; d < D; d += GB_THREADS) { qs[d] = (float)qg[d]; gs[d] = (float)gg[d]; }
     __syncthreads();
     const float lse = p.lse[(int64_t)g * L + row], dsum = p.dsum[(int64_t)g * L + row];
+    // attention mask / bias and dropout (fa_extras.h), as in fa_fwd_generic_kernel
+    const bool has_mask = p.ex.mask != nullptr, dropping = p.ex.drop_thr != 0u;
+    const char* const mbase = has_mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh) * (p.ex.mask_kind == 2 ? (int)sizeof(T) : 1) : nullptr;
+    const unsigned drop_kg = drop_group_key(p.ex.drop_key0, (unsigned)g);
     float acc[GB_MAXD_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < GB_MAXD_PER_THREAD; ++i) acc[i] = 0.f;
@@ -58,7 +63,15 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dq_kernel(const Bwd
                 s = __builtin_fmaf(qs[d], (float)kp[d], s);
                 dp = __builtin_fmaf(gs[d], (float)vp[d], dp);
             }
-            dsbuf[c] = __expf(s * p.scale - lse) * (dp - dsum) * p.scale;
+            s *= p.scale;
+            if (has_mask) s += mask_load1<T>(p.ex.mask_kind, mbase, (int64_t)row * p.ex.m_sl, k0 + c, 1.0f);
+            if (dropping) {
+                const unsigned col = (unsigned)(k0 + c);
+                const bool keep = mix32(drop_tile_key(drop_kg, (unsigned)row, col) ^ ((((unsigned)row & 0xffffu) << 16) | (col & 0xffffu))) >= p.ex.drop_thr;
+                dp = keep ? dp * p.ex.drop_rp : 0.0f;
+            }
+            const float pr = lse == -INFINITY ? 0.0f : __expf(s - lse);      // (a row without any admitted key: P = 0)
+            dsbuf[c] = pr * (dp - dsum) * p.scale;
         }
         __syncthreads();
 #pragma unroll
@@ -102,11 +115,15 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dkdv_kernel(const B
     for (int i = 0; i < GB_MAXD_PER_THREAD; ++i) { ak[i] = 0.f; av[i] = 0.f; }
     const int row_lo = p.causal ? key : 0;   // causal: rows key .. L-1 can see this key; otherwise every row
     const int nrows = L - row_lo;
+    const bool has_mask = p.ex.mask != nullptr, dropping = p.ex.drop_thr != 0u;
+    const int mask_esz = p.ex.mask_kind == 2 ? (int)sizeof(T) : 1;
     for (int hq = hh * p.kv_div; hq < (hh + 1) * p.kv_div; ++hq) {   // every query head that reads this K/V head
         const T* qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hq * p.q_sh;
         const T* gg = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hq * p.do_sh;
         const float* lse = p.lse + ((int64_t)bb * p.H + hq) * L;
         const float* dsum = p.dsum + ((int64_t)bb * p.H + hq) * L;
+        const char* const mbase = has_mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hq * p.ex.m_sh) * mask_esz : nullptr;
+        const unsigned drop_kg = drop_group_key(p.ex.drop_key0, (unsigned)(bb * p.H + hq));
         for (int r0 = 0; r0 < nrows; r0 += GB_CHUNK) {
             const int rn = nrows - r0 < GB_CHUNK ? nrows - r0 : GB_CHUNK;
             for (int c = tid; c < rn; c += GB_THREADS) {
@@ -118,8 +135,16 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dkdv_kernel(const B
                     s = __builtin_fmaf((float)qp[d], ks[d], s);
                     dp = __builtin_fmaf((float)gp[d], vs[d], dp);
                 }
-                const float pr = __expf(s * p.scale - lse[row]);
-                pbuf[c] = pr;
+                s *= p.scale;
+                if (has_mask) s += mask_load1<T>(p.ex.mask_kind, mbase, (int64_t)row * p.ex.m_sl, key, 1.0f);
+                const float pr = lse[row] == -INFINITY ? 0.0f : __expf(s - lse[row]);
+                float pd = pr;           // what dV sees: P, or with dropout keep ? P / (1 - p) : 0
+                if (dropping) {
+                    const bool keep = mix32(drop_tile_key(drop_kg, (unsigned)row, (unsigned)key) ^ ((((unsigned)row & 0xffffu) << 16) | ((unsigned)key & 0xffffu))) >= p.ex.drop_thr;
+                    dp = keep ? dp * p.ex.drop_rp : 0.0f;
+                    pd = keep ? pr * p.ex.drop_rp : 0.0f;
+                }
+                pbuf[c] = pd;
                 dsbuf[c] = pr * (dp - dsum[row]) * p.scale;
             }
             __syncthreads();

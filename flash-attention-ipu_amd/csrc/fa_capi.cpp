@@ -351,7 +351,7 @@ const char* fa_error_string(int code) {
         case FA_ERR_TOO_LARGE: return "problem too large";
         case FA_ERR_BAD_SCALE: return "softmax_scale must be finite and > 0";
         case FA_ERR_BAD_OPTION: return "unknown debug option or value out of range";
-        case FA_ERR_UNSUPPORTED: return "mask / dropout launches need f16 or bf16 operands, head_dim 64 or 128, 16-byte aligned rows";
+        case FA_ERR_UNSUPPORTED: return "unsupported combination (reserved: every combination fa_fwd serves is served with a mask / dropout too)";
         case FA_ERR_BAD_MASK: return "bad mask kind or mask pointer";
         case FA_ERR_BAD_DROPOUT: return "dropout_p must be in [0, 1)";
         default: return "unknown error";
@@ -495,13 +495,14 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     const bool wide_ok = !wide_rows && aligned16(D, elt_size(dtype), ptrs, strides) && L * k_strides[2] < (1ll << 31) && L * v_strides[2] < (1ll << 31);
     const bool mfma16_ok = wide_ok && (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16);
     const bool f32_ok = wide_ok && dtype == FA_DTYPE_F32 && !options().f32_generic;
+    // mask / dropout: the MFMA mask kernel (fa_fwd_extra.hip) for 16-bit operands it takes, the generic kernel for everything else
+    // fa_fwd serves (fp32, other head dims, unaligned rows) - never the fp32 MFMA kernel, which has no mask path
+    const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     Selection sel;
-    const int rc = select_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal, mfma16_ok, f32_ok, &sel);
+    const int rc = select_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal, mfma16_ok, f32_ok && !extra, &sel);
     if (rc != FA_OK) return rc;
     const fa_plan_t& plan = sel.plan;
-    const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
-    if (extra && !mfma16_ok)
-        return fail(FA_ERR_UNSUPPORTED, "mask / dropout launches need f16 or bf16 operands, head_dim 64 or 128 and 16-byte aligned rows");
+    const bool extra_mfma = extra && mfma16_ok;
 
     fa::FwdParams p;
     memset(&p.ex, 0, sizeof(p.ex));
@@ -519,7 +520,7 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     p.D = (int32_t)D;
     p.causal = causal;
     p.nq_tiles = plan.kernel != 1 ? (int32_t)((L + plan.block_q - 1) / plan.block_q) : 0;
-    if (extra) p.nq_tiles = (int32_t)((L + 127) / 128);     // fa_fwd_extra_kernel: 4 waves x 32 rows, exact-max arithmetic
+    if (extra_mfma) p.nq_tiles = (int32_t)((L + 127) / 128);     // fa_fwd_extra_kernel: 4 waves x 32 rows, exact-max arithmetic
     p.sched = plan.sched;
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
@@ -531,8 +532,8 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
         if (plan.grid * plan.waves * 16 * 8 <= g_stamp_bytes.load()) p.stamps = static_cast<unsigned long long*>(sb);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (extra) { p.perm_n = 0; p.skipmax = 0; }
-    hipError_t e = extra              ? fa::launch_fwd_extra(p, dtype, st)
+    if (extra_mfma) { p.perm_n = 0; p.skipmax = 0; }
+    hipError_t e = extra_mfma         ? fa::launch_fwd_extra(p, dtype, st)
                    : sel.which == 'g' ? fa::launch_fwd_generic(p, dtype, st)
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
@@ -629,8 +630,7 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
         if (strides[i][2] > (1ll << 32) || L * strides[i][2] >= (1ll << 31)) mfma = false;
     }
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
-    if (extra && !(mfma && dtype != FA_DTYPE_F32))
-        return fail(FA_ERR_UNSUPPORTED, "mask / dropout launches need f16 or bf16 operands, head_dim 64 or 128 and 16-byte aligned rows");
+    if (extra && dtype == FA_DTYPE_F32) mfma = false;       // (the fp32 MFMA kernels have no mask path: generic kernels)
     if (!mfma && D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic backward supports D <= 1024 (got %lld)", (long long)D);
     if (!mfma && G * L > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     fa::BwdParams p;
@@ -663,7 +663,7 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
     if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
-    hipError_t e = extra                  ? fa::launch_bwd_extra(p, dtype, (hipStream_t)stream)
+    hipError_t e = extra && mfma          ? fa::launch_bwd_extra(p, dtype, (hipStream_t)stream)
                    : !mfma                ? fa::launch_bwd_generic(p, dtype, (hipStream_t)stream)
                    : dtype == FA_DTYPE_F32 ? fa::launch_bwd_f32(p, (hipStream_t)stream)
                                            : fa::launch_bwd(p, dtype, (hipStream_t)stream);

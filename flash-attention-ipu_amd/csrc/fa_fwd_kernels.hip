@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #include "fa_device.h"
+#include "fa_extras.h"
 
 #ifndef FA_CHAIN_SPLIT
 #define FA_CHAIN_SPLIT 0   // experiment knob: split the max / row-sum dependency chains
@@ -380,6 +381,11 @@ __global__ __launch_bounds__(GEN_THREADS) void fa_fwd_generic_kernel(const FwdPa
     for (int i = 0; i < GEN_MAXD_PER_THREAD; ++i) oacc[i] = 0.f;
     float m = -INFINITY, l = 0.f;
     const int nkeys = p.causal ? row + 1 : L;   // causal: keys 0..row
+    // attention mask / bias and dropout (fa_extras.h; fa_fwd_ex on operands the MFMA kernels do not take): the mask term is added
+    // to the SCALED logit, the dropout decision zeroes the weight the PV product sees while the denominator keeps it
+    const bool has_mask = p.ex.mask != nullptr, dropping = p.ex.drop_thr != 0u;
+    const char* const mbase = has_mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh) * (p.ex.mask_kind == 2 ? (int)sizeof(T) : 1) : nullptr;
+    const unsigned drop_kg = drop_group_key(p.ex.drop_key0, (unsigned)g);
 
     for (int k0 = 0; k0 < nkeys; k0 += GEN_CHUNK) {
         const int kn = nkeys - k0 < GEN_CHUNK ? nkeys - k0 : GEN_CHUNK;
@@ -389,18 +395,22 @@ __global__ __launch_bounds__(GEN_THREADS) void fa_fwd_generic_kernel(const FwdPa
             float acc = 0.f;
             for (int d = 0; d < D; ++d) acc = __builtin_fmaf(qrow_s[d], to_f32(kp[d]), acc);
             acc *= p.scale;
+            if (has_mask) acc += mask_load1<T>(p.ex.mask_kind, mbase, (int64_t)row * p.ex.m_sl, k0 + cidx, 1.0f);
             pbuf[cidx] = acc;
             mx = fmaxf(mx, acc);
         }
         mx = block_reduce(mx, red, true);
         const float m_new = fmaxf(m, mx);
-        const float alpha = __expf(m - m_new);   // exp(-inf) = 0 on the first chunk
+        // exp(-inf) = 0 on the first chunk; a row that has met no admitted key yet (m_new = -inf under a mask) keeps alpha = 1, P = 0
+        const float alpha = m_new == -INFINITY ? 1.0f : __expf(m - m_new);
         m = m_new;
         float ls = 0.f;
         for (int cidx = tid; cidx < kn; cidx += GEN_THREADS) {
-            const float e = __expf(pbuf[cidx] - m_new);
-            pbuf[cidx] = e;
+            const float e = m_new == -INFINITY ? 0.0f : __expf(pbuf[cidx] - m_new);
             ls += e;
+            const unsigned col = (unsigned)(k0 + cidx);
+            const bool keep = !dropping || mix32(drop_tile_key(drop_kg, (unsigned)row, col) ^ ((((unsigned)row & 0xffffu) << 16) | (col & 0xffffu))) >= p.ex.drop_thr;
+            pbuf[cidx] = keep ? e : 0.0f;
         }
         ls = block_reduce(ls, red, false);   // barriers inside also publish pbuf
         l = l * alpha + ls;
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fa_fwd_generic_kernel(const FwdPa
     }
 
     T* og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)row * p.o_sl;
-    const float inv = 1.0f / l;
+    const float inv = (dropping ? p.ex.drop_rp : 1.0f) / l;
 #pragma unroll
     for (int i = 0; i < GEN_MAXD_PER_THREAD; ++i) {
         const int d = tid + i * GEN_THREADS;

@@ -69,7 +69,8 @@ enum {
     FA_ERR_TOO_LARGE = -10,         /* grid or offsets exceed what the kernel indexes */
     FA_ERR_BAD_SCALE = -11,         /* softmax_scale must be finite and > 0 */
     FA_ERR_BAD_OPTION = -12,        /* fa_debug_set_option: unknown name or value out of range */
-    FA_ERR_UNSUPPORTED = -13,       /* fa_fwd_ex / fa_bwd_ex with a mask or dropout on operands the MFMA kernels do not take */
+    FA_ERR_UNSUPPORTED = -13,       /* reserved (ABI 4 drafts returned it for a mask / dropout on operands the MFMA kernels do not take;
+                                       the generic kernels serve those now) */
     FA_ERR_BAD_MASK = -14,          /* mask_kind out of range, or mask pointer and mask_kind disagree */
     FA_ERR_BAD_DROPOUT = -15        /* dropout_p outside [0, 1) */
 };
@@ -214,8 +215,10 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
  *   dropout_p     : probability in [0, 1) of dropping an attention weight (0 = off); kept weights are scaled by 1 / (1 - p).
  *                   The decision for (g, row, key) is a pure function of (dropout_seed, dropout_offset, g, row, key)
  *                   (csrc/fa_extras.h), so fa_bwd_ex given the same three values regenerates the forward's mask.
- * Served by MFMA kernels only: f16 / bf16 operands, head_dim 64 or 128, 16-byte aligned rows - otherwise FA_ERR_UNSUPPORTED
- * (the Python override then lets stock SDPA serve the call).  With mask = NULL and dropout_p = 0 they ARE fa_fwd / fa_bwd.
+ * f16 / bf16 operands at head_dim 64 or 128 with 16-byte aligned rows run MFMA kernels (csrc/fa_fwd_extra.hip, fa_bwd_extra.hip);
+ * everything else fa_fwd serves (fp32, other head dims <= 1024, unaligned rows) runs the generic fp32-arithmetic kernels with the same
+ * mask and the same dropout decisions (a bias then has the operand dtype, fp32 included).  With mask = NULL and dropout_p = 0 they
+ * ARE fa_fwd / fa_bwd.
  */
 int fa_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
               int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,

@@ -129,11 +129,14 @@ int main() {
         EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 1.0f, 0, 0, nullptr) == FA_ERR_BAD_DROPOUT);
         EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, -0.5f, 0, 0, nullptr) == FA_ERR_BAD_DROPOUT);
         EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 0.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr) == FA_ERR_BAD_SCALE);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr) == FA_ERR_UNSUPPORTED);   // fp32
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 80, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_ERR_UNSUPPORTED);      // head_dim 80
+        // operands the MFMA mask kernels do not take go to the generic kernels (never to the fp32 MFMA kernel, which has no mask path)
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr) == FA_OK && g_stub_last == 'g');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 80, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last == 'g');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 2048, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_SHAPE);   // (head_dim > 1024: as fa_fwd)
         EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BIAS, ms, 0.1f, 3, 4, nullptr) == FA_OK && g_stub_last == 'e');
         EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last == 'B');
-        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.3f, 0, 0, nullptr) == FA_ERR_UNSUPPORTED);
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.3f, 0, 0, nullptr) == FA_OK && g_stub_last == 'b');
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last == 'F');   // nothing extra: the fp32 MFMA kernels
         EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 2.0f, 0, 0, nullptr) == FA_ERR_BAD_DROPOUT);
     }
     st8[3][1] = -5;

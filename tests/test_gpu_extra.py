@@ -213,10 +213,37 @@ def test_sdpa_override_serves_attn_mask_and_dropout():
         patched(q.cpu(), k.cpu(), v.cpu(), dropout_p=0.1, is_causal=True)
 
 
-def test_c_abi_reports_what_the_mask_kernels_do_not_take():
+@pytest.mark.parametrize("dtype,D,L", [(torch.float32, 64, 200), (torch.float32, 40, 130), (torch.bfloat16, 80, 190), (torch.float16, 64, 97)])
+def test_generic_kernels_serve_mask_and_dropout_for_everything_else(dtype, D, L):
+    """fa_fwd_ex / fa_bwd_ex on operands the MFMA mask kernels do not take - fp32, head dims other than 64 / 128, (f16, 64) with
+    unaligned rows - run the generic fp32-arithmetic kernels with the same mask terms and the same dropout decisions: out, logsumexp
+    and gradients against the oracle.  (The SDPA override hands such calls to stock SDPA for speed; the C ABI serves them.)"""
     from flash_attention_amd._impl import _native
+    from oracle import dense_attention_extra, frozen_randn
 
-    q = torch.randn(1, 2, 64, 64, device="cuda")
-    out = torch.empty_like(q)
-    with pytest.raises(NotImplementedError, match="mask / dropout"):
-        _native.fwd_ex(q, q, q, out, None, 64, 64, 0.125, True, None, 0.5, 1, 2)
+    B, H, Hkv, p = 2, 4, 2, 0.2
+    gen = torch.Generator().manual_seed(L)
+    pad = 1 if (dtype == torch.float16 and D == 64) else 0            # odd row pitch -> unaligned rows -> generic kernels
+    mk = lambda seed, h: (frozen_randn(SEED + seed, (B, h, L, D + pad)) * 0.6).to(dtype)[..., :D]  # noqa: E731
+    q, k, v, g = mk(1, H), mk(2, Hkv), mk(3, Hkv), mk(4, H)
+    mask = _masks("bias_BHLL", B, H, L, dtype, gen)
+    scale = D ** -0.5
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, ref_lse = dense_attention_extra(qr, kr, vr, scale, True, mask, p, 5, 6)
+    ref.backward(g.double())
+    qc, kc, vc, gc, mc = (t.cuda() for t in (q, k, v, g, mask))
+    out = torch.empty(B, H, L, D, dtype=dtype, device="cuda")
+    lse = torch.empty(B * H, L, dtype=torch.float32, device="cuda")
+    _native.fwd_ex(qc, kc, vc, out, lse, L, D, scale, True, mc, p, 5, 6)
+    o = out.cpu().double()
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert bool(((o - ref.detach()).abs() <= tol + tol * ref.detach().abs()).all()), (o - ref.detach()).abs().max().item()
+    torch.testing.assert_close(lse.view(B, H, L).cpu().double(), ref_lse.detach(), atol=1e-4 if dtype == torch.float32 else LSE_ATOL, rtol=1e-4)
+    dq, dk, dv = torch.empty_like(qc.contiguous()), torch.empty_like(kc.contiguous()), torch.empty_like(vc.contiguous())
+    _native.bwd_ex(qc, kc, vc, out, gc, lse, dq, dk, dv, L, D, scale, True, mc, p, 5, 6)
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        if dtype == torch.float32:
+            err = (got.cpu().double() - want).abs().max().item()
+            assert err <= 1e-4 * max(1.0, want.abs().max().item()), (name, err)
+        else:
+            _grad_close(got, want, f"{name} generic {dtype} D={D}")
