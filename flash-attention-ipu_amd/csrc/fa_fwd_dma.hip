@@ -118,6 +118,13 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const int mask_esz = p.ex.mask_kind == 2 ? (int)sizeof(T) : 1;
     const char* const mask_g = EXTRA && p.ex.mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh) * mask_esz : nullptr;
     const unsigned drop_kg = EXTRA ? drop_group_key(p.ex.drop_key0, (unsigned)g) : 0u;
+    // EXTRA: the raw mask data of the NEXT tile is requested as soon as this tile's has been decoded into the scores (one register set):
+    // a mask row is global memory nobody else has touched - its latency then runs under this tile's softmax and PV product, the barrier
+    // and the next tile's QK^T instead of sitting between QK^T and the softmax
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 mraw[EXTRA ? 8 : 1];
+    bool mpre_ok = false;
+    (void)mraw; (void)mpre_ok;
 
     // Q^T fragments of q tile QI_ (B operands of S^T = K Q^T): block b of this wave owns row QI_ * BQ + wave * WQ + 32 b + r
     vec8 qf[QB][KS];
@@ -212,6 +219,29 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     //     than 2^RESCALE_THR) - unscaled f16, and the fallback pass of the fast mode.
     constexpr bool SKIPMAX = FA_DMA_SKIPMAX && SKIP;
 
+    // EXTRA: request the raw mask data of tile T_ (aligned full tiles only; anything else is loaded in place when its scores exist)
+#define FA_MASK_PREFETCH(T_)                                                                 \
+    if constexpr (EXTRA) {                                                                         \
+        if (mask_g != nullptr) {                                                                   \
+            const int kvp_ = (T_) * BK;                                                            \
+            const bool ok_ = p.ex.mask_vec != 0 && wave_active && (T_) < n_tiles && kvp_ + BK <= L && kvp_ <= wave_kv_last;   \
+            mpre_ok = ok_;                                                                   \
+            if (ok_) {                                                                             \
+                /* (rows past L are clamped duplicates: their P must stay finite - the row-sum MFMA multiplies them by 0) */ \
+                const char* mrow_ = mask_g + (int64_t)(qrow < L ? qrow : L - 1) * p.ex.m_sl * mask_esz; \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
+                    const int k0_ = kvp_ + 8 * j + 4 * h;                                          \
+                    if (p.ex.mask_kind == 2) {                                                     \
+                        mraw[j] = *(const u32x2*)(mrow_ + (int64_t)k0_ * 2);                 \
+                        mraw[4 + j] = *(const u32x2*)(mrow_ + (int64_t)(k0_ + 32) * 2);      \
+                    } else {                                                                       \
+                        mraw[j].x = *(const unsigned*)(mrow_ + k0_);                         \
+                        mraw[4 + j].x = *(const unsigned*)(mrow_ + k0_ + 32);                \
+                    }                                                                              \
+                }                                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+    }
     // ---- the pieces of one kv tile (buffer index BUF_ is compile-time); same arithmetic as fa_fwd_tile_kernel
 #define FA_QK(BUF_)                                                                                \
     {                                                                                              \
@@ -227,7 +257,23 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             }                                                                                      \
         }                                                                                          \
         if constexpr (EXTRA) {                                                                     \
-            if (mask_g != nullptr) {   /* additive terms on the raw scores: bias / scale, or 0 | -inf */ \
+            if (mask_g != nullptr && mpre_ok) {   /* prefetched raw data of this tile (QB == 1) */ \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
+                    if (p.ex.mask_kind == 2) {                                                     \
+                        const vec4 b0_ = __builtin_bit_cast(vec4, mraw[j]), b1_ = __builtin_bit_cast(vec4, mraw[4 + j]); \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                            \
+                            s0[0][4 * j + i] += (float)b0_[i] * p.ex.inv_scale;                    \
+                            s1[0][4 * j + i] += (float)b1_[i] * p.ex.inv_scale;                    \
+                        }                                                                          \
+                    } else {                                                                       \
+                        const unsigned w0_ = mraw[j].x, w1_ = mraw[4 + j].x;           \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                            \
+                            s0[0][4 * j + i] += ((w0_ >> (8 * i)) & 0xffu) ? 0.f : -INFINITY;      \
+                            s1[0][4 * j + i] += ((w1_ >> (8 * i)) & 0xffu) ? 0.f : -INFINITY;      \
+                        }                                                                          \
+                    }                                                                              \
+                }                                                                                  \
+            } else if (mask_g != nullptr) {   /* additive terms on the raw scores: bias / scale, or 0 | -inf */ \
                 const bool fast_ = p.ex.mask_vec != 0 && kv0 + BK <= L;                            \
                 _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                   \
                     const int mr_ = qrow + 32 * b < L ? qrow + 32 * b : L - 1;                     \
@@ -330,7 +376,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         const int kv0 = (T_) * BK;                                                                 \
         if (wave_active && (SPLIT == 1 || (T_) < n_tiles) && kv0 <= wave_kv_last) {                \
             f32x16 s0[QB], s1[QB];                                                                 \
-            if (FA_DMA_ABL != 5) { FA_QK(BUF_) } else {                                            \
+            if (FA_DMA_ABL != 5) { FA_QK(BUF_) FA_MASK_PREFETCH((T_) + tstride) } else {                   \
                 _Pragma("unroll") for (int b = 0; b < QB; ++b)                                     \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[b][e] = o[b][0][e]; s1[b][e] = o[b][1][e]; } \
             }                                                                                      \
@@ -351,6 +397,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     {                                                                                              \
         if (!tile0_requested && (SPLIT == 1 || tfirst < n_tiles)) FA_DMA_TILE(tfirst, 0)           \
         tile0_requested = false;                                                                   \
+        FA_MASK_PREFETCH(tfirst)                                                                   \
         FA_TILE_BARRIER()                                                                          \
         if (pass == 0) FA_STAMP(st1_)                                                              \
         for (int rr = 0; rr < n_rounds; rr += 2) {              /* (workgroup-uniform bounds) */   \
@@ -504,6 +551,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     }   // wave_active
     }   // pass
 #undef FA_DMA_TILE
+#undef FA_MASK_PREFETCH
 #undef FA_TILE_BARRIER
 #undef FA_COMPUTE
 #undef FA_PASS
