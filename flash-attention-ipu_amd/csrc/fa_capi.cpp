@@ -37,7 +37,7 @@ int elt_size(int dtype) { return dtype == FA_DTYPE_F32 ? 4 : 2; }
 // either the old or the new value of one knob and never a torn one; fa_plan() and fa_fwd() go through the same
 // make_plan(), so a reported plan is the launched plan.
 struct Options {
-    std::atomic<int> kernel{0};     // 0 auto, 'd' | 'p' | 'x' | 't'
+    std::atomic<int> kernel{0};     // 0 auto, 'd' | 'p' | 'x' | 't' | 'P'
     std::atomic<int> qb{0};         // 0 auto, 1 | 2 query blocks per wave
     std::atomic<int> waves{0};      // 0 auto, 1 | 2 | 4 | 8
     std::atomic<int> sched{0};      // 0 auto, else groups per L2 bunch
@@ -54,8 +54,9 @@ std::once_flag g_opt_once;
 std::atomic<void*> g_stamp_buf{nullptr};
 std::atomic<int64_t> g_stamp_bytes{0};
 
-int parse_kernel(const char* v) {   // dma | pipe | pipe16 | tile
+int parse_kernel(const char* v) {   // dma | pipe | pipe16 | pp | tile
     if (!v) return 0;
+    if (strcmp(v, "pp") == 0 || v[0] == 'P') return 'P';
     if (strcmp(v, "pipe16") == 0 || v[0] == 'x') return 'x';
     return (v[0] == 't' || v[0] == 'd' || v[0] == 'p') ? v[0] : 0;
 }
@@ -103,6 +104,8 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 //   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic only
 //   'x' fa_fwd_pipe16_kernel the pipelined kernel on v_mfma_f32_16x16x32 (fa_fwd_pipe16.hip): head_dim 128 with 4 | 8 waves and qb 1,
 //       head_dim 64 with 4 waves and qb 1 | 2
+//   'P' fa_fwd_pp_kernel    the 32-key-step kernel with the two waves of a SIMD in complementary phases (fa_fwd_pp.hip): head_dim 64,
+//       512-thread workgroups = two 256-row halves (the same q tile of two groups), skip-max arithmetic only
 //   't' fa_fwd_tile_kernel  register-staged A/B baseline (debug override only)
 // qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
 // split = kv split groups of a 'd' workgroup (4 waves x 32 rows each, all on the same 128 query rows; fa_fwd_dma.hip): for
@@ -111,7 +114,7 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 // kernels' own constraints are enforced on whatever was picked.
 struct Selection {
     fa_plan_t plan;
-    char which;      // 'd' | 'p' | 't' | 'g' generic | 'f' fp32 MFMA
+    char which;      // 'd' | 'p' | 'x' | 'P' | 't' | 'g' generic | 'f' fp32 MFMA
     int split;       // kv split groups per workgroup ('d' only; plan.waves counts all of the workgroup's waves)
     int pair;        // 'd' only: 1 = a workgroup owns q tiles (nq - 1 - i) and i, one after the other
     int perm_n;      // 'd' only: > 0 = placement-balanced order of the XCD's first perm_n slots
@@ -211,6 +214,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (fk == 't') { which = 't'; qb = 1; }
         else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
         else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && D == 128) ? 8 : 4; if (!fq) qb = 1; }
+        else if (fk == 'P' && pipe_ok && D == 64) { which = 'P'; waves = 4; qb = 2; }
         else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
         if (fq == 1) qb = 1;
         if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
@@ -221,6 +225,8 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (want32 && pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
         if (which == 'p' && ((waves > 4 && D != 128) || !pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
         if (which == 'x' && !pipe_ok) which = 'd';
+        if (which == 'P' && !(pipe_ok && D == 64)) which = 'd';
+        if (which == 'P') { waves = 4; qb = 2; split = 1; }
         if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
         if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
         if (which == 't' && waves > 4) waves = 4;
@@ -260,18 +266,23 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
                 sel->perm_n = balanced_order((int)(ng * nitem), weight, sel->perm);
             }
         }
-        plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : 0;
+        plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : which == 'P' ? 5 : 0;
         plan->pair = pair;
         plan->balanced = sel->perm_n > 0;
         plan->waves = waves * split;
         plan->qb = qb;
         plan->block_q = 32 * waves * qb;
-        plan->block_kv = (which == 'p' || which == 'x') ? 32 : 64;
+        plan->block_kv = (which == 'p' || which == 'x' || which == 'P') ? 32 : 64;
         plan->skipmax = skip;
         plan->source = source;
         plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
         if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
-        plan->lds_bytes = which == 'x' ? 8 * 32 * D * 2 + 16
+        if (which == 'P') {   // one workgroup = 8 waves = two 256-row halves: the same q tile of two groups of one XCD class
+            plan->waves = 8;
+            plan->grid = 8 * ((g8 / 8 + 1) / 2) * ((L + 255) / 256);
+        }
+        plan->lds_bytes = which == 'P' ? 2 * (4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64)) + 32
+                          : which == 'x' ? 8 * 32 * D * 2 + 16
                           : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
                                        : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
         // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
@@ -280,7 +291,8 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
             const int64_t kv_bytes = 2 * L * D * es;
             int64_t bunch = sched > 0 ? sched : (8ll << 20) / kv_bytes;
             if (opt.sched > 0) bunch = opt.sched;
-            const int64_t ng = g8 / 8;
+            int64_t ng = g8 / 8;
+            if (which == 'P') { bunch = (bunch + 1) / 2; ng = (ng + 1) / 2; }   // (counted in PAIRS of groups)
             if (bunch < 1) bunch = 1;
             if (bunch > ng) bunch = ng;
             plan->sched = (int32_t)bunch;
@@ -364,8 +376,8 @@ int fa_debug_set_option(const char* name, int32_t value) {
     for (const OptionName& o : kOptionNames) {
         if (strcmp(o.name, name) != 0) continue;
         if (value < o.lo || value > o.hi) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: %s=%d out of range [%d, %d]", name, value, o.lo, o.hi);
-        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 't'))
-            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x' or 't'");
+        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 't' || value == 'P'))
+            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x', 'P' or 't'");
         if (o.field == &Options::waves && !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: waves must be 0, 1, 2, 4 or 8");
         if (o.field == &Options::split && value == 3) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: split must be 0, 1, 2 or 4");
@@ -538,6 +550,7 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, plan.qb, st)
+                   : sel.which == 'P' ? fa::launch_fwd_pp(p, dtype, st)
                    : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves / sel.split, plan.qb, sel.split, sel.pair, st)
                                       : fa::launch_fwd_tile(p, dtype, plan.waves, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

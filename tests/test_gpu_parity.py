@@ -273,6 +273,61 @@ def test_pipelined_kernel_on_16x16x32_mfma_head_dim_64(knobs, dtype, scale, G, L
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("causal", [1, 0])
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 64 ** -0.5), (torch.float16, 64 ** -0.5)])
+@pytest.mark.parametrize("G,L", [(1, 32), (2, 64), (3, 100), (2, 257), (17, 300), (2, 1000), (1, 4608), (9, 600), (16, 2049), (5, 1024)])
+def test_ping_pong_kernel_head_dim_64(knobs, dtype, scale, G, L, causal):
+    """fa_fwd_pp_kernel (fa_fwd_pp.hip: 512-thread workgroups = two 256-row halves, the two waves of a SIMD in complementary matrix /
+    vector phases): out and logsumexp against the oracle - one step only, ragged last steps, waves without rows, odd group counts
+    (a half without a group of its own), group counts that leave XCD classes empty, causal and unmasked."""
+    _, native, _ = _mods()
+    from oracle import dense_attention_lse, frozen_randn
+
+    knobs.set("kernel", "pp")
+    p = native.plan(G, L, 64, dtype, 1, 1, softmax_scale=scale, causal=causal)
+    assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (5, 8, 2, 256, 32)
+    assert p.grid == 8 * (((G + 7) // 8 + 1) // 2) * ((L + 255) // 256)
+    x = frozen_randn(SEED + 19 * L + G, (3, G, L, 64)).to(dtype)
+    if causal:
+        ref, ref_lse = _oracle(x, scale=scale)
+    else:
+        ref, ref_lse = dense_attention_lse(x[0][None], x[1][None], x[2][None], scale=scale, causal=False)
+        ref, ref_lse = ref[0], ref_lse[0]
+    q, k, v = x.cuda()
+    out = torch.full_like(q, float("nan"))
+    lse = torch.full((G, L), float("nan"), device="cuda", dtype=torch.float32)
+    st = (L * 64, 0, 64)
+    native.fwd_strided(q, k, v, out, lse, G, L, 64, 1, st, st, st, st, 1, 1, scale, causal=causal)
+    _check(out, ref, dtype, f"pp {dtype} scale={scale:.3g} causal={causal} {G}x{L}x64")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
+def test_ping_pong_growing_logits_force_the_exact_pass(knobs, dtype, step):
+    """The optimistic pass of fa_fwd_pp_kernel must detect a P that left the safe range and redo the workgroup (both halves) through
+    its exact pass (cdna guide rule 26: force the rare branch).  Group 0 keeps small logits: its half is dragged through the
+    exact pass by its partner and must come out right too."""
+    _, native, with_lse = _mods()
+    from oracle import frozen_randn
+
+    knobs.set("kernel", "pp")
+    knobs.set("skipmax", 1)
+    G, L, D = 18, 1024, 64
+    x = frozen_randn(SEED + 57, (3, G, L, D)) * 0.05
+    u = torch.zeros(D)
+    u[:4] = 1.0
+    tile = torch.arange(L) // 64
+    x[0] += u
+    x[1, 8:] += u[None, None, :] * (step / 4.0) * tile[None, :, None]      # groups 8 .. 17 grow, groups 0 .. 7 (their partners) do not
+    x = x.to(dtype)
+    assert native.plan(G, L, D, dtype, 1, 1).kernel == 5
+    ref, ref_lse = _oracle(x)
+    out, lse = with_lse(x.cuda(), 1, 1)
+    _check(out, ref, dtype, f"pp growing logits step={step}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
+
+
 @pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
 @pytest.mark.parametrize("D,qb", [(128, 1), (64, 1), (64, 2)])
 def test_pipe16_growing_logits_force_the_exact_pass(knobs, step, D, qb):
