@@ -192,6 +192,22 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+    // EXTRA: the raw mask data of a 32-key half are requested ONE TILE AHEAD, into the registers the same half of the current tile has
+    // just decoded (a mask row is global memory nobody else has touched: requested when its scores exist, its latency sits between
+    // the score MFMAs and the exponentials of every half tile).  Aligned full tiles only; anything else is loaded in place.
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 mq[EXTRA ? 8 : 1];
+    (void)mq;
+#define FA_DQ_MASK_PF(T_, HB_)                                                                     \
+    if constexpr (EXTRA) {                                                                         \
+        if (mrow != nullptr && p.ex.mask_vec != 0 && (T_) < n_tiles && (T_) * BK + BK <= L) {      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
+                const int k0_ = (T_) * BK + 32 * (HB_) + 8 * j + 4 * h;                            \
+                if (p.ex.mask_kind == 2) mq[4 * (HB_) + j] = *(const u32x2*)(mrow + (int64_t)k0_ * 2); \
+                else mq[4 * (HB_) + j].x = *(const unsigned*)(mrow + k0_);                         \
+            }                                                                                      \
+        }                                                                                          \
+    }
 
 #ifndef FA_BWD_HALVES
 #define FA_BWD_HALVES 1   /* 1: a 64-row (dK/dV) / 64-key (dQ) tile is consumed as two 32-wide halves one after the other: one score and
@@ -218,11 +234,24 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
                 if constexpr (EXTRA) {                                                             \
                     if (mrow != nullptr) {                                                         \
                         const bool fast_ = p.ex.mask_vec != 0 && kv0 + BK <= L;                    \
-                        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                            \
-                            float a_[4];                                                           \
-                            mask_load4<T>(p.ex.mask_kind, fast_, mrow, kv0 + 32 * hb + 8 * j + 4 * h, L, p.ex.inv_scale, a_); \
-                            _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += a_[i];  \
+                        if (fast_) {   /* requested one tile ago */                                \
+                            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                        \
+                                if (p.ex.mask_kind == 2) {                                         \
+                                    const vec4 b_ = __builtin_bit_cast(vec4, mq[4 * hb + j]);      \
+                                    _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += (float)b_[i] * p.ex.inv_scale; \
+                                } else {                                                           \
+                                    const unsigned w_ = mq[4 * hb + j].x;                          \
+                                    _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += ((w_ >> (8 * i)) & 0xffu) ? 0.f : -INFINITY; \
+                                }                                                                  \
+                            }                                                                      \
+                        } else {                                                                   \
+                            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                        \
+                                float a_[4];                                                       \
+                                mask_load4<T>(p.ex.mask_kind, false, mrow, kv0 + 32 * hb + 8 * j + 4 * h, L, p.ex.inv_scale, a_); \
+                                _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += a_[i]; \
+                            }                                                                      \
                         }                                                                          \
+                        FA_DQ_MASK_PF((T_) + 1, hb)                                                \
                     }                                                                              \
                 }                                                                                  \
                 if (kv0 + 32 * hb + 31 > wave_last) {                                              \
@@ -317,6 +346,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     // ring of NB buffers: tile t lives in buffer t % NB; at the top of tile t the DMA for tile t + NB - 1 goes out (its buffer
     // was released by the barrier that ended tile t - 1); at the end of tile t only that newest DMA may still be in flight
     fa_static_for<0, NB - 1>([&](auto bi_) { constexpr int b_ = decltype(bi_)::value; if (b_ < n_tiles) FA_DMA_KV(b_, b_) });
+    if (wave_active) { FA_DQ_MASK_PF(0, 0) FA_DQ_MASK_PF(0, 1) }
     FA_TILE_BARRIER()
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));   // row operands landed
@@ -338,6 +368,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 #undef FA_DMA_KV
 #undef FA_TILE_BARRIER
 #undef FA_DQ_TILE
+#undef FA_DQ_MASK_PF
 
     if (!wave_active || qrow >= L) return;
     T* __restrict__ og = (T*)p.dq + (int64_t)bb * p.dq_sb + (int64_t)hh * p.dq_sh + (int64_t)qrow * p.dq_sl;
@@ -482,6 +513,22 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
     float rc_stage = 0.f;
+    // EXTRA: the raw mask elements of a 32-row half of the NEXT item (this lane's key, the 16 query rows its registers hold) are
+    // requested one item ahead, into the registers the same half of the current item has just decoded (see the dQ kernel)
+    unsigned mkv[EXTRA ? 32 : 1];
+    (void)mkv;
+#define FA_KV_MASK_PF(J_, HB_)                                                                     \
+    if constexpr (EXTRA) {                                                                         \
+        if (p.ex.mask != nullptr && wave_active && (J_) < n_items) {                               \
+            FA_ITEM(J_, hqp_, itp_)                                                                \
+            const char* mbp_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqp_) * p.ex.m_sh) * mask_esz; \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                       \
+                const int qq_ = itp_ * BQ + 32 * (HB_) + (e & 3) + 8 * (e >> 2) + 4 * h;           \
+                const int64_t off_ = (int64_t)(qq_ < L ? qq_ : L - 1) * p.ex.m_sl + kr;            \
+                mkv[16 * (HB_) + e] = p.ex.mask_kind == 2 ? (unsigned)((const unsigned short*)mbp_)[off_] : (unsigned)((const unsigned char*)mbp_)[off_]; \
+            }                                                                                      \
+        }                                                                                          \
+    }
 
 #if FA_BWD_HALVES
 #define FA_DKDV_TILE(J_, BUF_)                                                                     \
@@ -494,7 +541,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
             const float* rc_ = rowc + (BUF_) * 128;                                                \
             _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {       /* query rows q0 + 32 hb .. +31 */ \
-                if (causal && q0 + 32 * hb + 31 < key0) continue;    /* every query of this half lies before the wave's keys */ \
+                if (causal && q0 + 32 * hb + 31 < key0) { FA_KV_MASK_PF((J_) + 1, hb) continue; }   /* every query of this half lies before the wave's keys */ \
                 f32x16 s0, t0;                                                                     \
                 /* dP accumulators start at -Dsum[q] (rowc holds the negated sums) */              \
                 _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                 \
@@ -506,12 +553,13 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                     t0 = E::mfma(*(const vec8*)(gb_ + 2048 * hb + a_rd[ks]), vf[ks], t0);          \
                 }                                                                                  \
                 if constexpr (EXTRA) {                                                             \
-                    if (p.ex.mask != nullptr) {   /* mask[row][this lane's key], one row per register */ \
-                        const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqt_) * p.ex.m_sh) * mask_esz; \
+                    if (p.ex.mask != nullptr) {   /* mask[row][this lane's key], one row per register: requested one item ago */ \
                         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                           \
-                            const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;          \
-                            s0[e] += mask_load1<T>(p.ex.mask_kind, mb_, (int64_t)(qq < L ? qq : L - 1) * p.ex.m_sl, kr, p.ex.inv_scale); \
+                            const unsigned w_ = mkv[16 * hb + e];                                  \
+                            if (p.ex.mask_kind == 2) s0[e] += (float)__builtin_bit_cast(T, (unsigned short)w_) * p.ex.inv_scale; \
+                            else s0[e] += w_ ? 0.f : -INFINITY;                                    \
                         }                                                                          \
+                        FA_KV_MASK_PF((J_) + 1, hb)                                                \
                     }                                                                              \
                 }                                                                                  \
                 if (causal && q0 + 32 * hb < key0 + 31) { /* diagonal: query < key is masked */    \
@@ -570,6 +618,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                     }                                                                              \
                 }                                                                                  \
             }                                                                                      \
+        } else {                                                                                   \
+            FA_KV_MASK_PF((J_) + 1, 0) FA_KV_MASK_PF((J_) + 1, 1)                                  \
         }                                                                                          \
     }
 #else
@@ -659,6 +709,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             FA_ROWC_STORE(b_)
         }
     });
+    FA_KV_MASK_PF(0, 0) FA_KV_MASK_PF(0, 1)
     lds_dma_wait_all();
     __syncthreads();
 #pragma unroll
@@ -687,6 +738,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #undef FA_ROWC_LOAD
 #undef FA_ROWC_STORE
 #undef FA_DKDV_TILE
+#undef FA_KV_MASK_PF
 
     if (!wave_active || key >= L) return;
     T* __restrict__ dkg = (T*)p.dk + (int64_t)bb * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)key * p.dk_sl;

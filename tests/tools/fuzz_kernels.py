@@ -61,6 +61,7 @@ def fuzz(cases, seed, log=print):
           variants.append({"kernel": "pipe16", "waves": rng.choice([4, 8]), "sched": rng.choice([1, 2, 8])})
       else:             # 32 or 64 query rows per wave at head_dim 64
           variants.append({"kernel": "pipe16", "waves": 4, "qb": rng.choice([1, 2]), "sched": rng.choice([1, 2, 8])})
+          variants.append({"kernel": "pp", "sched": rng.choice([1, 2, 8])})      # 512-thread workgroups of two halves in complementary phases
       variants.append({"split": 2 if D == 128 else rng.choice([2, 4]), "sched": rng.choice([1, 2, 8])})   # kv split groups (dma kernel)
       if only is not None and case != int(only):
           continue
