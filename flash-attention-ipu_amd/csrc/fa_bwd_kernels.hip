@@ -80,7 +80,9 @@ __device__ __forceinline__ bool bwd_block_map(int G8, int G, int sched, int nblk
 // EXTRA: the forward ran with an attention mask / bias and / or dropout (fa_extras.h): the same additive terms go onto the recomputed
 // scores, the dropout decisions are regenerated from (seed, offset, g, row, col):  dP = keep ? dP_raw / (1 - p) : 0  before
 // dS = P o (dP - Dsum)  (Dsum = rowsum(dO o O) still equals sum_j P_j dP_j);  dV sees  keep ? P / (1 - p) : 0.
-template <typename T, int D, int NWAVES, bool EXTRA = false>
+// EXTRA: 0 plain, 1 mask / dropout with the mask loaded in place, 2 the same with the mask's raw data requested one tile ahead (masks
+// that differ from row to row: [.., L, L]; a key-padding or key-bias row is cache-resident and gains nothing from 8 - 32 more registers)
+template <typename T, int D, int NWAVES, int EXTRA = 0>
 __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -196,10 +198,10 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     // just decoded (a mask row is global memory nobody else has touched: requested when its scores exist, its latency sits between
     // the score MFMAs and the exponentials of every half tile).  Aligned full tiles only; anything else is loaded in place.
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 mq[EXTRA ? 8 : 1];
+    u32x2 mq[EXTRA == 2 ? 8 : 1];
     (void)mq;
 #define FA_DQ_MASK_PF(T_, HB_)                                                                     \
-    if constexpr (EXTRA) {                                                                         \
+    if constexpr (EXTRA == 2) {                                                                    \
         if (mrow != nullptr && p.ex.mask_vec != 0 && (T_) < n_tiles && (T_) * BK + BK <= L) {      \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
                 const int k0_ = (T_) * BK + 32 * (HB_) + 8 * j + 4 * h;                            \
@@ -234,7 +236,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
                 if constexpr (EXTRA) {                                                             \
                     if (mrow != nullptr) {                                                         \
                         const bool fast_ = p.ex.mask_vec != 0 && kv0 + BK <= L;                    \
-                        if (fast_) {   /* requested one tile ago */                                \
+                        if (EXTRA == 2 && fast_) {   /* requested one tile ago */                  \
                             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                        \
                                 if (p.ex.mask_kind == 2) {                                         \
                                     const vec4 b_ = __builtin_bit_cast(vec4, mq[4 * hb + j]);      \
@@ -247,7 +249,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
                         } else {                                                                   \
                             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                        \
                                 float a_[4];                                                       \
-                                mask_load4<T>(p.ex.mask_kind, false, mrow, kv0 + 32 * hb + 8 * j + 4 * h, L, p.ex.inv_scale, a_); \
+                                mask_load4<T>(p.ex.mask_kind, fast_, mrow, kv0 + 32 * hb + 8 * j + 4 * h, L, p.ex.inv_scale, a_); \
                                 _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += a_[i]; \
                             }                                                                      \
                         }                                                                          \
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dq_kernel(const BwdParams 
 // ---------------------------------------------------------------------------------------------
 // dK, dV: one workgroup = NWAVES x 32 keys; streams Q and dO tiles of 64 query rows
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int NWAVES, bool EXTRA = false>
+template <typename T, int D, int NWAVES, int EXTRA = 0>
 __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -515,10 +517,10 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     float rc_stage = 0.f;
     // EXTRA: the raw mask elements of a 32-row half of the NEXT item (this lane's key, the 16 query rows its registers hold) are
     // requested one item ahead, into the registers the same half of the current item has just decoded (see the dQ kernel)
-    unsigned mkv[EXTRA ? 32 : 1];
+    unsigned mkv[EXTRA == 2 ? 32 : 1];
     (void)mkv;
 #define FA_KV_MASK_PF(J_, HB_)                                                                     \
-    if constexpr (EXTRA) {                                                                         \
+    if constexpr (EXTRA == 2) {                                                                    \
         if (p.ex.mask != nullptr && wave_active && (J_) < n_items) {                               \
             FA_ITEM(J_, hqp_, itp_)                                                                \
             const char* mbp_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqp_) * p.ex.m_sh) * mask_esz; \
@@ -553,13 +555,21 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                     t0 = E::mfma(*(const vec8*)(gb_ + 2048 * hb + a_rd[ks]), vf[ks], t0);          \
                 }                                                                                  \
                 if constexpr (EXTRA) {                                                             \
-                    if (p.ex.mask != nullptr) {   /* mask[row][this lane's key], one row per register: requested one item ago */ \
-                        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                           \
-                            const unsigned w_ = mkv[16 * hb + e];                                  \
-                            if (p.ex.mask_kind == 2) s0[e] += (float)__builtin_bit_cast(T, (unsigned short)w_) * p.ex.inv_scale; \
-                            else s0[e] += w_ ? 0.f : -INFINITY;                                    \
+                    if (p.ex.mask != nullptr) {   /* mask[row][this lane's key], one row per register */ \
+                        if constexpr (EXTRA == 2) {   /* requested one item ago */                 \
+                            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                       \
+                                const unsigned w_ = mkv[16 * hb + e];                              \
+                                if (p.ex.mask_kind == 2) s0[e] += (float)__builtin_bit_cast(T, (unsigned short)w_) * p.ex.inv_scale; \
+                                else s0[e] += w_ ? 0.f : -INFINITY;                                \
+                            }                                                                      \
+                            FA_KV_MASK_PF((J_) + 1, hb)                                            \
+                        } else {                                                                   \
+                            const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqt_) * p.ex.m_sh) * mask_esz; \
+                            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                       \
+                                const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;      \
+                                s0[e] += mask_load1<T>(p.ex.mask_kind, mb_, (int64_t)(qq < L ? qq : L - 1) * p.ex.m_sl, kr, p.ex.inv_scale); \
+                            }                                                                      \
                         }                                                                          \
-                        FA_KV_MASK_PF((J_) + 1, hb)                                                \
                     }                                                                              \
                 }                                                                                  \
                 if (causal && q0 + 32 * hb < key0 + 31) { /* diagonal: query < key is masked */    \

@@ -46,7 +46,9 @@ namespace fa {
 //
 // EXTRA: attention mask / additive bias and dropout (fa_extras.h), exact-max arithmetic only (a mask can hide every key of a
 // tile from a row, so the fixed reference max of the skip-max mode has nothing to stand on); instantiated in fa_fwd_extra.hip.
-template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT, bool PAIR, bool EXTRA = false>
+// MPRE (EXTRA only): a mask that differs from row to row has the raw data of the NEXT tile requested one tile ahead (16 more registers,
+// which a key-padding row - cache-resident - or a dropout-only launch would pay for nothing: measured +6 % on those).
+template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT, bool PAIR, bool EXTRA = false, bool MPRE = false>
 __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     static_assert(!EXTRA || !SKIP, "mask / dropout launches use the exact-max arithmetic");
     using E = Elt<T>;
@@ -122,7 +124,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // a mask row is global memory nobody else has touched - its latency then runs under this tile's softmax and PV product, the barrier
     // and the next tile's QK^T instead of sitting between QK^T and the softmax
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 mraw[EXTRA ? 8 : 1];
+    u32x2 mraw[(EXTRA && MPRE) ? 8 : 1];
     bool mpre_ok = false;
     (void)mraw; (void)mpre_ok;
 
@@ -221,7 +223,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 
     // EXTRA: request the raw mask data of tile T_ (aligned full tiles only; anything else is loaded in place when its scores exist)
 #define FA_MASK_PREFETCH(T_)                                                                 \
-    if constexpr (EXTRA) {                                                                         \
+    if constexpr (EXTRA && MPRE) {                                                                 \
         if (mask_g != nullptr) {                                                                   \
             const int kvp_ = (T_) * BK;                                                            \
             const bool ok_ = p.ex.mask_vec != 0 && wave_active && (T_) < n_tiles && kvp_ + BK <= L && kvp_ <= wave_kv_last;   \
@@ -257,7 +259,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             }                                                                                      \
         }                                                                                          \
         if constexpr (EXTRA) {                                                                     \
-            if (mask_g != nullptr && mpre_ok) {   /* prefetched raw data of this tile (QB == 1) */ \
+            if (MPRE && mask_g != nullptr && mpre_ok) {   /* prefetched raw data of this tile (QB == 1) */ \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
                     if (p.ex.mask_kind == 2) {                                                     \
                         const vec4 b0_ = __builtin_bit_cast(vec4, mraw[j]), b1_ = __builtin_bit_cast(vec4, mraw[4 + j]); \

@@ -8,18 +8,22 @@
 
 namespace fa {
 
-template <typename T, int D>
+// MPRE: the mask's raw data requested one tile ahead - for masks that differ from row to row (fa_fwd_dma.hip)
+template <typename T, int D, bool MPRE>
 __global__ __launch_bounds__(256) void fa_fwd_extra_kernel(const FwdParams p) {
-    fa_fwd_dma_body<T, D, 4, false, 1, 1, false, true>(p);
+    fa_fwd_dma_body<T, D, 4, false, 1, 1, false, true, MPRE>(p);
+}
+
+template <typename T, int D>
+static hipError_t launch_fwd_extra_t(const FwdParams& p, hipStream_t stream) {
+    const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles)), block(256);
+    return (p.ex.mask != nullptr && p.ex.m_sl != 0) ? launch1((const void*)(fa_fwd_extra_kernel<T, D, true>), grid, block, 0, stream, p)
+                                                    : launch1((const void*)(fa_fwd_extra_kernel<T, D, false>), grid, block, 0, stream, p);
 }
 
 hipError_t launch_fwd_extra(const FwdParams& p, int dtype, hipStream_t stream) {
-    const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles)), block(256);
-    if (dtype == 1)
-        return p.D == 64 ? launch1((const void*)(fa_fwd_extra_kernel<__bf16, 64>), grid, block, 0, stream, p)
-                         : launch1((const void*)(fa_fwd_extra_kernel<__bf16, 128>), grid, block, 0, stream, p);
-    return p.D == 64 ? launch1((const void*)(fa_fwd_extra_kernel<_Float16, 64>), grid, block, 0, stream, p)
-                     : launch1((const void*)(fa_fwd_extra_kernel<_Float16, 128>), grid, block, 0, stream, p);
+    if (dtype == 1) return p.D == 64 ? launch_fwd_extra_t<__bf16, 64>(p, stream) : launch_fwd_extra_t<__bf16, 128>(p, stream);
+    return p.D == 64 ? launch_fwd_extra_t<_Float16, 64>(p, stream) : launch_fwd_extra_t<_Float16, 128>(p, stream);
 }
 
 }  // namespace fa
