@@ -37,7 +37,7 @@ int elt_size(int dtype) { return dtype == FA_DTYPE_F32 ? 4 : 2; }
 // either the old or the new value of one knob and never a torn one; fa_plan() and fa_fwd() go through the same
 // make_plan(), so a reported plan is the launched plan.
 struct Options {
-    std::atomic<int> kernel{0};     // 0 auto, 'd' | 'p' | 'x' | 't' | 'P'
+    std::atomic<int> kernel{0};     // 0 auto, 'd' | 'p' | 'x' | 't' | 'P' | 'h'
     std::atomic<int> qb{0};         // 0 auto, 1 | 2 query blocks per wave
     std::atomic<int> waves{0};      // 0 auto, 1 | 2 | 4 | 8
     std::atomic<int> sched{0};      // 0 auto, else groups per L2 bunch
@@ -47,6 +47,8 @@ struct Options {
     std::atomic<int> split{0};      // 0 auto, 1 | 2 | 4 kv split groups per workgroup (fa_fwd_dma.hip)
     std::atomic<int> pair{-1};      // -1 auto, 0 | 1 q-tile pairs per workgroup (fa_fwd_dma.hip, causal)
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
+    std::atomic<int> khsplit{0};    // 'h' kernel: 0 auto, 1 | 2 key splits of a tile (128- | 64-row workgroups)
+    std::atomic<int> nb{0};         // 'h' kernel: 0 auto, 2 | 3 tile buffers per operand
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -57,6 +59,7 @@ std::atomic<int64_t> g_stamp_bytes{0};
 int parse_kernel(const char* v) {   // dma | pipe | pipe16 | pp | tile
     if (!v) return 0;
     if (strcmp(v, "pp") == 0 || v[0] == 'P') return 'P';
+    if (strcmp(v, "kh") == 0 || v[0] == 'h') return 'h';
     if (strcmp(v, "pipe16") == 0 || v[0] == 'x') return 'x';
     return (v[0] == 't' || v[0] == 'd' || v[0] == 'p') ? v[0] : 0;
 }
@@ -73,6 +76,8 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_TABLE")) { if (*e) g_opt.table = atoi(e); }
         if (const char* e = getenv("FA_AMD_PAIR")) { if (*e) g_opt.pair = atoi(e); }
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
+        if (const char* e = getenv("FA_AMD_KHSPLIT")) g_opt.khsplit = atoi(e);
+        if (const char* e = getenv("FA_AMD_NB")) g_opt.nb = atoi(e);
     });
     return g_opt;
 }
@@ -106,6 +111,8 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 //       head_dim 64 with 4 waves and qb 1 | 2
 //   'P' fa_fwd_pp_kernel    the 32-key-step kernel with the two waves of a SIMD in complementary phases (fa_fwd_pp.hip): head_dim 64,
 //       512-thread workgroups = two 256-row halves (the same q tile of two groups), skip-max arithmetic only
+//   'h' fa_fwd_kh_kernel    64-row workgroups, every wave = (row block, key half) of the streamed 64-key tiles (fa_fwd_kh.hip): half the
+//       dependency chain per tile - for causal launches bound by their heaviest workgroup's kv loop (grids of about one round of slots)
 //   't' fa_fwd_tile_kernel  register-staged A/B baseline (debug override only)
 // qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
 // split = kv split groups of a 'd' workgroup (4 waves x 32 rows each, all on the same 128 query rows; fa_fwd_dma.hip): for
@@ -114,9 +121,10 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 // kernels' own constraints are enforced on whatever was picked.
 struct Selection {
     fa_plan_t plan;
-    char which;      // 'd' | 'p' | 'x' | 'P' | 't' | 'g' generic | 'f' fp32 MFMA
+    char which;      // 'd' | 'p' | 'x' | 'P' | 'h' | 't' | 'g' generic | 'f' fp32 MFMA
     int split;       // kv split groups per workgroup ('d' only; plan.waves counts all of the workgroup's waves)
     int pair;        // 'd' only: 1 = a workgroup owns q tiles (nq - 1 - i) and i, one after the other
+    int kh, nb;      // 'h' only: key splits of a tile (1 | 2), tile buffers per operand (2 | 3)
     int perm_n;      // 'd' only: > 0 = placement-balanced order of the XCD's first perm_n slots
     uint8_t perm[128];
 };
@@ -169,6 +177,8 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     sel->split = 1;
     sel->pair = 0;
     sel->perm_n = 0;
+    sel->kh = 2;
+    sel->nb = 2;
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
     const int64_t g8 = (G + 7) / 8 * 8;
@@ -192,6 +202,10 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         // a grid of at most 512 128-row workgroups leaves CUs idle or at one workgroup each: split every q tile's kv loop over
         // 2 | 4 wave groups of the same workgroup (measured: G=8 L=4096 394 -> 514, G=8 L=8192 754 -> 883, G=4 L=8192 D=128 458 -> 512)
         if (waves == 4 && cq >= 128 && L >= 1024 && g8 * ((L + 127) / 128) <= 512) split = (D == 64 && L >= 2048) ? 4 : 2;
+        // ... and at head_dim 64 up to L = 2048 the 64-row workgroups with (row block, key half) waves do better still: same slots, twice the
+        // workgroups, half the chain per tile (measured, profiles/r03_kh: G=12..64 L=1024 +10..17 %, G=8..32 L=2048 +10..22 % over the split plans;
+        // L = 4096: level with 4 split groups; 768 workgroups and more: slower than the 128-row workgroups)
+        if (D == 64 && waves == 4 && cq >= 128 && !want32 && L >= 1024 && L <= 2048 && g8 * ((L + 127) / 128) <= 512) { which = 'h'; split = 1; }
         // ---- measured table
         if (opt.table) {
             const int64_t wgs128 = g8 * ((L + 127) / 128);
@@ -215,6 +229,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
         else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && D == 128) ? 8 : 4; if (!fq) qb = 1; }
         else if (fk == 'P' && pipe_ok && D == 64) { which = 'P'; waves = 4; qb = 2; }
+        else if (fk == 'h') { which = 'h'; waves = 4; qb = 1; }
         else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
         if (fq == 1) qb = 1;
         if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
@@ -227,6 +242,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (which == 'x' && !pipe_ok) which = 'd';
         if (which == 'P' && !(pipe_ok && D == 64)) which = 'd';
         if (which == 'P') { waves = 4; qb = 2; split = 1; }
+        if (which == 'h') { waves = 4; qb = 1; split = 1; }
         if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
         if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
         if (which == 't' && waves > 4) waves = 4;
@@ -266,7 +282,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
                 sel->perm_n = balanced_order((int)(ng * nitem), weight, sel->perm);
             }
         }
-        plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : which == 'P' ? 5 : 0;
+        plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : which == 'P' ? 5 : which == 'h' ? 6 : 0;
         plan->pair = pair;
         plan->balanced = sel->perm_n > 0;
         plan->waves = waves * split;
@@ -277,6 +293,16 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         plan->source = source;
         plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
         if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
+        if (which == 'h') {   // 4 waves = (4 / kh) row blocks x kh key splits: 64- | 128-row workgroups; nb tile buffers per operand
+            int kh = 2, nb = 2;
+            if (opt.khsplit == 1 && D == 64) kh = 1;
+            if (kh == 1) nb = 3;                              // (the 128-row shape exists with a ring of three only)
+            if (opt.nb == 3) nb = 3;
+            sel->kh = kh;
+            sel->nb = nb;
+            plan->block_q = 128 / kh;
+            plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
+        }
         if (which == 'P') {   // one workgroup = 8 waves = two 256-row halves: the same q tile of two groups of one XCD class
             plan->waves = 8;
             plan->grid = 8 * ((g8 / 8 + 1) / 2) * ((L + 255) / 256);
@@ -284,7 +310,8 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         plan->lds_bytes = which == 'P' ? 2 * (4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64)) + 32
                           : which == 'x' ? 8 * 32 * D * 2 + 16
                           : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
-                                       : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
+                                       : which == 'h' ? sel->nb * (64 * D * 2 + (D / 32) * (64 * 64 + 64)) + 16
+                                         : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
         // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
         // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
         {
@@ -337,7 +364,7 @@ const OptionName kOptionNames[] = {
     {"kernel", &Options::kernel, 0, 127}, {"qb", &Options::qb, 0, 2}, {"waves", &Options::waves, 0, 8},
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
-    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1},
+    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"khsplit", &Options::khsplit, 0, 2}, {"nb", &Options::nb, 0, 3},
 };
 
 }  // namespace
@@ -376,8 +403,8 @@ int fa_debug_set_option(const char* name, int32_t value) {
     for (const OptionName& o : kOptionNames) {
         if (strcmp(o.name, name) != 0) continue;
         if (value < o.lo || value > o.hi) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: %s=%d out of range [%d, %d]", name, value, o.lo, o.hi);
-        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 't' || value == 'P'))
-            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x', 'P' or 't'");
+        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 't' || value == 'P' || value == 'h'))
+            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x', 'P', 'h' or 't'");
         if (o.field == &Options::waves && !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: waves must be 0, 1, 2, 4 or 8");
         if (o.field == &Options::split && value == 3) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: split must be 0, 1, 2 or 4");
@@ -551,6 +578,7 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'P' ? fa::launch_fwd_pp(p, dtype, st)
+                   : sel.which == 'h' ? fa::launch_fwd_kh(p, dtype, sel.kh, sel.nb, st)
                    : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves / sel.split, plan.qb, sel.split, sel.pair, st)
                                       : fa::launch_fwd_tile(p, dtype, plan.waves, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

@@ -82,7 +82,8 @@ typedef struct fa_plan_t {
                             3 = fp32 MFMA kernel (fp32 inputs, D in {64,128}, 16-byte rows),
                             4 = software-pipelined kernel on v_mfma_f32_16x16x32 (bf16/f16, D in {64,128}),
                             5 = 32-key steps with the two waves of a SIMD in complementary matrix / vector phases (bf16/f16, D = 64):
-                                a workgroup of 8 waves = two halves of block_q rows each, the same q tile of two groups */
+                                a workgroup of 8 waves = two halves of block_q rows each, the same q tile of two groups,
+                            6 = 64-key tiles, 64-row workgroups whose 4 waves are (row block, key half) pairs (bf16/f16, D in {64,128}) */
     int32_t block_q;     /* q rows per workgroup */
     int32_t block_kv;    /* keys per LDS tile / step */
     int32_t waves;       /* wavefronts per workgroup; waves * qb * 32 / block_q = kv split groups of the workgroup (1, or 2 | 4

@@ -90,6 +90,8 @@ def candidates(G, L, D, skip, causal, scheds=True):
     if wg128 <= 2048 and L >= 256:        # under-filled grids: kv split groups inside the dma kernel's workgroup
         for sp in ((2, 4) if D == 64 else (2,)):
             out.append({"kernel": "dma", "qb": 1, "waves": 4, "sched": auto, "split": sp})
+    if wg128 <= 2048 and L >= 256:        # ... and 64-row workgroups whose waves are (row block, key half) pairs (fa_fwd_kh.hip)
+        out.append({"kernel": "kh", "qb": 1, "waves": 4, "sched": auto})
     if D == 64 and skip and L >= 256:     # ... at head_dim 64: 4 waves x 32 or 64 rows
         for qb in (1, 2):
             for b in bunches:
@@ -185,7 +187,7 @@ def emit(args):
                 ok, wins = beats_rules(best, 0)
                 verdict = f"beats the rules' choice ({shape.flops / med[0] / 1e9:.0f}) by >= 2 % in {wins} of {len(LAST_ROUNDS[0])} rounds"
                 if ok:
-                    rows.append((D, skip, causal, L_lo, L_hi, wg, {"dma": "d", "pipe": "p", "pipe16": "x"}[c["kernel"]], c["waves"], c["qb"], sched, L, G,
+                    rows.append((D, skip, causal, L_lo, L_hi, wg, {"dma": "d", "pipe": "p", "pipe16": "x", "kh": "h"}[c["kernel"]], c["waves"], c["qb"], sched, L, G,
                                  shape.flops / med[best] / 1e9, c.get("split", 1), c.get("pair", 0), shape.flops / med[0] / 1e9))
                 log.append(f"D={D} skip={skip} causal={causal} L={L} G={G} wg128={wg}: {c} sched->{sched}  "
                            f"{shape.flops / med[best] / 1e9:.0f} TFLOP/s; {verdict}: {'ROW' if ok else 'no row (the rules decide)'}")

@@ -328,6 +328,60 @@ def test_ping_pong_growing_logits_force_the_exact_pass(knobs, dtype, step):
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
 
 
+@pytest.mark.parametrize("causal", [1, 0])
+@pytest.mark.parametrize("D,dtype,scale", [(64, torch.bfloat16, 1.0), (64, torch.bfloat16, 64 ** -0.5), (64, torch.float16, 1.0), (64, torch.float16, 64 ** -0.5),
+                                           (128, torch.bfloat16, 128 ** -0.5), (128, torch.float16, 1.0)])
+@pytest.mark.parametrize("G,L", [(1, 32), (2, 64), (3, 100), (2, 257), (17, 300), (2, 1000), (1, 4608), (9, 600), (5, 1024)])
+def test_key_halves_kernel(knobs, D, dtype, scale, G, L, causal):
+    """fa_fwd_kh_kernel (fa_fwd_kh.hip: 64-row workgroups, every wave = (row block, key half) of the streamed 64-key tiles, the two
+    halves' softmax statistics merged through LDS): out and logsumexp against the oracle - a single half tile, key halves that hold
+    nothing for a wave, ragged last tiles, waves without rows, both arithmetic modes (skip-max and per-tile max), causal and unmasked."""
+    _, native, _ = _mods()
+    from oracle import dense_attention_lse, frozen_randn
+
+    knobs.set("kernel", "kh")
+    p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale, causal=causal)
+    assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (6, 4, 1, 64, 64)
+    assert p.grid == ((G + 7) // 8 * 8) * ((L + 63) // 64)
+    x = frozen_randn(SEED + 23 * L + G + D, (3, G, L, D)).to(dtype)
+    if causal:
+        ref, ref_lse = _oracle(x, scale=scale)
+    else:
+        ref, ref_lse = dense_attention_lse(x[0][None], x[1][None], x[2][None], scale=scale, causal=False)
+        ref, ref_lse = ref[0], ref_lse[0]
+    q, k, v = x.cuda()
+    out = torch.full_like(q, float("nan"))
+    lse = torch.full((G, L), float("nan"), device="cuda", dtype=torch.float32)
+    st = (L * D, 0, D)
+    native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, scale, causal=causal)
+    _check(out, ref, dtype, f"kh {dtype} D={D} scale={scale:.3g} causal={causal} {G}x{L}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
+def test_key_halves_growing_logits_force_the_exact_pass(knobs, dtype, step):
+    """The optimistic pass of fa_fwd_kh_kernel must detect a P that left the safe range and redo the workgroup through its exact pass."""
+    _, native, with_lse = _mods()
+    from oracle import frozen_randn
+
+    knobs.set("kernel", "kh")
+    knobs.set("skipmax", 1)
+    G, L, D = 2, 1024, 64
+    x = frozen_randn(SEED + 58, (3, G, L, D)) * 0.05
+    u = torch.zeros(D)
+    u[:4] = 1.0
+    tile = torch.arange(L) // 64
+    x[0] += u
+    x[1] += u[None, None, :] * (step / 4.0) * tile[None, :, None]
+    x = x.to(dtype)
+    assert native.plan(G, L, D, dtype, 1, 1).kernel == 6
+    ref, ref_lse = _oracle(x)
+    out, lse = with_lse(x.cuda(), 1, 1)
+    _check(out, ref, dtype, f"kh growing logits step={step}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
+
+
 @pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
 @pytest.mark.parametrize("D,qb", [(128, 1), (64, 1), (64, 2)])
 def test_pipe16_growing_logits_force_the_exact_pass(knobs, step, D, qb):

@@ -134,7 +134,7 @@ def test_measured_tuning_table_is_consulted_and_bounded_by_the_chunks(native):
             continue
         dt = torch.bfloat16 if skip == "1" else torch.float16
         p = native.plan(G, L, D, dt, 1, 1, causal=causal == "1")
-        assert p.source == 1 and (p.kernel, p.waves, p.qb, p.pair) == ({"p": 2, "x": 4, "d": 0}[kern], waves * split, qb, int(pair)), (D, skip, causal, L, G)
+        assert p.source == 1 and (p.kernel, p.waves, p.qb, p.pair) == ({"p": 2, "x": 4, "d": 0, "h": 6}[kern], waves * split, qb, int(pair)), (D, skip, causal, L, G)
         with native.debug_options(table=0):
             assert native.plan(G, L, D, dt, 1, 1, causal=causal == "1").source == 0
         checked += 1
@@ -174,8 +174,13 @@ def _check_builtin_rules(native):
     assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 128, 8, 2 * (2 * 16384 + 8 * (4096 + 64)))
     p = native.plan(8, 4096, 64, torch.bfloat16, 8, 8)
     assert (p.kernel, p.block_q, p.waves, p.grid) == (0, 128, 16, 8 * 32)
-    p = native.plan(8, 1024, 64, torch.bfloat16, 8, 8)
+    p = native.plan(8, 1024, 128, torch.bfloat16, 8, 8)
     assert (p.kernel, p.block_q, p.waves) == (0, 128, 8)
+    # ... and at head_dim 64 up to L = 2048 by 64-row workgroups whose four waves are (row block, key half) pairs (fa_fwd_kh.hip)
+    p = native.plan(8, 1024, 64, torch.bfloat16, 8, 8)
+    assert (p.kernel, p.block_q, p.block_kv, p.waves, p.grid, p.lds_bytes) == (6, 64, 64, 4, 8 * 16, 2 * 8192 + 4 * (4096 + 64))
+    assert native.plan(32, 2048, 64, torch.bfloat16, 8, 8).kernel == 6
+    assert native.plan(64, 2048, 64, torch.bfloat16, 8, 8).kernel == 0          # 1024 128-row workgroups: the ordinary tiles
     assert native.plan(4, 4096, 64, torch.float16, 64, 64).block_q == 64     # 64-row chunks honoured
     # num_chunks_kv bounds the kv step: a chunk below 64 keys is served by 32-key steps where the pipelined kernel
     # applies (skip-max arithmetic, causal); 64-key tiles otherwise (the result never depends on the chunking)
