@@ -224,6 +224,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         const int fk = opt.kernel, fw = opt.waves, fq = opt.qb, fs = opt.split;
         if (fk || fw || fq || fs || opt.sched > 0 || (dtype == FA_DTYPE_F16 && opt.skipmax >= 0)) source = 2;
         if (fk || fw || fq) { split = 1; table_pair = 0; } // (a forced tile drops the table's split / pairs unless forced too)
+        if ((fw || fq || fs > 1) && !fk && which == 'h') which = 'd';   // (the key-halves kernel has one tile shape: a forced tile leaves it)
         if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
         if (fk == 't') { which = 't'; qb = 1; }
         else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }

@@ -178,7 +178,7 @@ def _check_builtin_rules(native):
     assert (p.kernel, p.block_q, p.waves) == (0, 128, 8)
     # ... and at head_dim 64 up to L = 2048 by 64-row workgroups whose four waves are (row block, key half) pairs (fa_fwd_kh.hip)
     p = native.plan(8, 1024, 64, torch.bfloat16, 8, 8)
-    assert (p.kernel, p.block_q, p.block_kv, p.waves, p.grid, p.lds_bytes) == (6, 64, 64, 4, 8 * 16, 2 * 8192 + 4 * (4096 + 64))
+    assert (p.kernel, p.block_q, p.block_kv, p.waves, p.grid, p.lds_bytes) == (6, 64, 64, 4, 8 * 16, 2 * 8192 + 4 * (4096 + 64) + 16)
     assert native.plan(32, 2048, 64, torch.bfloat16, 8, 8).kernel == 6
     assert native.plan(64, 2048, 64, torch.bfloat16, 8, 8).kernel == 0          # 1024 128-row workgroups: the ordinary tiles
     assert native.plan(4, 4096, 64, torch.float16, 64, 64).block_q == 64     # 64-row chunks honoured
