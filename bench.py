@@ -301,7 +301,7 @@ def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
 
 def kernel_name(plan):
     return {0: "fa_fwd_dma_kernel", 1: "fa_fwd_generic_kernel", 2: "fa_fwd_pipe_kernel", 3: "fa_fwd_f32_kernel",
-            4: "fa_fwd_pipe16_kernel"}[plan.kernel]
+            4: "fa_fwd_pipe16_kernel", 5: "fa_fwd_pp_kernel", 6: "fa_fwd_kh_kernel"}[plan.kernel]
 
 
 def profiled_traffic(config, plan, kname=None):
