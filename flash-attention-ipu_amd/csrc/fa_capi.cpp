@@ -47,8 +47,6 @@ struct Options {
     std::atomic<int> split{0};      // 0 auto, 1 | 2 | 4 kv split groups per workgroup (fa_fwd_dma.hip)
     std::atomic<int> pair{-1};      // -1 auto, 0 | 1 q-tile pairs per workgroup (fa_fwd_dma.hip, causal)
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
-    std::atomic<int> khsplit{0};    // 'h' kernel: 0 auto, 1 | 2 key splits of a tile (128- | 64-row workgroups)
-    std::atomic<int> nb{0};         // 'h' kernel: 0 auto, 2 | 3 tile buffers per operand
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -76,8 +74,6 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_TABLE")) { if (*e) g_opt.table = atoi(e); }
         if (const char* e = getenv("FA_AMD_PAIR")) { if (*e) g_opt.pair = atoi(e); }
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
-        if (const char* e = getenv("FA_AMD_KHSPLIT")) g_opt.khsplit = atoi(e);
-        if (const char* e = getenv("FA_AMD_NB")) g_opt.nb = atoi(e);
     });
     return g_opt;
 }
@@ -124,7 +120,6 @@ struct Selection {
     char which;      // 'd' | 'p' | 'x' | 'P' | 'h' | 't' | 'g' generic | 'f' fp32 MFMA
     int split;       // kv split groups per workgroup ('d' only; plan.waves counts all of the workgroup's waves)
     int pair;        // 'd' only: 1 = a workgroup owns q tiles (nq - 1 - i) and i, one after the other
-    int kh, nb;      // 'h' only: key splits of a tile (1 | 2), tile buffers per operand (2 | 3)
     int perm_n;      // 'd' only: > 0 = placement-balanced order of the XCD's first perm_n slots
     uint8_t perm[128];
 };
@@ -177,8 +172,6 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     sel->split = 1;
     sel->pair = 0;
     sel->perm_n = 0;
-    sel->kh = 2;
-    sel->nb = 2;
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
     const int64_t g8 = (G + 7) / 8 * 8;
@@ -206,6 +199,9 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         // workgroups, half the chain per tile (measured, profiles/r03_kh: G=12..64 L=1024 +10..17 %, G=8..32 L=2048 +10..22 % over the split plans;
         // L = 4096: level with 4 split groups; 768 workgroups and more: slower than the 128-row workgroups)
         if (D == 64 && waves == 4 && cq >= 128 && !want32 && L >= 1024 && L <= 2048 && g8 * ((L + 127) / 128) <= 512) { which = 'h'; split = 1; }
+        // ... with two kv split groups on top where even the 64-row workgroups leave CUs idle (at most 256 128-row workgroups, L = 2048 .. 4096:
+        // G = 8 L = 2048 18.0 -> 15.5 us, G = 8 L = 4096 35.0 (4 split groups of 128-row workgroups) -> 30.5 us; L = 8192: the 128-row split plan stays)
+        if (D == 64 && waves == 4 && cq >= 128 && !want32 && L >= 2048 && L <= 4096 && g8 * ((L + 127) / 128) <= 256) { which = 'h'; split = 2; }
         // ---- measured table
         if (opt.table) {
             const int64_t wgs128 = g8 * ((L + 127) / 128);
@@ -237,17 +233,18 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         if (fq == 2 && fk == 'x' && D == 64) qb = 2;        // (a forced variant ignores the chunk bound, as the forced kernel does)
         if (fs == 1) split = 1;
         if (fs > 1 && (fk == 0 || fk == 'd')) { which = 'd'; waves = 4; qb = 1; split = fs; }
+        if (fs > 1 && fk == 'h') split = fs;
         // ---- constraints of the kernels
         if (want32 && pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
         if (which == 'p' && ((waves > 4 && D != 128) || !pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
         if (which == 'x' && !pipe_ok) which = 'd';
         if (which == 'P' && !(pipe_ok && D == 64)) which = 'd';
         if (which == 'P') { waves = 4; qb = 2; split = 1; }
-        if (which == 'h') { waves = 4; qb = 1; split = 1; }
+        if (which == 'h') { waves = 4; qb = 1; if (!(split == 1 || split == 2 || (split == 4 && D == 64))) split = 1; }
         if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
         if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
         if (which == 't' && waves > 4) waves = 4;
-        if (split > 1 && !(which == 'd' && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
+        if (split > 1 && !((which == 'd' || which == 'h') && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
         // ---- q-tile pairs and the placement-balanced order ('d', causal)
         int pair = 0;
         {
@@ -294,15 +291,9 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         plan->source = source;
         plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
         if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
-        if (which == 'h') {   // 4 waves = (4 / kh) row blocks x kh key splits: 64- | 128-row workgroups; nb tile buffers per operand
-            int kh = 2, nb = 2;
-            if (opt.khsplit == 1 && D == 64) kh = 1;
-            if (kh == 1) nb = 3;                              // (the 128-row shape exists with a ring of three only)
-            if (opt.nb == 3) nb = 3;
-            sel->kh = kh;
-            sel->nb = nb;
-            plan->block_q = 128 / kh;
-            plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
+        if (which == 'h') {   // 4 waves = 2 row blocks x 2 key halves per kv split group: 64-row workgroups
+            plan->block_q = 64;
+            plan->grid = g8 * ((L + 63) / 64);
         }
         if (which == 'P') {   // one workgroup = 8 waves = two 256-row halves: the same q tile of two groups of one XCD class
             plan->waves = 8;
@@ -311,7 +302,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         plan->lds_bytes = which == 'P' ? 2 * (4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64)) + 32
                           : which == 'x' ? 8 * 32 * D * 2 + 16
                           : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
-                                       : which == 'h' ? sel->nb * (64 * D * 2 + (D / 32) * (64 * 64 + 64)) + 16
+                                       : which == 'h' ? split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64)) + 16 * split
                                          : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
         // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
         // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
@@ -365,7 +356,7 @@ const OptionName kOptionNames[] = {
     {"kernel", &Options::kernel, 0, 127}, {"qb", &Options::qb, 0, 2}, {"waves", &Options::waves, 0, 8},
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
-    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"khsplit", &Options::khsplit, 0, 2}, {"nb", &Options::nb, 0, 3},
+    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1},
 };
 
 }  // namespace
@@ -579,7 +570,7 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'P' ? fa::launch_fwd_pp(p, dtype, st)
-                   : sel.which == 'h' ? fa::launch_fwd_kh(p, dtype, sel.kh, sel.nb, st)
+                   : sel.which == 'h' ? fa::launch_fwd_kh(p, dtype, sel.split, st)
                    : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves / sel.split, plan.qb, sel.split, sel.pair, st)
                                       : fa::launch_fwd_tile(p, dtype, plan.waves, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

@@ -13,23 +13,24 @@
 // with softmax statistics of its own; the two key halves of a row block are merged through LDS once, before the epilogue
 // (m, l, O of the upper half folded into the lower half's, as the kv split groups of fa_fwd_dma_kernel are).  Twice as many
 // workgroups of half the work each: the grid fills the chip's slots better, and the heaviest chain is half as long.
+//
+// SPLIT > 1 adds the kv split of fa_fwd_dma_kernel on top (grids of a few hundred workgroups at long L): SPLIT groups of 4 waves own the
+// SAME 64 query rows, group s streams the tiles s, s + SPLIT, ... through LDS buffers of its own in lock step with the others, and all
+// 2 SPLIT (group, key half) states of a row block are folded into one before the epilogue.
+// (Measured and dropped, DESIGN.md 3.0h: a ring of three tile buffers - slower everywhere, the request issued one tile ahead has landed -
+// and a 128-row shape in which every wave takes both key halves.)
 
 #include "fa_device.h"
 
 namespace fa {
 
-// KH = key splits of a tile (2: waves = 2 row blocks x 2 key halves, 64-row workgroups; 1: 4 row blocks, every wave takes both halves of a
-// tile one after the other, 128-row workgroups).  NB = tile buffers per operand (a ring: with three, a tile's LDS-DMA has two tile times to
-// land - a lone workgroup's tile is shorter than the L2 round trip, so with two buffers every tile ends in a DMA wait; 50 KB of LDS = 3
-// workgroups per CU instead of 4).
-template <typename T, int D, int KH, int NB>
+template <typename T, int D, int SPLIT>
 __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
-    constexpr int NW = 4;                       // waves: (4 / KH) row blocks x KH key splits
-    constexpr int NRB = NW / KH;
-    constexpr int BQ = 32 * NRB, BK = 64;
+    constexpr int NW = 4;                       // waves per split group: 2 row blocks x 2 key halves
+    constexpr int BQ = 64, BK = 64;
     constexpr int ROWB = D * 2;
     constexpr int KTILE_B = BK * ROWB;
     constexpr int VBLK_B = BK * 64 + 64;
@@ -37,11 +38,11 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
     constexpr int PIECES = KTILE_B / 1024;      // 1 KiB DMA pieces per K (or V) tile
     constexpr int PPW = PIECES / NW;
     constexpr int KS = D / 16, DT = D / 32;
+    constexpr int GROUP_B = 2 * KTILE_B + 2 * VTILE_B;     // K0 K1 V0 V1 of one split group
     static_assert(PIECES % NW == 0 && PPW >= 1, "pieces must split evenly over the waves");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NB * KTILE_B + NB * VTILE_B];   // K0 .. K(NB-1)  V0 .. V(NB-1)
-    __shared__ int flags[NW];
-    unsigned char* const smem_v = smem + NB * KTILE_B;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[SPLIT * GROUP_B];
+    __shared__ int flags[NW * SPLIT];
 
     const int nq = p.nq_tiles;
     int g, qi;
@@ -62,13 +63,18 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
 
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rb = KH == 2 ? (wave & 1) : wave, kh = KH == 2 ? (wave >> 1) : 0;      // row block, key half
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = SPLIT == 1 ? 0 : wave_all >> 2;           // kv split group
+    const int wave = wave_all & 3;
+    const int rb = wave & 1, kh = wave >> 1;                 // row block, key half
+    const int vg = 2 * ws + kh;                              // which of the 2 SPLIT partial states of its row block this wave holds
+    unsigned char* const smem = smem_all + ws * GROUP_B;
+    unsigned char* const smem_v = smem + 2 * KTILE_B;
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.H, hh = g - bb * p.H;
     const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
     const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
-    const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
+    const T* __restrict__ vg_ = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
     const int q_row0 = qi * BQ + rb * 32;
     const int qrow = q_row0 + r;
@@ -104,26 +110,28 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
     auto dma_tile = [&](int t, int buf) {          // descriptors start at the tile's first row; rows past L read as zeros
         const unsigned ko = (unsigned)t * BK * k_slb, vo = (unsigned)t * BK * v_slb;
         const i32x4 kr = make_raw_rsrc((const char*)kg + ko, k_bytes - ko);
-        const i32x4 vr = make_raw_rsrc((const char*)vg + vo, v_bytes - vo);
+        const i32x4 vr = make_raw_rsrc((const char*)vg_ + vo, v_bytes - vo);
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             lds_dma_b128(kr, smem_lds + buf * KTILE_B + k_dst[j], k_vo[j]);
-            lds_dma_b128(vr, smem_lds + NB * KTILE_B + buf * VTILE_B + v_dst[j], v_vo[j]);
+            lds_dma_b128(vr, smem_lds + 2 * KTILE_B + buf * VTILE_B + v_dst[j], v_vo[j]);
         }
     };
+    auto tile_barrier = [&]() { lds_dma_wait_all(); __syncthreads(); };
 
     // LDS read offsets of this wave's key half: K rows 32 kh + r of a tile, V^T fragments kk = 2 kh, 2 kh + 1 (16 keys each)
     int k_rd[KS];
     {
         const int sw = (D == 64) ? ((r >> 1) & 7) : (r & 15);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) k_rd[ks] = (32 * kh + r) * ROWB + (((2 * ks + h) ^ sw) << 4);   // (kh = 0 when KH == 1)
+        for (int ks = 0; ks < KS; ++ks) k_rd[ks] = (32 * kh + r) * ROWB + (((2 * ks + h) ^ sw) << 4);
     }
     const int v_rd = 2 * kh * 1024 + (4 * h + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
     const bool causal = p.causal != 0;
     const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
     const int n_tiles = (kv_end + BK - 1) / BK;
+    const int n_rounds = (n_tiles + SPLIT - 1) / SPLIT;        // rounds of the workgroup's lock-step loop (uniform over all its waves)
     const int wave_last = causal ? q_row0 : L - 1;             // a half tile reaching past this key carries a mask for the wave
     const int wave_kv_last = causal ? q_row0 + 31 : L - 1;     // half tiles starting after it hold nothing for the wave
     const int klim = causal ? qrow : L - 1;
@@ -142,13 +150,13 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
             for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
     };
 
-    // one half tile of this wave; EXACT: per-tile row max with lazy rescale, else the reference max is set on the wave's first half
+    // this wave's half of tile t; EXACT: per-tile row max with lazy rescale, else the reference max is set on the wave's first half
     // tile and left alone (fa_fwd_dma.hip: skip-max)
-    auto compute_half = [&](int t, int buf, int hsel, bool exact, bool& first) {
-        const int k0 = t * BK + 32 * hsel;          // first key of the half tile
-        if (!(wave_active && k0 <= wave_kv_last)) return;
-        const unsigned char* kb = smem + buf * KTILE_B + (KH == 2 ? 0 : 32 * ROWB * hsel);     // (KH == 2: the half is in k_rd / v_rd)
-        const unsigned char* vb = smem_v + buf * VTILE_B + (KH == 2 ? 0 : 2 * 1024 * hsel);
+    auto compute = [&](int t, int buf, bool exact, bool& first) {
+        const int k0 = t * BK + 32 * kh;            // first key of the half tile
+        if (!(wave_active && t < n_tiles && k0 <= wave_kv_last)) return;
+        const unsigned char* kb = smem + buf * KTILE_B;
+        const unsigned char* vb = smem_v + buf * VTILE_B;
         f32x16 s;
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
@@ -200,35 +208,23 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
             }
         }
     };
-    auto compute = [&](int t, int buf, bool exact, bool& first) {
-        if constexpr (KH == 2) {
-            compute_half(t, buf, kh, exact, first);
-        } else {
-            compute_half(t, buf, 0, exact, first);
-            compute_half(t, buf, 1, exact, first);
-        }
-    };
-    // one pass over the workgroup's kv tiles: tile t lives in buffer t % NB; at the top of tile t the DMA for tile t + NB - 1 goes out (its
-    // buffer was released by the barrier that ended tile t - 1); at the end of tile t only the newest NB - 2 requests may still be in flight
+    // one pass over the workgroup's kv tiles: group ws streams the tiles ws, ws + SPLIT, ... (the loop is unrolled by two: LDS addresses
+    // are base + immediate; every bound is workgroup-uniform)
     auto pass = [&](bool exact) {
         reset_state();
         bool first = true;
-        fa_static_for<0, NB - 1>([&](auto bi) { constexpr int b_ = decltype(bi)::value; if (b_ < n_tiles) dma_tile(b_, b_); });
-        lds_dma_wait_all();
-        __syncthreads();
-        for (int t0 = 0; t0 < n_tiles; t0 += NB) {
-            fa_static_for<0, NB>([&](auto ki) {
-                constexpr int k_ = decltype(ki)::value;
-                const int t = t0 + k_;
-                if (t < n_tiles) {                                   // (workgroup-uniform)
-                    const bool more = t + NB - 1 < n_tiles;
-                    if (more) dma_tile(t + NB - 1, (k_ + NB - 1) % NB);
-                    compute(t, k_, exact, first);
-                    if (more && NB > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NB - 2)) : "memory");
-                    else lds_dma_wait_all();
-                    __syncthreads();
-                }
-            });
+        if (ws < n_tiles) dma_tile(ws, 0);
+        tile_barrier();
+        for (int rr = 0; rr < n_rounds; rr += 2) {
+            const int t = ws + rr * SPLIT;               // this group's tile of the round
+            if (t + SPLIT < n_tiles) dma_tile(t + SPLIT, 1);
+            compute(t, 0, exact, first);
+            tile_barrier();
+            if (rr + 1 < n_rounds) {
+                if (t + 2 * SPLIT < n_tiles) dma_tile(t + 2 * SPLIT, 0);
+                compute(t + SPLIT, 1, exact, first);
+                tile_barrier();
+            }
         }
     };
 
@@ -240,51 +236,54 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
     if (optimistic) {
         // Did any row of the workgroup leave the safe range?  (All waves must agree: the exact pass re-streams K/V through the same barriers.)
         const bool bad = wave_active && sum_left_safe_range(lsum[0]);
-        flags[wave] = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
+        flags[wave_all] = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
         __syncthreads();
         int any_bad = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) any_bad |= flags[w];
+        for (int w = 0; w < NW * SPLIT; ++w) any_bad |= flags[w];
         if (any_bad) {
             __syncthreads();
             pass(true);
         }
     }
 
-    // ---- fold the upper key half's (m, l, O) into the lower half's through LDS (the K/V buffers are free after the pass's last barrier;
-    // the exchange area lies behind the epilogue's row slabs; a lane's values sit at [value][lane]: conflict-free).  A half that saw no
-    // key of a row hands over m = -inf, l = 0, O = 0: its weight 2^((m - m_new) c) is 0.
-    if constexpr (KH == 2) {
+    // ---- fold the other (split group, key half) states of a row block into state 0, one at a time, through LDS (the K/V buffers are free
+    // after the pass's last barrier; the exchange area lies behind the epilogue's row slabs; a lane's values sit at [value][lane]:
+    // conflict-free).  A state that saw no key of a row hands over m = -inf, l = 0, O = 0: its weight 2^((m - m_new) c) is 0.
+    {
         constexpr int NVAL = DT * 16 + 2;
-        float* xb = (float*)(smem + 2 * 32 * ROWB) + rb * (NVAL * 64) + lane;
-        static_assert(2 * 32 * ROWB + 2 * NVAL * 64 * 4 <= NB * KTILE_B + NB * VTILE_B, "exchange area must fit the K/V buffers");
-        if (kh == 1) {
-            xb[0] = m;
-            xb[64] = lsum[0];
+        float* xb = (float*)(smem_all + 2 * 32 * ROWB) + rb * (NVAL * 64) + lane;
+        static_assert(2 * 32 * ROWB + 2 * NVAL * 64 * 4 <= SPLIT * GROUP_B, "exchange area must fit the K/V buffers");
+        for (int v = 1; v < 2 * SPLIT; ++v) {
+            if (v > 1) __syncthreads();
+            if (vg == v) {
+                xb[0] = m;
+                xb[64] = lsum[0];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) xb[(2 + dt * 16 + e) * 64] = o[dt][e];
+                    for (int e = 0; e < 16; ++e) xb[(2 + dt * 16 + e) * 64] = o[dt][e];
+            }
+            __syncthreads();
+            if (vg == 0 && wave_active) {
+                const float m1 = xb[0], l1 = xb[64];
+                const float mn = max2(m, m1);
+                const float a0 = fast_exp2((m - mn) * c), a1 = fast_exp2((m1 - mn) * c);
+                m = mn;
+                const float ln = lsum[0] * a0 + l1 * a1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lsum[j] = ln;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[dt][e] = o[dt][e] * a0 + xb[(2 + dt * 16 + e) * 64] * a1;
+            }
         }
-        __syncthreads();
-        if (kh == 1) return;
-        if (wave_active) {
-            const float m1 = xb[0], l1 = xb[64];
-            const float mn = max2(m, m1);
-            const float a0 = fast_exp2((m - mn) * c), a1 = fast_exp2((m1 - mn) * c);
-            m = mn;
-            const float ln = lsum[0] * a0 + l1 * a1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) lsum[j] = ln;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[dt][e] = o[dt][e] * a0 + xb[(2 + dt * 16 + e) * 64] * a1;
-        }
+        if (vg != 0) return;
     }
     // ---- epilogue (fa_fwd_dma.hip): O /= l staged through a private 32-row LDS slab so that every store writes whole rows
     if (!wave_active) return;
-    unsigned char* slab = smem + rb * (32 * ROWB);
+    unsigned char* slab = smem_all + rb * (32 * ROWB);
     constexpr int CPR = D / 8;      // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;   // rows per store instruction
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
@@ -311,28 +310,30 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
     }
 }
 
-template <typename T, int D, int KH, int NB>
-__global__ __launch_bounds__(256) void fa_fwd_kh_kernel(const FwdParams p) {
-    fa_fwd_kh_body<T, D, KH, NB>(p);
+template <typename T, int D, int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void fa_fwd_kh_kernel(const FwdParams p) {
+    fa_fwd_kh_body<T, D, SPLIT>(p);
 }
 
 template <typename T, int D>
-static hipError_t launch_kh_t(const FwdParams& p, int kh, int nb, hipStream_t stream) {
-    const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles)), block(256);
-    if (kh == 2) return nb == 3 ? launch1((const void*)(fa_fwd_kh_kernel<T, D, 2, 3>), grid, block, 0, stream, p)
-                                : launch1((const void*)(fa_fwd_kh_kernel<T, D, 2, 2>), grid, block, 0, stream, p);
-    if constexpr (D == 64) {   // (128-row workgroups with a ring of three: head_dim 64 only - 99 KB of LDS at head_dim 128)
-        return launch1((const void*)(fa_fwd_kh_kernel<T, D, 1, 3>), grid, block, 0, stream, p);
-    } else {
-        return hipErrorInvalidValue;
+static hipError_t launch_kh_t(const FwdParams& p, int split, hipStream_t stream) {
+    const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles));
+    if (split == 2) return launch1((const void*)(fa_fwd_kh_kernel<T, D, 2>), grid, dim3(512), 0, stream, p);
+    if (split == 4) {   // 16 waves, 132 KB of LDS at head_dim 64 (264 KB at 128: does not exist)
+        if constexpr (D == 64) {
+            return launch1((const void*)(fa_fwd_kh_kernel<T, D, 4>), grid, dim3(1024), 0, stream, p);
+        } else {
+            return hipErrorInvalidValue;
+        }
     }
+    return launch1((const void*)(fa_fwd_kh_kernel<T, D, 1>), grid, dim3(256), 0, stream, p);
 }
 
-// callers guarantee: D in {64, 128}; kh = key splits per tile (2: 64-row workgroups; 1: 128-row workgroups, head_dim 64, nb = 3),
-// nb = tile buffers per operand (2 | 3); p.nq_tiles = q tiles of 32 x (4 / kh) rows per group; grid = G8 x q tiles
-hipError_t launch_fwd_kh(const FwdParams& p, int dtype, int kh, int nb, hipStream_t stream) {
-    if (dtype == 1) return p.D == 64 ? launch_kh_t<__bf16, 64>(p, kh, nb, stream) : launch_kh_t<__bf16, 128>(p, kh, nb, stream);
-    return p.D == 64 ? launch_kh_t<_Float16, 64>(p, kh, nb, stream) : launch_kh_t<_Float16, 128>(p, kh, nb, stream);
+// callers guarantee: D in {64, 128}; split = kv split groups per workgroup (1 | 2; 4 at head_dim 64); p.nq_tiles = 64-row q tiles per
+// group; grid = G8 x q tiles
+hipError_t launch_fwd_kh(const FwdParams& p, int dtype, int split, hipStream_t stream) {
+    if (dtype == 1) return p.D == 64 ? launch_kh_t<__bf16, 64>(p, split, stream) : launch_kh_t<__bf16, 128>(p, split, stream);
+    return p.D == 64 ? launch_kh_t<_Float16, 64>(p, split, stream) : launch_kh_t<_Float16, 128>(p, split, stream);
 }
 
 }  // namespace fa

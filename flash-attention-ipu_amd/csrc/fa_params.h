@@ -91,7 +91,7 @@ hipError_t launch_fwd_f32(const FwdParams& p, hipStream_t stream);   // fa_fwd_f
 hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);   // fa_fwd_pipe.hip
 hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream); // fa_fwd_pipe16.hip
 hipError_t launch_fwd_pp(const FwdParams& p, int dtype, hipStream_t stream);                        // fa_fwd_pp.hip (head_dim 64)
-hipError_t launch_fwd_kh(const FwdParams& p, int dtype, int kh, int nb, hipStream_t stream);        // fa_fwd_kh.hip
+hipError_t launch_fwd_kh(const FwdParams& p, int dtype, int split, hipStream_t stream);             // fa_fwd_kh.hip
 double probe_mfma_peak(int dtype, int iters, int random_data);
 hipError_t launch_clock_sampler(unsigned long long* out, int spins, hipStream_t stream);   // fa_probe.hip
 

@@ -49,11 +49,11 @@ def parse(spec):
 
 def setknobs(lib, rest):
     """knobs go through fa_debug_set_option of THAT library (the environment is only read once, at load)"""
-    want = {"kernel": 0, "waves": 0, "sched": 0, "qb": 0, "split": 0, "pair": -1, "balance": -1, "khsplit": 0, "nb": 0}
+    want = {"kernel": 0, "waves": 0, "sched": 0, "qb": 0, "split": 0, "pair": -1, "balance": -1}
     for kv in rest.split(","):
         if kv:
             k, val = kv.split("=")
-            name = {"K": "kernel", "W": "waves", "S": "sched", "Q": "qb", "P": "split", "R": "pair", "B": "balance", "H": "khsplit", "N": "nb"}[k]
+            name = {"K": "kernel", "W": "waves", "S": "sched", "Q": "qb", "P": "split", "R": "pair", "B": "balance"}[k]
             want[name] = (ord("x") if val in ("pipe16", "x") else ord("P") if val in ("pp", "P") else ord("h") if val in ("kh", "h") else ord(val[0])) if name == "kernel" else int(val)
     for name, val in want.items():
         assert lib.fa_debug_set_option(name.encode(), val) == 0, (name, val)

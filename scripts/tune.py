@@ -92,6 +92,8 @@ def candidates(G, L, D, skip, causal, scheds=True):
             out.append({"kernel": "dma", "qb": 1, "waves": 4, "sched": auto, "split": sp})
     if wg128 <= 2048 and L >= 256:        # ... and 64-row workgroups whose waves are (row block, key half) pairs (fa_fwd_kh.hip)
         out.append({"kernel": "kh", "qb": 1, "waves": 4, "sched": auto})
+        if wg128 <= 512 and L >= 1024:
+            out.append({"kernel": "kh", "qb": 1, "waves": 4, "sched": auto, "split": 2})
     if D == 64 and skip and L >= 256:     # ... at head_dim 64: 4 waves x 32 or 64 rows
         for qb in (1, 2):
             for b in bunches:

@@ -333,20 +333,20 @@ def test_ping_pong_growing_logits_force_the_exact_pass(knobs, dtype, step):
                                            (128, torch.bfloat16, 128 ** -0.5), (128, torch.float16, 1.0)])
 @pytest.mark.parametrize("G,L", [(1, 32), (2, 64), (3, 100), (2, 257), (17, 300), (2, 1000), (1, 4608), (9, 600), (5, 1024)])
 def test_key_halves_kernel(knobs, D, dtype, scale, G, L, causal):
-    _key_halves_case(knobs, D, dtype, scale, G, L, causal, 2, 2)
+    _key_halves_case(knobs, D, dtype, scale, G, L, causal, 1)
 
 
-@pytest.mark.parametrize("khsplit,nb", [(2, 3), (1, 3)])
+@pytest.mark.parametrize("split", [2, 4])
 @pytest.mark.parametrize("causal", [1, 0])
-@pytest.mark.parametrize("D,dtype,scale", [(64, torch.bfloat16, 1.0), (64, torch.float16, 1.0), (128, torch.bfloat16, 128 ** -0.5)])
-@pytest.mark.parametrize("G,L", [(1, 32), (3, 100), (2, 257), (17, 300), (1, 4608), (5, 1024)])
-def test_key_halves_kernel_ring_of_three_and_128_row_shape(knobs, D, dtype, scale, G, L, causal, khsplit, nb):
-    """The same kernel with three tile buffers per operand (counted DMA waits), and its 128-row shape (every wave takes both key halves
-    of a tile; head_dim 64 only - a request at head_dim 128 falls back to the 64-row shape)."""
-    _key_halves_case(knobs, D, dtype, scale, G, L, causal, khsplit if D == 64 else 2, nb, force=(khsplit, nb))
+@pytest.mark.parametrize("D,dtype,scale", [(64, torch.bfloat16, 1.0), (64, torch.float16, 1.0), (64, torch.float16, 64 ** -0.5), (128, torch.bfloat16, 128 ** -0.5)])
+@pytest.mark.parametrize("G,L", [(1, 32), (3, 100), (2, 257), (17, 300), (1, 4608), (5, 1024), (2, 1000)])
+def test_key_halves_kernel_with_kv_split_groups(knobs, D, dtype, scale, G, L, causal, split):
+    """The same kernel with 2 | 4 kv split groups per workgroup (8 | 16 waves: every group streams every SPLIT-th tile through buffers of
+    its own; 2 SPLIT partial states per row block folded through LDS; 4 groups exist at head_dim 64 only - a request at 128 runs 1)."""
+    _key_halves_case(knobs, D, dtype, scale, G, L, causal, split if (split == 2 or D == 64) else 1, force=split)
 
 
-def _key_halves_case(knobs, D, dtype, scale, G, L, causal, khsplit, nb, force=None):
+def _key_halves_case(knobs, D, dtype, scale, G, L, causal, split, force=None):
     """fa_fwd_kh_kernel (fa_fwd_kh.hip: 64-row workgroups, every wave = (row block, key half) of the streamed 64-key tiles, the two
     halves' softmax statistics merged through LDS): out and logsumexp against the oracle - a single half tile, key halves that hold
     nothing for a wave, ragged last tiles, waves without rows, both arithmetic modes (skip-max and per-tile max), causal and unmasked."""
@@ -355,13 +355,11 @@ def _key_halves_case(knobs, D, dtype, scale, G, L, causal, khsplit, nb, force=No
 
     knobs.set("kernel", "kh")
     if force:
-        knobs.set("khsplit", force[0])
-        knobs.set("nb", force[1])
+        knobs.set("split", force)
     p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale, causal=causal)
-    bq = 128 // khsplit
-    assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (6, 4, 1, bq, 64)
-    assert p.grid == ((G + 7) // 8 * 8) * ((L + bq - 1) // bq)
-    assert p.lds_bytes == nb * (64 * D * 2 + (D // 32) * (64 * 64 + 64)) + 16
+    assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (6, 4 * split, 1, 64, 64)
+    assert p.grid == ((G + 7) // 8 * 8) * ((L + 63) // 64)
+    assert p.lds_bytes == split * (2 * (64 * D * 2 + (D // 32) * (64 * 64 + 64)) + 16)
     x = frozen_randn(SEED + 23 * L + G + D, (3, G, L, D)).to(dtype)
     if causal:
         ref, ref_lse = _oracle(x, scale=scale)

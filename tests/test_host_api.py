@@ -172,8 +172,11 @@ def _check_builtin_rules(native):
     # of the same workgroup (plan.waves counts them all; block_q stays 128)
     p = native.plan(16, 2048, 128, torch.bfloat16, 8, 8)
     assert (p.kernel, p.block_q, p.waves, p.lds_bytes) == (0, 128, 8, 2 * (2 * 16384 + 8 * (4096 + 64)))
+    p = native.plan(8, 8192, 64, torch.bfloat16, 8, 8)
+    assert (p.kernel, p.block_q, p.waves, p.grid) == (0, 128, 16, 8 * 64)
+    # ... at head_dim 64 and L = 2048 .. 4096 by 64-row key-half workgroups with two kv split groups (8 waves)
     p = native.plan(8, 4096, 64, torch.bfloat16, 8, 8)
-    assert (p.kernel, p.block_q, p.waves, p.grid) == (0, 128, 16, 8 * 32)
+    assert (p.kernel, p.block_q, p.waves, p.grid) == (6, 64, 8, 8 * 64)
     p = native.plan(8, 1024, 128, torch.bfloat16, 8, 8)
     assert (p.kernel, p.block_q, p.waves) == (0, 128, 8)
     # ... and at head_dim 64 up to L = 2048 by 64-row workgroups whose four waves are (row block, key half) pairs (fa_fwd_kh.hip)
