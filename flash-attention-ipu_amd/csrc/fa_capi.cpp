@@ -120,7 +120,7 @@ struct Selection {
     char which;      // 'd' | 'p' | 'x' | 'P' | 'h' | 't' | 'g' generic | 'f' fp32 MFMA
     int split;       // kv split groups per workgroup ('d' only; plan.waves counts all of the workgroup's waves)
     int pair;        // 'd' only: 1 = a workgroup owns q tiles (nq - 1 - i) and i, one after the other
-    int perm_n;      // 'd' only: > 0 = placement-balanced order of the XCD's first perm_n slots
+    int perm_n;      // 'd' | 'h': > 0 = placement-balanced order of the XCD's first perm_n slots
     uint8_t perm[128];
 };
 
@@ -259,19 +259,24 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         }
         sel->pair = pair;
         sel->perm_n = 0;
-        if (which == 'd' && causal && !pair && qb == 1 && waves == 4 && split == 1 && opt.balance != 0) {
-            const int64_t nqt = (L + 32 * waves - 1) / (32 * waves), ng = g8 / 8;
+        // (the key-halves kernel takes the order too, but measured no gain from it - G = 8 L = 4096 31.7 vs 31.5 us, profiles/r03_kh/balance_*.txt:
+        //  its launches are bound per SIMD, not per CU sum - so there it is applied on request only)
+        if (((which == 'd' && !pair && split == 1 && opt.balance != 0) || (which == 'h' && opt.balance == 1)) && causal && qb == 1 && waves == 4) {
+            const int rows = which == 'h' ? 64 : 32 * waves;                                    // q rows per workgroup
+            const int64_t nqt = (L + rows - 1) / rows, ng = g8 / 8;
             const int64_t nitem = nqt;                                                          // workgroups per group
-            const int64_t slots_per_xcd = (D == 64 ? 4 : 2) * kCusPerXcd;                       // resident workgroups per XCD
+            // resident workgroups per XCD: by LDS (33 KB per 4-wave group at head_dim 64, 66 KB at 128; 160 KB per CU)
+            const int per_cu = which == 'h' ? (D == 64 ? (split == 1 ? 4 : split == 2 ? 2 : 1) : (split == 1 ? 2 : 1)) : (D == 64 ? 4 : 2);
+            const int64_t slots_per_xcd = (int64_t)per_cu * kCusPerXcd;
             if (ng * nitem <= slots_per_xcd && ng * nitem <= 128) {
                 int bunch_sz = (int)((8ll << 20) / (2 * L * D * es));
                 if (sched > 0) bunch_sz = sched;
                 if (opt.sched > 0) bunch_sz = opt.sched;
                 if (bunch_sz < 1) bunch_sz = 1;
                 if (bunch_sz > ng) bunch_sz = (int)ng;
-                const auto tiles_of = [&](int64_t qi) { const int64_t kv_end = (qi + 1) * 128 < L ? (qi + 1) * 128 : L; return (int)((kv_end + 63) / 64); };
+                const auto tiles_of = [&](int64_t qi) { const int64_t kv_end = (qi + 1) * rows < L ? (qi + 1) * rows : L; return (int)((kv_end + 63) / 64); };
                 int weight[128];
-                for (int s_ = 0; s_ < ng * nitem; ++s_) {    // the kernels' natural slot -> (group, work item) map (fa_fwd_dma.hip)
+                for (int s_ = 0; s_ < ng * nitem; ++s_) {    // the kernels' natural slot -> (group, work item) map (fa_fwd_dma.hip, fa_fwd_kh.hip)
                     const int per_bunch = bunch_sz * (int)nitem, b_ = s_ / per_bunch, rem = s_ - b_ * per_bunch;
                     const int g0 = b_ * bunch_sz, bc = (ng - g0) < bunch_sz ? (int)(ng - g0) : bunch_sz;
                     const int64_t qd = rem / bc;

@@ -47,7 +47,11 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
     const int nq = p.nq_tiles;
     int g, qi;
     {
-        const int b = blockIdx.x;
+        int b = blockIdx.x;
+        if (p.perm_n > 0) {                            // placement-balanced order of a grid below one round of slots (fa_capi.cpp)
+            const int s_ = b >> 3;
+            b = (s_ < p.perm_n ? (int)p.perm[s_] : s_) * 8 + (b & 7);
+        }
         const int xcd = b & 7, slot = b >> 3;
         const int ng = p.G8 >> 3;
         const int per_bunch = p.sched * nq;

@@ -399,6 +399,35 @@ def test_key_halves_growing_logits_force_the_exact_pass(knobs, dtype, step):
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
 
 
+@pytest.mark.parametrize("G,L,D,split", [(8, 4096, 64, 2), (64, 1024, 64, 1), (29, 2048, 64, 1), (16, 2048, 128, 1), (13, 1300, 64, 1)])
+def test_key_halves_placement_balanced_block_order(knobs, G, L, D, split):
+    """The key-halves kernel in the placement-balanced block order (grids below one round of its slots): every (group, q tile) still
+    computed exactly once - bit-identical output and logsumexp with the order on and off, and the oracle on sampled groups."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    dtype = torch.bfloat16
+    x = frozen_randn(SEED + 31 * L + G, (3, G, L, D)).to(dtype)
+    q, k, v = x.cuda()
+    st = (L * D, 0, D)
+    res = {}
+    for bal in (1, 0):
+        knobs.set("kernel", "kh")
+        knobs.set("split", split)
+        knobs.set("balance", bal)
+        p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=D ** -0.5)
+        assert (p.kernel, p.waves, p.balanced) == (6, 4 * split, bal), (p.kernel, p.waves, p.balanced, p.grid)
+        out = torch.full_like(q, float("nan"))
+        lse = torch.full((G, L), float("nan"), device="cuda", dtype=torch.float32)
+        native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, D ** -0.5)
+        res[bal] = (out, lse)
+    assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1])
+    for g in (0, G // 2, G - 1):
+        ref, ref_lse = _oracle(x[:, g:g + 1], scale=D ** -0.5)
+        _check(res[1][0][g:g + 1], ref, dtype, f"kh balanced order group {g}")
+        torch.testing.assert_close(res[1][1][g:g + 1].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
 @pytest.mark.parametrize("D,qb", [(128, 1), (64, 1), (64, 2)])
 def test_pipe16_growing_logits_force_the_exact_pass(knobs, step, D, qb):
