@@ -63,6 +63,8 @@ def fuzz(cases, seed, log=print):
           variants.append({"kernel": "pipe16", "waves": 4, "qb": rng.choice([1, 2]), "sched": rng.choice([1, 2, 8])})
           variants.append({"kernel": "pp", "sched": rng.choice([1, 2, 8])})      # 512-thread workgroups of two halves in complementary phases
       variants.append({"split": 2 if D == 128 else rng.choice([2, 4]), "sched": rng.choice([1, 2, 8])})   # kv split groups (dma kernel)
+      variants.append({"kernel": "kh", "sched": rng.choice([1, 2, 8])})      # 64-row workgroups, waves = (row block, key half) ...
+      variants.append({"kernel": "kh", "split": 2 if D == 128 else rng.choice([2, 4]), "balance": rng.choice([0, 1])})   # ... with kv split groups
       if only is not None and case != int(only):
           continue
       base, base_lse = run(q, k, v, H, scale, {"kernel": "tile"}, causal)
@@ -176,7 +178,9 @@ def fuzz(cases, seed, log=print):
         tol = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2, torch.float32: 1e-5}[dt]
         for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
             got = got.cpu().double()
-            floor = tol * max(1e-3, want.abs().max().item())
+            # (a gradient that is exactly 0 - L = 1: dS = P (dP - Dsum) = 0 - comes out as the rounding of Dsum = rowsum(dO o O) over the 16-bit O:
+          #  ~1e-3 relative to |dO| |O| ~ 1, hence the absolute floor)
+          floor = tol * max(1e-2, want.abs().max().item())
             if not (bool(torch.isfinite(got).all()) and bool(((got - want).abs() <= floor + 2e-2 * want.abs()).all())):
                 bad += 1
                 log(f"MISMATCH grouped-query backward case {case} {name}: B={B} H={H}/{Hkv} L={L} D={D} {dt} scale={scale:.3g} causal={causal} max|d|={(got - want).abs().max().item():.3e}")
@@ -235,7 +239,9 @@ def fuzz(cases, seed, log=print):
       tol = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2}[dt]
       for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
           got = got.cpu().double()
-          floor = tol * max(1e-3, want.abs().max().item())
+          # (a gradient that is exactly 0 - L = 1: dS = P (dP - Dsum) = 0 - comes out as the rounding of Dsum = rowsum(dO o O) over the 16-bit O:
+          #  ~1e-3 relative to |dO| |O| ~ 1, hence the absolute floor)
+          floor = tol * max(1e-2, want.abs().max().item())
           if not (bool(torch.isfinite(got).all()) and bool(((got - want).abs() <= floor + 2e-2 * want.abs()).all())):
               bad += 1
               log(f"MISMATCH {name} {what}: max|d|={(got - want).abs().max().item():.3e} (ref max {want.abs().max().item():.2f})")
