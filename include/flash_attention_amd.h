@@ -140,10 +140,11 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  * process until set back to its "auto" value.  The FA_AMD_* environment variables of round 1 are read ONCE, at the
  * first call into the library, into the same knobs; nothing reads the environment per launch.
  *   "kernel"  0 auto | 'd' (64-key tiles, LDS-DMA) | 'p' (pipelined 32-key steps) | 'x' (the same on 16x16x32 MFMAs)
- *             | 't' (register-staged baseline)
+ *             | 'h' (64-row workgroups, waves = (row block, key half) of the 64-key tiles) | 'P' (32-key steps, the two waves of a
+ *             SIMD in complementary phases: head_dim 64) | 't' (register-staged baseline)
  *   "qb"      0 auto | 1 | 2        "waves"  0 auto | 1 | 2 | 4 | 8        "sched"  0 auto | n >= 1
  *   "skipmax" -1 auto | 0 | 1       "f32_generic" 0 | 1                    "table"  1 use the tuning table | 0 rules only
- *   "split"   0 auto | 1 | 2 | 4    kv split groups per workgroup ('d' kernel, 4 waves x 32 rows per group)
+ *   "split"   0 auto | 1 | 2 | 4    kv split groups per workgroup ('d' kernel: 4 waves x 32 rows per group; 'h' kernel when forced with it)
  *   "pair"    -1 auto | 0 | 1       q-tile pairs (n - 1 - i, i) per workgroup ('d' kernel, causal, 4 waves)
  *   "balance" -1 auto | 0 | 1       placement-balanced block order of a causal grid below one round of workgroup slots
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
