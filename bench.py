@@ -52,6 +52,7 @@ CONFIGS = {
     "l1024": (512, 1024, 64, "bf16", (4, 4)),        # not a BASELINE config: the short-sequence regime on a full grid
     "cfg4_attn": (96, 1024, 64, "bf16", (4, 4)),     # configs[3]'s attention call alone: SDPA override on head-inner [8,12,1024,64] views
     "nb_65536": (8, 65536, 64, "f16", (64, 64)),     # the reference notebook's longest demonstrated context (nb:939, :952-963)
+    "cfg2_sdpa": (128, 4096, 64, "bf16", (8, 8)),    # the headline shape through the SDPA override ([8,16,4096,64], scale 1/sqrt(D): sdpa.py:55-59)
     # total work fixed ("strong"): G is the TOTAL group count, G/N per rank
     "cfg5": (2048, 8192, 64, "bf16", (16, 8)),       # configs[4]: batch 64 x heads 32, seq 8192, head_dim 64
 }
@@ -140,6 +141,19 @@ def make_op(name, dev, seed=1, backward=False):
         fn = lambda: _native.bwd(qkv[0], qkv[1], qkv[2], out, dout, lse, dqkv[0], dqkv[1], dqkv[2], G, L, D, 1, 1.0, True)  # noqa: E731
         return fn, 5.0 * G * L * L * D, "fa_bwd_dq_kernel + fa_bwd_dkdv_kernel", \
             f"{name}: gradients of packed qkv [3,{G},{L},{D}] {dname}, causal (fa_bwd: dQ + dK/dV kernels)", None
+    if name == "cfg2_sdpa":
+        import torch.nn.functional as F
+        import flash_attention_amd.auto  # noqa: F401
+        B, H = 8, 16
+        q, k, v = (torch.randn(B, H, L, D, device=dev, generator=gen).to(dtype) for _ in range(3))
+
+        def fn():
+            with torch.no_grad():
+                return F.scaled_dot_product_attention(q, k, v, is_causal=True)
+        plan = _native.plan(G, L, D, dtype, nq, nk, softmax_scale=D ** -0.5)
+        return fn, 2.0 * G * L * L * D, kernel_name(plan), \
+            f"{name}: F.scaled_dot_product_attention(is_causal=True) through the override on [{B},{H},{L},{D}] {dname} (scaled logits: the " \
+            f"pipelined kernel folds scale log2(e) into Q, DESIGN.md 3.0i)", plan
     if name == "cfg4_attn":
         import torch.nn.functional as F
         import flash_attention_amd.auto  # noqa: F401
@@ -731,7 +745,7 @@ def main():
             line["secondary"] = {"gather_modes": gather_modes}
         if world == 1 and not args.no_secondary and not strong:
             sec = {}
-            for name in ("cfg3", "cfg5_shard", "small_grid", "l1024", "cfg4_attn", "nb_65536"):
+            for name in ("cfg3", "cfg5_shard", "small_grid", "l1024", "cfg4_attn", "nb_65536", "cfg2_sdpa"):
                 if name != args.config:
                     try:
                         sec[name] = secondary_attention(name, dev)

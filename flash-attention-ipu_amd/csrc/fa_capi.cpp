@@ -47,6 +47,7 @@ struct Options {
     std::atomic<int> split{0};      // 0 auto, 1 | 2 | 4 kv split groups per workgroup (fa_fwd_dma.hip)
     std::atomic<int> pair{-1};      // -1 auto, 0 | 1 q-tile pairs per workgroup (fa_fwd_dma.hip, causal)
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
+    std::atomic<int> fold{-1};      // -1 auto (on for scaled calls), 0 off: the scale fold of the pipelined kernel (fa_fwd_pipe.hip FOLD)
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -74,6 +75,7 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_TABLE")) { if (*e) g_opt.table = atoi(e); }
         if (const char* e = getenv("FA_AMD_PAIR")) { if (*e) g_opt.pair = atoi(e); }
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
+        if (const char* e = getenv("FA_AMD_FOLD")) { if (*e) g_opt.fold = atoi(e); }
     });
     return g_opt;
 }
@@ -361,7 +363,7 @@ const OptionName kOptionNames[] = {
     {"kernel", &Options::kernel, 0, 127}, {"qb", &Options::qb, 0, 2}, {"waves", &Options::waves, 0, 8},
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
-    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1},
+    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"fold", &Options::fold, -1, 1},
 };
 
 }  // namespace
@@ -561,6 +563,8 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.skipmax = plan.skipmax;
+    // the scale fold of the pipelined kernel (fa_fwd_pipe.hip FOLD): scaled calls only - softmax_scale <= 1/4, the SDPA override's 1 / sqrt(D)
+    p.fold = (sel.which == 'p' && D == 64 && plan.qb == 2 && plan.waves == 4 && softmax_scale <= 0.25f && options().fold != 0) ? 1 : 0;
     p.perm_n = sel.perm_n;
     if (sel.perm_n > 0) memcpy(p.perm, sel.perm, sizeof(p.perm));
     p.stamps = nullptr;

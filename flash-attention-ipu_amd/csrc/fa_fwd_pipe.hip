@@ -76,7 +76,14 @@
 
 namespace fa {
 
-template <typename T, int D, int NWAVES, int QB, bool CAUSAL>
+// FOLD (scaled calls only: softmax_scale <= 1/4, i.e. the SDPA override's 1 / sqrt(D)): the factor c = scale log2(e) is folded into the Q
+// fragments when they are loaded (re-rounded to 16 bits: an error of 2^-9 of a unit-variance logit, a quarter of P's own bf16 rounding -
+// NOT legal for the packed op's unscaled logits, where it breaks parity) and the optimistic pass runs with the reference
+// max fixed at 0 instead of the first step's row max: P = 2^(s') with no `v_fma` per score at all - 32 of the step's 80 vector
+// instructions go (456 -> 328 issue cycles against 576 matrix cycles: the step turns matrix-bound).  Any reference value cancels in
+// O / l; what 0 must guarantee is that P neither overflows (caught as before: the row sum turns inf / NaN) nor underflows to nothing
+// (caught by a row sum below 2^-80) - either sends the workgroup through the exact pass, which works on the folded scores with c = 1.
+template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false>
 __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -157,6 +164,14 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         const T* qp = qg + (int64_t)qr * p.q_sl + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[b][ks] = *(const vec8*)(qp + 16 * ks);
+    }
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[b][ks][j] = (T)((float)qf[b][ks][j] * p.scale_log2);
     }
 
     // ---- LDS-DMA geometry (as fa_fwd_dma_kernel, for 32-key slots)
@@ -250,7 +265,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     (void)asel;
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        m[b] = -INFINITY;
+        m[b] = FOLD ? 0.f : -INFINITY;     // (FOLD: the optimistic pass keeps the reference max at 0)
         l[b] = 0.f;
         lsum[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -258,7 +273,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[b][dt][e] = 0.f;
     }
-    const float c = p.scale_log2;
+    const float c = FOLD ? 1.0f : p.scale_log2;   // (FOLD: the scores arrive in log2 units)
     constexpr float P_LIMIT = E::is_f16 ? 32768.0f : 1152921504606846976.0f;   // 2^15 | 2^60
 
     // S[b] = K(slot) Q_b^T for one 32-key step (every K row read feeds all blocks)
@@ -386,7 +401,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 if (key_ > FA_KLIM(b_)) SC_[b_][e_] = -INFINITY;                                   \
                 if (key_ + 1 > FA_KLIM(b_)) SC_[b_][e_ + 1] = -INFINITY;                           \
             }                                                                                      \
-            if constexpr (!FA_ITEM_DEAD(MASK_, b_)) {                                              \
+            if constexpr (!FA_ITEM_DEAD(MASK_, b_) && !FOLD) {   /* (FOLD: the score IS the exponent - c folded into Q, reference max 0) */ \
                 SC_[b_][e_] = __builtin_fmaf(SC_[b_][e_], c, -mc[b_]);                             \
                 SC_[b_][e_ + 1] = __builtin_fmaf(SC_[b_][e_ + 1], c, -mc[b_]);                     \
             }                                                                                      \
@@ -517,7 +532,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             float ls[QB];                                                                          \
             const bool diag_ = i_ >= nh_w - QB;                                                    \
             if (diag_) FA_MASK_H(SC_, i_)                                                          \
-            if (i_ == 0) FA_MAXR_H(SC_)                                                            \
+            if (i_ == 0 && !(FOLD && !(SAFE_))) FA_MAXR_H(SC_)                                     \
             FA_SM_H(SC_)                                                                           \
             bool over_ = false;                                                                    \
             _Pragma("unroll") for (int b = 0; b < QB; ++b) over_ |= !(ls[b] <= P_LIMIT);           \
@@ -612,7 +627,11 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     FA_RUN(false)
     // (sums of non-negative P only grow, and an overflowed P makes them inf or NaN for good: one check per pass)
 #pragma unroll
-    for (int b = 0; b < QB; ++b) bad |= sum_left_safe_range(lsum[b][0]);
+    for (int b = 0; b < QB; ++b) {
+        bad |= sum_left_safe_range(lsum[b][0]);
+        // (FOLD: with the reference max at 0 a row whose logits are all far below 0 would underflow; a row owns its diagonal key at least)
+        if constexpr (FOLD) bad |= wave_active && (half_swap_sum(l[b]) + lsum[b][0]) < 8.2718061e-25f;   /* 2^-80 */
+    }
     // Did any row of the workgroup leave the safe range?  (All waves must agree: the fallback pass re-streams
     // K/V through the same barriers.)  Practically never taken: logits must outgrow the first step's row max
     // by 2^60 (bf16) / 2^15 (f16, 1/sqrt(D)-scaled logits only).
@@ -625,7 +644,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         __syncthreads();   // (flags are rewritten only by a later launch; this orders the LDS ring reuse)
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
-            m[b] = -INFINITY;
+            m[b] = -INFINITY;                  // (the exact pass finds its own reference max, FOLD or not)
             l[b] = 0.f;
             lsum[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -688,7 +707,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             }
         }
         const int row_b = qrow + 32 * b;
-        if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * p.scale + __logf(lt);
+        if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * (FOLD ? 0.69314718f : p.scale) + __logf(lt);   /* (FOLD: m is in log2 units) */
 #pragma unroll
         for (int i = 0; i < 32 / RPI; ++i) {
             const int rr = i * RPI + lane / CPR, ch = lane % CPR;
@@ -721,9 +740,9 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 }
 
 // (two query blocks per wave: hold the register allocator to 2 waves per SIMD = 256 registers)
-template <typename T, int D, int NWAVES, int QB, bool CAUSAL>
+template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false>
 __global__ __launch_bounds__(NWAVES * 64, QB == 2 ? 2 : 1) void fa_fwd_pipe_kernel(const FwdParams p) {
-    fa_fwd_pipe_body<T, D, NWAVES, QB, CAUSAL>(p);
+    fa_fwd_pipe_body<T, D, NWAVES, QB, CAUSAL, FOLD>(p);
 }
 
 template <typename T, int D, bool CAUSAL>
@@ -731,6 +750,7 @@ static hipError_t launch_pipe_c(const FwdParams& p, int waves, int qb, hipStream
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
     if (qb == 2) {
         if constexpr (D == 64) {
+            if (p.fold) return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
             return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         } else {
             return hipErrorInvalidValue;

@@ -40,6 +40,7 @@ struct FwdParams {
     int32_t nq_tiles;      // q tiles per group
     int32_t sched;         // groups per XCD bunch (>= 1): heavy-first order inside a bunch
     int32_t skipmax;       // f16 only: 1 = reference max from the first tile + overflow-triggered redo
+    int32_t fold;          // fa_fwd_pipe_kernel, head_dim 64, two blocks per wave: 1 = scale log2(e) folded into Q, reference max 0 (scaled calls)
     float scale;           // softmax scale
     float scale_log2;      // scale * log2(e)
     ExtraParams ex;

@@ -428,6 +428,74 @@ def test_key_halves_placement_balanced_block_order(knobs, G, L, D, split):
         torch.testing.assert_close(res[1][1][g:g + 1].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+def _run_strided(native, x, scale, causal=True):
+    G, L, D = x.shape[1:]
+    q, k, v = x.cuda()
+    out = torch.full_like(q, float("nan"))
+    lse = torch.full((G, L), float("nan"), device="cuda", dtype=torch.float32)
+    st = (L * D, 0, D)
+    native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, scale, causal=causal)
+    return out, lse
+
+
+@pytest.mark.parametrize("causal", [1, 0])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("G,L", [(2, 300), (3, 1000), (1, 4608), (9, 2049)])
+def test_scale_fold_of_the_pipelined_kernel(knobs, dtype, G, L, causal):
+    """Scaled calls (softmax_scale <= 1/4: the SDPA override's 1 / sqrt(D)) run the two-block pipelined kernel with scale log2(e) folded
+    into the Q fragments and the reference max fixed at 0 (fa_fwd_pipe.hip FOLD): out and logsumexp against the oracle, with the fold on
+    (the default) and off - the two must agree within the rounding of the re-rounded Q."""
+    _, native, _ = _mods()
+    from oracle import dense_attention_lse, frozen_randn
+
+    D, scale = 64, 64 ** -0.5
+    knobs.set("kernel", "pipe")
+    knobs.set("qb", 2)
+    x = frozen_randn(SEED + 37 * L + G, (3, G, L, D)).to(dtype)
+    if causal:
+        ref, ref_lse = _oracle(x, scale=scale)
+    else:
+        ref, ref_lse = dense_attention_lse(x[0][None], x[1][None], x[2][None], scale=scale, causal=False)
+        ref, ref_lse = ref[0], ref_lse[0]
+    res = {}
+    for fold in (-1, 0):
+        knobs.set("fold", fold)
+        out, lse = _run_strided(native, x, scale, causal)
+        _check(out, ref, dtype, f"pipe fold={fold} {dtype} causal={causal} {G}x{L}")
+        torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+        res[fold] = out
+    assert not torch.equal(res[-1], res[0]), "the fold was not in force"       # (re-rounded Q: results differ in the last bits)
+    assert (res[-1].float() - res[0].float()).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind", ["overflow", "underflow", "mixed"])
+def test_scale_fold_leaves_through_the_exact_pass(knobs, dtype, kind):
+    """With the reference max at 0 a P can overflow (scaled logits far above 0: the row sum turns inf / NaN) or a whole row can
+    underflow (every logit far below 0: row sum < 2^-80) - both must send the workgroup through the exact pass and come out right."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    G, L, D, scale = 3, 1024, 64, 64 ** -0.5
+    knobs.set("kernel", "pipe")
+    knobs.set("qb", 2)
+    if dtype == torch.float16:
+        knobs.set("skipmax", 1)
+    x = frozen_randn(SEED + 59, (3, G, L, D)) * 0.3
+    u = torch.zeros(D)
+    u[:16] = 1.0                                                   # |u|^2 = 16
+    amp = {"overflow": 9.0, "underflow": -9.0, "mixed": 9.0}[kind]   # q.k = +-81 * 16 = +-1296 -> scaled logit +-162 -> exponent +-234
+    x[0, 1] += u * 9.0
+    x[1, 1] += u * amp
+    if kind == "mixed":
+        x[1, 1, ::2] -= 2 * u * amp                                # every other key far below, the rest far above
+    x = x.to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale)
+    out, lse = _run_strided(native, x, scale)
+    _check(out, ref, dtype, f"pipe fold {kind}")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
+
+
 @pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
 @pytest.mark.parametrize("D,qb", [(128, 1), (64, 1), (64, 2)])
 def test_pipe16_growing_logits_force_the_exact_pass(knobs, step, D, qb):
