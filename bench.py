@@ -445,10 +445,10 @@ def main():
     g_launch = G // args.slabs if strong else G    # groups per kernel launch
     plan = _native.plan(g_launch, L, D, dtype, nq, nk)
 
-    if world > 1 and (args.backward or args.config == "cfg4_attn"):
-        raise SystemExit("--backward / cfg4_attn are single-GPU records")
+    if world > 1 and (args.backward or args.config in ("cfg4_attn", "cfg2_sdpa")):
+        raise SystemExit("--backward / cfg4_attn / cfg2_sdpa are single-GPU records")
     op_fn, op_flops, op_kernel, op_desc = None, None, None, None
-    if world == 1 and not strong and (args.backward or args.config == "cfg4_attn"):
+    if world == 1 and not strong and (args.backward or args.config in ("cfg4_attn", "cfg2_sdpa")):
         del qkv
         op_fn, op_flops, op_kernel, op_desc, plan_ = make_op(args.config, dev, seed=rank, backward=args.backward)
         plan = plan_ or plan
