@@ -563,8 +563,10 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.skipmax = plan.skipmax;
-    // the scale fold of the pipelined kernel (fa_fwd_pipe.hip FOLD): scaled calls only - softmax_scale <= 1/4, the SDPA override's 1 / sqrt(D)
-    p.fold = (sel.which == 'p' && D == 64 && plan.qb == 2 && plan.waves == 4 && softmax_scale <= 0.25f && options().fold != 0) ? 1 : 0;
+    // the scale fold of the pipelined kernel (fa_fwd_pipe.hip FOLD): scaled calls only - softmax_scale <= 1/4, the SDPA override's 1 / sqrt(D) -
+    // and bf16 only: with the reference max at 0 an f16 P overflows from a scaled logit of 11 on (2^16), which sharp attention heads reach,
+    // and every such workgroup would pay the exact pass; bf16 P has the fp32 exponent range (overflow needs a scaled logit of 88)
+    p.fold = (sel.which == 'p' && D == 64 && plan.qb == 2 && plan.waves == 4 && dtype == FA_DTYPE_BF16 && softmax_scale <= 0.25f && options().fold != 0) ? 1 : 0;
     p.perm_n = sel.perm_n;
     if (sel.perm_n > 0) memcpy(p.perm, sel.perm, sizeof(p.perm));
     p.stamps = nullptr;

@@ -750,7 +750,9 @@ static hipError_t launch_pipe_c(const FwdParams& p, int waves, int qb, hipStream
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
     if (qb == 2) {
         if constexpr (D == 64) {
-            if (p.fold) return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+            if constexpr (!Elt<T>::is_f16) {   // (the scale fold is selected for bf16 only: fa_capi.cpp)
+                if (p.fold) return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+            }
             return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         } else {
             return hipErrorInvalidValue;

@@ -464,8 +464,11 @@ def test_scale_fold_of_the_pipelined_kernel(knobs, dtype, G, L, causal):
         _check(out, ref, dtype, f"pipe fold={fold} {dtype} causal={causal} {G}x{L}")
         torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
         res[fold] = out
-    assert not torch.equal(res[-1], res[0]), "the fold was not in force"       # (re-rounded Q: results differ in the last bits)
-    assert (res[-1].float() - res[0].float()).abs().max().item() <= 2e-2
+    if dtype == torch.bfloat16:
+        assert not torch.equal(res[-1], res[0]), "the fold was not in force"   # (re-rounded Q: results differ in the last bits)
+        assert (res[-1].float() - res[0].float()).abs().max().item() <= 2e-2
+    else:                                                                      # f16 P would overflow from a scaled logit of 11 on: no fold
+        assert torch.equal(res[-1], res[0])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
