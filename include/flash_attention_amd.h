@@ -147,7 +147,8 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  *   "split"   0 auto | 1 | 2 | 4    kv split groups per workgroup ('d' kernel: 4 waves x 32 rows per group; 'h' kernel when forced with it)
  *   "pair"    -1 auto | 0 | 1       q-tile pairs (n - 1 - i, i) per workgroup ('d' kernel, causal, 4 waves)
  *   "balance" -1 auto | 0 | 1       placement-balanced block order of a causal grid below one round of workgroup slots
- *   "fold"    -1 auto | 0           0 = never fold scale log2(e) into Q (pipelined kernel, head_dim 64, softmax_scale <= 1/4)
+ *   "fold"    -1 auto (off) | 0 | 1   1 = fold scale log2(e) into Q (pipelined kernel, bf16, head_dim 64, softmax_scale <= 1/4): +5 %, but an
+ *                                   error of 2^-9 of the logit's magnitude - for callers who know their logits are small
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
 int fa_debug_set_option(const char* name, int32_t value);
 int fa_debug_get_option(const char* name, int32_t* value);

@@ -178,7 +178,7 @@ def fuzz(cases, seed, log=print):
         tol = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2, torch.float32: 1e-5}[dt]
         for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
             got = got.cpu().double()
-            floor = tol * max(1e-3, want.abs().max().item())
+            floor = tol * max(1e-1, want.abs().max().item())     # (absolute floor: an exactly-zero gradient - L = 1 - comes out as rounding noise of Dsum)
             if not (bool(torch.isfinite(got).all()) and bool(((got - want).abs() <= floor + 2e-2 * want.abs()).all())):
                 bad += 1
                 log(f"MISMATCH grouped-query backward case {case} {name}: B={B} H={H}/{Hkv} L={L} D={D} {dt} scale={scale:.3g} causal={causal} max|d|={(got - want).abs().max().item():.3e}")
