@@ -240,7 +240,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
                             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                        \
                                 if (p.ex.mask_kind == 2) {                                         \
                                     const vec4 b_ = __builtin_bit_cast(vec4, mq[4 * hb + j]);      \
-                                    _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += (float)b_[i] * p.ex.inv_scale; \
+                                    _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += bias_term((float)b_[i], p.ex.inv_scale); \
                                 } else {                                                           \
                                     const unsigned w_ = mq[4 * hb + j].x;                          \
                                     _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += ((w_ >> (8 * i)) & 0xffu) ? 0.f : -INFINITY; \
@@ -559,7 +559,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                         if constexpr (EXTRA == 2) {   /* requested one item ago */                 \
                             _Pragma("unroll") for (int e = 0; e < 16; ++e) {                       \
                                 const unsigned w_ = mkv[16 * hb + e];                              \
-                                if (p.ex.mask_kind == 2) s0[e] += (float)__builtin_bit_cast(T, (unsigned short)w_) * p.ex.inv_scale; \
+                                if (p.ex.mask_kind == 2) s0[e] += bias_term((float)__builtin_bit_cast(T, (unsigned short)w_), p.ex.inv_scale); \
                                 else s0[e] += w_ ? 0.f : -INFINITY;                                \
                             }                                                                      \
                             FA_KV_MASK_PF((J_) + 1, hb)                                            \

@@ -16,6 +16,13 @@
 #include "fa_params.h"
 #include "fa_tuning_table.h"
 
+// 1 = this build carries the kernels that no rule or table row selects (make EXPERIMENTAL=1): the register-staged baseline 't'
+// (fa_fwd_tile_kernel), the complementary-phase workgroups 'P' (fa_fwd_pp.hip) and the one-wave-per-SIMD AGPR variant
+// of the pipelined kernel at head_dim 128 ('p' with two query blocks per wave) - A/B material, not product code
+#ifndef FA_EXPERIMENTAL
+#define FA_EXPERIMENTAL 0
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -57,6 +64,7 @@ std::atomic<int64_t> g_stamp_bytes{0};
 
 int parse_kernel(const char* v) {   // dma | pipe | pipe16 | pp | tile
     if (!v) return 0;
+    if (!FA_EXPERIMENTAL && (strcmp(v, "pp") == 0 || v[0] == 'P' || v[0] == 't')) return 0;   // (not in this build)
     if (strcmp(v, "pp") == 0 || v[0] == 'P') return 'P';
     if (strcmp(v, "kh") == 0 || v[0] == 'h') return 'h';
     if (strcmp(v, "pipe16") == 0 || v[0] == 'x') return 'x';
@@ -159,6 +167,184 @@ int balanced_order(int n_slots, const int* weight, uint8_t* perm) {
     return n_slots;
 }
 
+// ---- the selection, in four steps that each do one thing: built-in rules -> measured table -> debug overrides -> ONE constraints pass
+// (what the kernels can actually launch, enforced on whatever the first three picked), then the plan's geometry.
+// tests/cpp/test_capi_host.cpp walks a grid of requests x every override through fa_plan and asserts the invariants.
+struct Request {
+    int64_t G, L, D, g8, cq, ck;   // cq / ck: the q / kv chunk lengths, capped at L
+    int32_t dtype, causal;
+    float scale;
+    int es, skip, wmax;            // element size; 1 = skip-max arithmetic; waves the q chunk allows
+    bool pipe_ok, want32;          // the pipelined kernels implement skip-max only; a kv chunk below 64 keys wants 32-key steps
+};
+struct Choice {
+    char which;                    // 'd' | 'p' | 'x' | 'P' | 'h' | 't'
+    int waves, qb, sched, source, split, table_pair;
+};
+
+// built-in rules (round-1 .. round-3 measurements)
+Choice rules_choice(const Request& r) {
+    Choice c{'d', r.wmax, 1, 0, 0, 1, 0};
+    const int64_t wgs256 = r.g8 * ((r.L + 255) / 256), wgs128 = r.g8 * ((r.L + 127) / 128);
+    if (r.D == 64 && r.pipe_ok && c.waves == 4 && r.cq >= 256 && r.L >= 4096 && wgs256 >= 1024) { c.which = 'p'; c.qb = 2; }
+    if (r.D == 128 && r.skip && c.waves == 4 && r.cq >= 256 && r.L >= 4096 && wgs256 >= 512) c.waves = 8;
+    // a grid of at most 512 128-row workgroups leaves CUs idle or at one workgroup each: split every q tile's kv loop over
+    // 2 | 4 wave groups of the same workgroup (measured: G=8 L=4096 394 -> 514, G=8 L=8192 754 -> 883, G=4 L=8192 D=128 458 -> 512)
+    if (c.waves == 4 && r.cq >= 128 && r.L >= 1024 && wgs128 <= 512) c.split = (r.D == 64 && r.L >= 2048) ? 4 : 2;
+    // ... and at head_dim 64 up to L = 2048 the 64-row workgroups with (row block, key half) waves do better still: same slots, twice the
+    // workgroups, half the chain per tile (measured, profiles/r03_kh: G=12..64 L=1024 +10..17 %, G=8..32 L=2048 +10..22 % over the split plans;
+    // L = 4096: level with 4 split groups; 768 workgroups and more: slower than the 128-row workgroups)
+    if (r.D == 64 && c.waves == 4 && r.cq >= 128 && !r.want32 && r.L >= 1024 && r.L <= 2048 && wgs128 <= 512) { c.which = 'h'; c.split = 1; }
+    // ... with two kv split groups on top where even the 64-row workgroups leave CUs idle (at most 256 128-row workgroups, L = 2048 .. 4096:
+    // G = 8 L = 2048 18.0 -> 15.5 us, G = 8 L = 4096 35.0 (4 split groups of 128-row workgroups) -> 30.5 us; L = 8192: the 128-row split plan stays)
+    if (r.D == 64 && c.waves == 4 && r.cq >= 128 && !r.want32 && r.L >= 2048 && r.L <= 4096 && wgs128 <= 256) { c.which = 'h'; c.split = 2; }
+    return c;
+}
+
+// measured table (fa_tuning_table.h): the first row whose bucket holds the request and whose tile the q chunk allows
+void table_choice(const Request& r, Choice* c) {
+    const int64_t wgs128 = r.g8 * ((r.L + 127) / 128);
+    for (const fa::TuneRow& t : fa::kTuneTable) {
+        if (t.D != r.D || t.skip != r.skip || t.causal != r.causal || r.L < t.L_lo || r.L > t.L_hi || wgs128 < t.wg_lo || wgs128 > t.wg_hi) continue;
+        if (32 * t.waves * t.qb > (r.cq > 32 ? r.cq : 32)) continue;   // the q chunk forbids the row's tile
+        if ((t.kernel == 'p' || t.kernel == 'x') && !r.pipe_ok) continue;
+        if (t.kernel == 'x' && r.D == 64 && t.waves != 4) continue;
+        c->which = t.kernel; c->waves = t.waves; c->qb = t.qb; c->sched = t.sched; c->source = 1;
+        c->split = t.split > 1 ? t.split : 1;
+        c->table_pair = t.pair;
+        return;
+    }
+}
+
+// debug overrides (fa_debug_set_option / FA_AMD_* at load): a forced variant ignores the chunk bound, as the forced kernel does
+void apply_overrides(const Request& r, const Options& opt, Choice* c) {
+    const int fk = opt.kernel, fw = opt.waves, fq = opt.qb, fs = opt.split;
+    const int64_t D = r.D, L = r.L, cq = r.cq;
+    const bool pipe_ok = r.pipe_ok;
+    char& which = c->which;
+    int &waves = c->waves, &qb = c->qb, &split = c->split;
+    if (fk || fw || fq || fs || opt.sched > 0 || (r.dtype == FA_DTYPE_F16 && opt.skipmax >= 0)) c->source = 2;
+    if (fk || fw || fq) { split = 1; c->table_pair = 0; } // (a forced tile drops the table's split / pairs unless forced too)
+    if ((fw || fq || fs > 1) && !fk && which == 'h') which = 'd';   // (the key-halves kernel has one tile shape: a forced tile leaves it)
+    if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
+    if (fk == 't') { which = 't'; qb = 1; }
+    else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
+    else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && D == 128) ? 8 : 4; if (!fq) qb = 1; }
+    else if (fk == 'P' && pipe_ok && D == 64) { which = 'P'; waves = 4; qb = 2; }
+    else if (fk == 'h') { which = 'h'; waves = 4; qb = 1; }
+    else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
+    if (fq == 1) qb = 1;
+    if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
+    if (fq == 2 && fk == 'x' && D == 64) qb = 2;
+    if (fq == 2 && fk == 'p' && D == 128 && pipe_ok && L >= 256 && FA_EXPERIMENTAL) { qb = 2; waves = 4; }   // the one-wave-per-SIMD AGPR variant (fa_fwd_pipe_ag_kernel)
+    if (fs == 1) split = 1;
+    if (fs > 1 && (fk == 0 || fk == 'd')) { which = 'd'; waves = 4; qb = 1; split = fs; }
+    if (fs > 1 && fk == 'h') split = fs;
+}
+
+// what the kernels can launch - enforced on whatever rules, table and overrides picked
+void apply_constraints(const Request& r, const Options& opt, Choice* c) {
+    const int fk = opt.kernel, fs = opt.split;
+    const int64_t D = r.D;
+    char& which = c->which;
+    int &waves = c->waves, &qb = c->qb, &split = c->split;
+    if (!FA_EXPERIMENTAL && (which == 't' || which == 'P')) which = 'd';      // (not in this build: make EXPERIMENTAL=1)
+    if (r.want32 && r.pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
+    if (which == 'p' && ((waves > 4 && D != 128) || !r.pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
+    if (which == 'x' && !r.pipe_ok) which = 'd';
+    if (which == 'P' && !(r.pipe_ok && D == 64)) which = 'd';
+    if (which == 'P') { waves = 4; qb = 2; split = 1; }
+    if (which == 'h') { waves = 4; qb = 1; if (!(split == 1 || split == 2 || (split == 4 && D == 64))) split = 1; }
+    if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
+    if (qb == 2 && !((D == 64 || (D == 128 && which == 'p' && FA_EXPERIMENTAL)) && waves == 4)) qb = 1;
+    if (which == 't' && waves > 4) waves = 4;
+    if (split > 1 && !((which == 'd' || which == 'h') && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
+}
+
+// q-tile pairs and the placement-balanced order ('d', causal), then the plan's geometry
+void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection* sel) {
+    fa_plan_t* plan = &sel->plan;
+    const char which = c.which;
+    const int waves = c.waves, qb = c.qb, split = c.split, sched = c.sched;
+    const int64_t L = r.L, D = r.D, g8 = r.g8;
+    const int es = r.es;
+    int pair = 0;
+    {
+        const int64_t nq128 = (L + 127) / 128;
+        const bool pair_ok = which == 'd' && r.causal && waves == 4 && qb == 1 && split == 1 && nq128 >= 2;
+        // measured (profiles/r03_short/sweep_*.txt): pairs LOSE 2..10 % at L = 1024 .. 4096 (4 resident workgroups per CU already hide each
+        // other's prologues; the pair's second tile waits for the first tile's stores at its first barrier) - built-in rule: off
+        if (c.table_pair && pair_ok && c.source == 1) pair = 1;          // (a measured row may switch them on)
+        if (opt.pair >= 0) { pair = (opt.pair != 0 && pair_ok) ? 1 : 0; c.source = 2; }
+    }
+    sel->pair = pair;
+    sel->perm_n = 0;
+    // (the key-halves kernel takes the order too, but measured no gain from it - G = 8 L = 4096 31.7 vs 31.5 us, profiles/r03_kh/balance_*.txt:
+    //  its launches are bound per SIMD, not per CU sum - so there it is applied on request only)
+    if (((which == 'd' && !pair && split == 1 && opt.balance != 0) || (which == 'h' && opt.balance == 1)) && r.causal && qb == 1 && waves == 4) {
+        const int rows = which == 'h' ? 64 : 32 * waves;                                    // q rows per workgroup
+        const int64_t nqt = (L + rows - 1) / rows, ng = g8 / 8;
+        const int64_t nitem = nqt;                                                          // workgroups per group
+        // resident workgroups per XCD: by LDS (33 KB per 4-wave group at head_dim 64, 66 KB at 128; 160 KB per CU)
+        const int per_cu = which == 'h' ? (D == 64 ? (split == 1 ? 4 : split == 2 ? 2 : 1) : (split == 1 ? 2 : 1)) : (D == 64 ? 4 : 2);
+        const int64_t slots_per_xcd = (int64_t)per_cu * kCusPerXcd;
+        if (ng * nitem <= slots_per_xcd && ng * nitem <= 128) {
+            int bunch_sz = (int)((8ll << 20) / (2 * L * D * es));
+            if (sched > 0) bunch_sz = sched;
+            if (opt.sched > 0) bunch_sz = opt.sched;
+            if (bunch_sz < 1) bunch_sz = 1;
+            if (bunch_sz > ng) bunch_sz = (int)ng;
+            const auto tiles_of = [&](int64_t qi) { const int64_t kv_end = (qi + 1) * rows < L ? (qi + 1) * rows : L; return (int)((kv_end + 63) / 64); };
+            int weight[128];
+            for (int s_ = 0; s_ < ng * nitem; ++s_) {    // the kernels' natural slot -> (group, work item) map (fa_fwd_dma.hip, fa_fwd_kh.hip)
+                const int per_bunch = bunch_sz * (int)nitem, b_ = s_ / per_bunch, rem = s_ - b_ * per_bunch;
+                const int g0 = b_ * bunch_sz, bc = (ng - g0) < bunch_sz ? (int)(ng - g0) : bunch_sz;
+                const int64_t qd = rem / bc;
+                weight[s_] = tiles_of(nqt - 1 - qd);
+            }
+            sel->perm_n = balanced_order((int)(ng * nitem), weight, sel->perm);
+        }
+    }
+    plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : which == 'P' ? 5 : which == 'h' ? 6 : 0;
+    plan->pair = pair;
+    plan->balanced = sel->perm_n > 0;
+    plan->waves = waves * split;
+    plan->qb = qb;
+    plan->block_q = 32 * waves * qb;
+    plan->block_kv = (which == 'p' || which == 'x' || which == 'P') ? 32 : 64;
+    plan->skipmax = r.skip;
+    plan->source = c.source;
+    plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
+    if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
+    if (which == 'h') {   // 4 waves = 2 row blocks x 2 key halves per kv split group: 64-row workgroups
+        plan->block_q = 64;
+        plan->grid = g8 * ((L + 63) / 64);
+    }
+    if (which == 'P') {   // one workgroup = 8 waves = two 256-row halves: the same q tile of two groups of one XCD class
+        plan->waves = 8;
+        plan->grid = 8 * ((g8 / 8 + 1) / 2) * ((L + 255) / 256);
+    }
+    plan->lds_bytes = which == 'P' ? 2 * (4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64)) + 32
+                      : which == 'x' ? 8 * 32 * D * 2 + 16
+                      : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
+                                   : which == 'h' ? split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64)) + 16 * split
+                                     : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
+    // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
+    // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
+    {
+        const int64_t kv_bytes = 2 * L * D * es;
+        int64_t bunch = sched > 0 ? sched : (8ll << 20) / kv_bytes;
+        if (opt.sched > 0) bunch = opt.sched;
+        int64_t ng = g8 / 8;
+        if (which == 'P') { bunch = (bunch + 1) / 2; ng = (ng + 1) / 2; }   // (counted in PAIRS of groups)
+        if (bunch < 1) bunch = 1;
+        if (bunch > ng) bunch = ng;
+        plan->sched = (int32_t)bunch;
+    }
+    sel->which = which;
+    sel->split = split;
+}
+
 int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, float scale, int32_t causal,
                 bool mfma16_ok, bool f32_ok, Selection* sel) {
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1 (got %lld, %lld, %lld)", (long long)G, (long long)L, (long long)D);
@@ -179,152 +365,22 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     const int64_t g8 = (G + 7) / 8 * 8;
     const int es = elt_size(dtype);
     if (mfma16_ok) {
+        Request r;
+        r.G = G; r.L = L; r.D = D; r.g8 = g8; r.dtype = dtype; r.causal = causal; r.scale = scale; r.es = es;
         // f16 skip-max pays off when logits are small against the 2^15 headroom of f16 P: a softmax scale
         // <= 0.25 means 1/sqrt(D)-style scaled attention (D >= 16); the packed op (scale 1) keeps the row max
-        int skip = dtype == FA_DTYPE_BF16 ? 1 : (scale <= 0.25f ? 1 : 0);
-        if (dtype == FA_DTYPE_F16 && opt.skipmax >= 0) skip = opt.skipmax != 0;
-        const int64_t cq = plan->chunk_q < L ? plan->chunk_q : L;
-        const int64_t ck = plan->chunk_kv < L ? plan->chunk_kv : L;
-        const int wmax = waves_for_chunk(cq);            // the q chunk bounds the workgroup's rows
-        const bool pipe_ok = skip != 0;                   // (the pipelined kernels implement the skip-max arithmetic only)
-        const bool want32 = ck < 64;                      // a kv chunk below 64 keys is served by 32-key steps
-        char which = 'd';
-        int waves = wmax, qb = 1, sched = 0, source = 0, split = 1, table_pair = 0;
-        // ---- built-in rules (round-1 measurements)
-        const int64_t wgs256 = g8 * ((L + 255) / 256);
-        if (D == 64 && pipe_ok && waves == 4 && cq >= 256 && L >= 4096 && wgs256 >= 1024) { which = 'p'; qb = 2; }
-        if (D == 128 && skip && waves == 4 && cq >= 256 && L >= 4096 && wgs256 >= 512) waves = 8;
-        // a grid of at most 512 128-row workgroups leaves CUs idle or at one workgroup each: split every q tile's kv loop over
-        // 2 | 4 wave groups of the same workgroup (measured: G=8 L=4096 394 -> 514, G=8 L=8192 754 -> 883, G=4 L=8192 D=128 458 -> 512)
-        if (waves == 4 && cq >= 128 && L >= 1024 && g8 * ((L + 127) / 128) <= 512) split = (D == 64 && L >= 2048) ? 4 : 2;
-        // ... and at head_dim 64 up to L = 2048 the 64-row workgroups with (row block, key half) waves do better still: same slots, twice the
-        // workgroups, half the chain per tile (measured, profiles/r03_kh: G=12..64 L=1024 +10..17 %, G=8..32 L=2048 +10..22 % over the split plans;
-        // L = 4096: level with 4 split groups; 768 workgroups and more: slower than the 128-row workgroups)
-        if (D == 64 && waves == 4 && cq >= 128 && !want32 && L >= 1024 && L <= 2048 && g8 * ((L + 127) / 128) <= 512) { which = 'h'; split = 1; }
-        // ... with two kv split groups on top where even the 64-row workgroups leave CUs idle (at most 256 128-row workgroups, L = 2048 .. 4096:
-        // G = 8 L = 2048 18.0 -> 15.5 us, G = 8 L = 4096 35.0 (4 split groups of 128-row workgroups) -> 30.5 us; L = 8192: the 128-row split plan stays)
-        if (D == 64 && waves == 4 && cq >= 128 && !want32 && L >= 2048 && L <= 4096 && g8 * ((L + 127) / 128) <= 256) { which = 'h'; split = 2; }
-        // ---- measured table
-        if (opt.table) {
-            const int64_t wgs128 = g8 * ((L + 127) / 128);
-            for (const fa::TuneRow& r : fa::kTuneTable) {
-                if (r.D != D || r.skip != skip || r.causal != causal || L < r.L_lo || L > r.L_hi || wgs128 < r.wg_lo || wgs128 > r.wg_hi) continue;
-                if (32 * r.waves * r.qb > (cq > 32 ? cq : 32)) continue;   // the q chunk forbids the row's tile
-                if ((r.kernel == 'p' || r.kernel == 'x') && !pipe_ok) continue;
-                if (r.kernel == 'x' && D == 64 && r.waves != 4) continue;
-                which = r.kernel; waves = r.waves; qb = r.qb; sched = r.sched; source = 1;
-                split = r.split > 1 ? r.split : 1;
-                table_pair = r.pair;
-                break;
-            }
-        }
-        // ---- debug overrides
-        const int fk = opt.kernel, fw = opt.waves, fq = opt.qb, fs = opt.split;
-        if (fk || fw || fq || fs || opt.sched > 0 || (dtype == FA_DTYPE_F16 && opt.skipmax >= 0)) source = 2;
-        if (fk || fw || fq) { split = 1; table_pair = 0; } // (a forced tile drops the table's split / pairs unless forced too)
-        if ((fw || fq || fs > 1) && !fk && which == 'h') which = 'd';   // (the key-halves kernel has one tile shape: a forced tile leaves it)
-        if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
-        if (fk == 't') { which = 't'; qb = 1; }
-        else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
-        else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && D == 128) ? 8 : 4; if (!fq) qb = 1; }
-        else if (fk == 'P' && pipe_ok && D == 64) { which = 'P'; waves = 4; qb = 2; }
-        else if (fk == 'h') { which = 'h'; waves = 4; qb = 1; }
-        else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
-        if (fq == 1) qb = 1;
-        if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
-        if (fq == 2 && fk == 'x' && D == 64) qb = 2;        // (a forced variant ignores the chunk bound, as the forced kernel does)
-        if (fs == 1) split = 1;
-        if (fs > 1 && (fk == 0 || fk == 'd')) { which = 'd'; waves = 4; qb = 1; split = fs; }
-        if (fs > 1 && fk == 'h') split = fs;
-        // ---- constraints of the kernels
-        if (want32 && pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
-        if (which == 'p' && ((waves > 4 && D != 128) || !pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
-        if (which == 'x' && !pipe_ok) which = 'd';
-        if (which == 'P' && !(pipe_ok && D == 64)) which = 'd';
-        if (which == 'P') { waves = 4; qb = 2; split = 1; }
-        if (which == 'h') { waves = 4; qb = 1; if (!(split == 1 || split == 2 || (split == 4 && D == 64))) split = 1; }
-        if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
-        if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
-        if (which == 't' && waves > 4) waves = 4;
-        if (split > 1 && !((which == 'd' || which == 'h') && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
-        // ---- q-tile pairs and the placement-balanced order ('d', causal)
-        int pair = 0;
-        {
-            const int64_t nq128 = (L + 127) / 128;
-            const bool pair_ok = which == 'd' && causal && waves == 4 && qb == 1 && split == 1 && nq128 >= 2;
-            // rule (measured, profiles/r03_pair): pairs pay where the fixed phases of a workgroup are a large share of its life
-            // (L <= 2048) and the paired grid still fills at least one round of the chip's slots
-            // measured (profiles/r03_short/sweep_*.txt): pairs LOSE 2..10 % at L = 1024 .. 4096 (4 resident workgroups per CU already hide each
-            // other's prologues; the pair's second tile waits for the first tile's stores at its first barrier) - built-in rule: off
-            if (table_pair && pair_ok && source == 1) pair = 1;          // (a measured row may switch them on)
-            if (opt.pair >= 0) { pair = (opt.pair != 0 && pair_ok) ? 1 : 0; source = 2; }
-        }
-        sel->pair = pair;
-        sel->perm_n = 0;
-        // (the key-halves kernel takes the order too, but measured no gain from it - G = 8 L = 4096 31.7 vs 31.5 us, profiles/r03_kh/balance_*.txt:
-        //  its launches are bound per SIMD, not per CU sum - so there it is applied on request only)
-        if (((which == 'd' && !pair && split == 1 && opt.balance != 0) || (which == 'h' && opt.balance == 1)) && causal && qb == 1 && waves == 4) {
-            const int rows = which == 'h' ? 64 : 32 * waves;                                    // q rows per workgroup
-            const int64_t nqt = (L + rows - 1) / rows, ng = g8 / 8;
-            const int64_t nitem = nqt;                                                          // workgroups per group
-            // resident workgroups per XCD: by LDS (33 KB per 4-wave group at head_dim 64, 66 KB at 128; 160 KB per CU)
-            const int per_cu = which == 'h' ? (D == 64 ? (split == 1 ? 4 : split == 2 ? 2 : 1) : (split == 1 ? 2 : 1)) : (D == 64 ? 4 : 2);
-            const int64_t slots_per_xcd = (int64_t)per_cu * kCusPerXcd;
-            if (ng * nitem <= slots_per_xcd && ng * nitem <= 128) {
-                int bunch_sz = (int)((8ll << 20) / (2 * L * D * es));
-                if (sched > 0) bunch_sz = sched;
-                if (opt.sched > 0) bunch_sz = opt.sched;
-                if (bunch_sz < 1) bunch_sz = 1;
-                if (bunch_sz > ng) bunch_sz = (int)ng;
-                const auto tiles_of = [&](int64_t qi) { const int64_t kv_end = (qi + 1) * rows < L ? (qi + 1) * rows : L; return (int)((kv_end + 63) / 64); };
-                int weight[128];
-                for (int s_ = 0; s_ < ng * nitem; ++s_) {    // the kernels' natural slot -> (group, work item) map (fa_fwd_dma.hip, fa_fwd_kh.hip)
-                    const int per_bunch = bunch_sz * (int)nitem, b_ = s_ / per_bunch, rem = s_ - b_ * per_bunch;
-                    const int g0 = b_ * bunch_sz, bc = (ng - g0) < bunch_sz ? (int)(ng - g0) : bunch_sz;
-                    const int64_t qd = rem / bc;
-                    weight[s_] = tiles_of(nqt - 1 - qd);
-                }
-                sel->perm_n = balanced_order((int)(ng * nitem), weight, sel->perm);
-            }
-        }
-        plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : which == 'P' ? 5 : which == 'h' ? 6 : 0;
-        plan->pair = pair;
-        plan->balanced = sel->perm_n > 0;
-        plan->waves = waves * split;
-        plan->qb = qb;
-        plan->block_q = 32 * waves * qb;
-        plan->block_kv = (which == 'p' || which == 'x' || which == 'P') ? 32 : 64;
-        plan->skipmax = skip;
-        plan->source = source;
-        plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
-        if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
-        if (which == 'h') {   // 4 waves = 2 row blocks x 2 key halves per kv split group: 64-row workgroups
-            plan->block_q = 64;
-            plan->grid = g8 * ((L + 63) / 64);
-        }
-        if (which == 'P') {   // one workgroup = 8 waves = two 256-row halves: the same q tile of two groups of one XCD class
-            plan->waves = 8;
-            plan->grid = 8 * ((g8 / 8 + 1) / 2) * ((L + 255) / 256);
-        }
-        plan->lds_bytes = which == 'P' ? 2 * (4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64)) + 32
-                          : which == 'x' ? 8 * 32 * D * 2 + 16
-                          : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
-                                       : which == 'h' ? split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64)) + 16 * split
-                                         : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
-        // groups per L2 bunch (see the kernels' block mapping): a bunch's K+V ~ 8 MiB measured best at
-        // L=4096, D=64 (bunch 1/2/4/8/16 -> 737/769/800/828/811 TFLOP/s)
-        {
-            const int64_t kv_bytes = 2 * L * D * es;
-            int64_t bunch = sched > 0 ? sched : (8ll << 20) / kv_bytes;
-            if (opt.sched > 0) bunch = opt.sched;
-            int64_t ng = g8 / 8;
-            if (which == 'P') { bunch = (bunch + 1) / 2; ng = (ng + 1) / 2; }   // (counted in PAIRS of groups)
-            if (bunch < 1) bunch = 1;
-            if (bunch > ng) bunch = ng;
-            plan->sched = (int32_t)bunch;
-        }
-        sel->which = which;
-        sel->split = split;
+        r.skip = dtype == FA_DTYPE_BF16 ? 1 : (scale <= 0.25f ? 1 : 0);
+        if (dtype == FA_DTYPE_F16 && opt.skipmax >= 0) r.skip = opt.skipmax != 0;
+        r.cq = plan->chunk_q < L ? plan->chunk_q : L;
+        r.ck = plan->chunk_kv < L ? plan->chunk_kv : L;
+        r.wmax = waves_for_chunk(r.cq);            // the q chunk bounds the workgroup's rows
+        r.pipe_ok = r.skip != 0;                   // (the pipelined kernels implement the skip-max arithmetic only)
+        r.want32 = r.ck < 64;                      // a kv chunk below 64 keys is served by 32-key steps
+        Choice c = rules_choice(r);
+        if (opt.table) table_choice(r, &c);
+        apply_overrides(r, opt, &c);
+        apply_constraints(r, opt, &c);
+        finish_mfma_plan(r, opt, c, sel);
     } else if (f32_ok) {
         plan->kernel = 3;
         plan->waves = 4;
@@ -372,6 +428,8 @@ extern "C" {
 
 int fa_abi_version(void) { return FA_ABI_VERSION; }
 
+int fa_experimental_kernels(void) { return FA_EXPERIMENTAL; }
+
 const char* fa_last_error(void) { return g_err; }
 
 const char* fa_error_string(int code) {
@@ -404,6 +462,8 @@ int fa_debug_set_option(const char* name, int32_t value) {
         if (value < o.lo || value > o.hi) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: %s=%d out of range [%d, %d]", name, value, o.lo, o.hi);
         if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 't' || value == 'P' || value == 'h'))
             return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x', 'P', 'h' or 't'");
+        if (o.field == &Options::kernel && !FA_EXPERIMENTAL && (value == 't' || value == 'P'))
+            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel '%c' is not in this build (make EXPERIMENTAL=1)", (char)value);
         if (o.field == &Options::waves && !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: waves must be 0, 1, 2, 4 or 8");
         if (o.field == &Options::split && value == 3) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: split must be 0, 1, 2 or 4");
@@ -583,10 +643,12 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, plan.qb, st)
+#if FA_EXPERIMENTAL
                    : sel.which == 'P' ? fa::launch_fwd_pp(p, dtype, st)
+                   : sel.which == 't' ? fa::launch_fwd_tile(p, dtype, plan.waves, st)
+#endif
                    : sel.which == 'h' ? fa::launch_fwd_kh(p, dtype, sel.split, st)
-                   : sel.which == 'd' ? fa::launch_fwd_dma(p, dtype, plan.waves / sel.split, plan.qb, sel.split, sel.pair, st)
-                                      : fa::launch_fwd_tile(p, dtype, plan.waves, st);
+                                      : fa::launch_fwd_dma(p, dtype, plan.waves / sel.split, plan.qb, sel.split, sel.pair, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
 }

@@ -31,6 +31,20 @@ __host__ __device__ __forceinline__ unsigned drop_tile_key(unsigned kg, unsigned
 }
 
 #if defined(__HIPCC__)   /* device-side loaders (fa_capi.cpp's host-only sanitizer build includes this header for mix32 alone) */
+// An additive bias reaches the RAW scores as bias / softmax_scale.  A finite "minus infinity" of the operand dtype - the common
+// torch.finfo(dtype).min padding convention, -3.39e38 in bf16 - must stay FINITE on the way: -3.39e38 * 8 is -inf in fp32, and a row
+// whose keys are all padded that way would then end with l = 0 and O = NaN where torch returns the uniform average of V (its masked
+// scores are all equal).  So the converted term is held at a floor of -2^99 unless the bias is exactly -inf:
+//   * far below any real score, and it ABSORBS the raw score (|s| < 2^75): every padded key of a row gets the same logit, as in torch;
+//   * a power of two, so that the row constants derived from it are exact: a fully padded row has m = -2^99, m c and
+//     lse = m scale (log l is absorbed) without rounding, hence the backward's exponent (s c - lse log2 e) is exactly 0 and its
+//     P is 1 - finite, never the 2^(+-1e22) a rounded floor gives (such a row's true P is 1 / l: stock SDPA's fused backward has
+//     the same artefact, and a padded row's dO is normally zero);
+//   * small enough that (floor - m) scale log2(e) cannot overflow in the exponent arithmetic for any scale up to 2^28.
+__device__ __forceinline__ float bias_term(float bias, float inv_scale) {
+    const float t = bias * inv_scale;
+    return bias == -INFINITY ? t : __builtin_fmaxf(t, -0x1p99f);
+}
 // four consecutive keys k0 .. k0+3 of one mask row -> additive terms on the raw scores
 template <typename T>
 __device__ __forceinline__ void mask_load4(int kind, bool fast, const char* mrow, int k0, int L, float inv_scale, float (&a)[4]) {
@@ -40,10 +54,10 @@ __device__ __forceinline__ void mask_load4(int kind, bool fast, const char* mrow
         if (fast) {
             const vec4 v = *(const vec4*)(mp + k0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = (float)v[i] * inv_scale;
+            for (int i = 0; i < 4; ++i) a[i] = bias_term((float)v[i], inv_scale);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = (float)mp[k0 + i < L ? k0 + i : L - 1] * inv_scale;
+            for (int i = 0; i < 4; ++i) a[i] = bias_term((float)mp[k0 + i < L ? k0 + i : L - 1], inv_scale);
         }
     } else {
         const unsigned char* mp = (const unsigned char*)mrow;
@@ -60,7 +74,7 @@ __device__ __forceinline__ void mask_load4(int kind, bool fast, const char* mrow
 // one element (the key-on-the-lane kernels: consecutive lanes read consecutive keys of one row)
 template <typename T>
 __device__ __forceinline__ float mask_load1(int kind, const char* mbase, int64_t row_off_elems, int key, float inv_scale) {
-    if (kind == 2) return (float)((const T*)mbase)[row_off_elems + key] * inv_scale;
+    if (kind == 2) return bias_term((float)((const T*)mbase)[row_off_elems + key], inv_scale);
     return ((const unsigned char*)mbase)[row_off_elems + key] ? 0.f : -INFINITY;
 }
 

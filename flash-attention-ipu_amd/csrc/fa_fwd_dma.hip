@@ -264,8 +264,8 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                     if (p.ex.mask_kind == 2) {                                                     \
                         const vec4 b0_ = __builtin_bit_cast(vec4, mraw[j]), b1_ = __builtin_bit_cast(vec4, mraw[4 + j]); \
                         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                            \
-                            s0[0][4 * j + i] += (float)b0_[i] * p.ex.inv_scale;                    \
-                            s1[0][4 * j + i] += (float)b1_[i] * p.ex.inv_scale;                    \
+                            s0[0][4 * j + i] += bias_term((float)b0_[i], p.ex.inv_scale);              \
+                            s1[0][4 * j + i] += bias_term((float)b1_[i], p.ex.inv_scale);              \
                         }                                                                          \
                     } else {                                                                       \
                         const unsigned w0_ = mraw[j].x, w1_ = mraw[4 + j].x;           \

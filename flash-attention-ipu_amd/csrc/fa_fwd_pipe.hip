@@ -83,9 +83,12 @@ namespace fa {
 // instructions go (456 -> 328 issue cycles against 576 matrix cycles: the step turns matrix-bound).  Any reference value cancels in
 // O / l; what 0 must guarantee is that P neither overflows (caught as before: the row sum turns inf / NaN) nor underflows to nothing
 // (caught by a row sum below 2^-80) - either sends the workgroup through the exact pass, which works on the folded scores with c = 1.
-template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false>
+// AG (one wave per SIMD, the whole 512-entry register file: head_dim 128 with two query blocks per wave): the O^T accumulators and
+// the Q^T fragments live in AGPRs (fa_device.h MfmaAsm), the architectural VGPRs hold the two score tiles, P and the operand fragments.
+template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false, bool AG = false>
 __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     using E = Elt<T>;
+    using MA = MfmaAsm<T>;
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
     constexpr int WQ = 32 * QB;                 // query rows per wave
@@ -284,8 +287,12 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             _Pragma("unroll") for (int e = 0; e < 16; ++e) S_[b][e] = 0.f;                         \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                        \
             const vec8 kf_ = *(const vec8*)(kb_ + k_rd[ks]);                                       \
-            _Pragma("unroll") for (int b = 0; b < QB; ++b) S_[b] = E::mfma(kf_, qf[b][ks], S_[b]); \
+            _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                       \
+                if constexpr (AG) { if (ks == 0) MA::bq0(S_[b], kf_, qf[b][ks]); else MA::bq(S_[b], kf_, qf[b][ks]); } \
+                else S_[b] = E::mfma(kf_, qf[b][ks], S_[b]);                                       \
+            }                                                                                      \
         }                                                                                          \
+        if constexpr (AG) FA_MFMA_SETTLE();                                                        \
     }
     // O_b^T += V(slot)^T P_b^T
 #define FA_PV_H(P_, SLOT_)                                                                         \
@@ -299,10 +306,13 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
                     (i16x4 __attribute__((address_space(3)))*)(vp + 512));                         \
                 const i16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);          \
-                _Pragma("unroll") for (int b = 0; b < QB; ++b)                                     \
-                    o[b][dt] = E::mfma(__builtin_bit_cast(vec8, v8), P_[b][kk], o[b][dt]);         \
+                _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                   \
+                    if constexpr (AG) MA::acc_a(o[b][dt], __builtin_bit_cast(vec8, v8), P_[b][kk]); \
+                    else o[b][dt] = E::mfma(__builtin_bit_cast(vec8, v8), P_[b][kk], o[b][dt]);    \
+                }                                                                                  \
             }                                                                                      \
         }                                                                                          \
+        if constexpr (AG) FA_MFMA_SETTLE();                                                        \
     }
 #define FA_MASK_H(S_, J_)                                                                          \
     _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
@@ -414,6 +424,11 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 SC_[b_][e_ + 1] = fast_exp2(SC_[b_][e_ + 1]);                                      \
             }                                                                                      \
         }
+#define FA_ITEM_EXP1(SC_, V_, EL_, MASK_)                                                          \
+        {                                                                                          \
+            constexpr int b_ = (V_) / 8, e_ = 2 * ((V_) % 8) + (EL_);                              \
+            if constexpr (!FA_ITEM_DEAD(MASK_, b_)) SC_[b_][e_] = fast_exp2(SC_[b_][e_]);          \
+        }
 #define FA_ITEM_SUM(SC_, PC_, V_, MASK_)                                                           \
         {                                                                                          \
             constexpr int b_ = (V_) / 8, p_ = (V_) % 8, e_ = 2 * p_;                               \
@@ -468,7 +483,10 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             constexpr int n_ = decltype(gi_)::value, g_ = n_ / QB, b_ = n_ % QB;                   \
             if constexpr (FA_OPND_IS_K(g_, NK)) {                                                  \
                 constexpr int kx_ = FA_OPND_KIDX(g_, NK);                                          \
-                if constexpr (kx_ == 0) {                                                          \
+                if constexpr (AG) {                                                                \
+                    if constexpr (kx_ == 0) MA::bq0(SN_[b_], opnd[g_], qf[b_][kx_ < KS ? kx_ : 0]); \
+                    else MA::bq(SN_[b_], opnd[g_], qf[b_][kx_ < KS ? kx_ : 0]);                    \
+                } else if constexpr (kx_ == 0) {                                                   \
                     f32x16 z_;                                                                     \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) z_[e] = 0.f;                    \
                     SN_[b_] = E::mfma(opnd[g_], qf[b_][kx_ < KS ? kx_ : 0], z_);                   \
@@ -477,7 +495,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 }                                                                                  \
             } else {                                                                               \
                 constexpr int t_ = FA_OPND_VIDX(g_, NK);                                           \
-                o[b_][t_ % DT] = E::mfma(opnd[g_], PP_[b_][t_ / DT], o[b_][t_ % DT]);              \
+                if constexpr (AG) MA::acc_a(o[b_][t_ % DT], opnd[g_], PP_[b_][t_ / DT]);           \
+                else o[b_][t_ % DT] = E::mfma(opnd[g_], PP_[b_][t_ / DT], o[b_][t_ % DT]);         \
             }                                                                                      \
             if constexpr (b_ == QB - 1 && g_ + PF_ < NM && g_ + PF_ >= NPRE) { FA_OPND_LOAD(g_ + PF_, NK) } \
             /* the NEXT step's V^T fragments, requested once this step's have been consumed */     \
@@ -485,12 +504,23 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 FA_PRE_LOAD(g_ - NPRE, vnext_)                                                     \
             }                                                                                      \
             /* this MFMA's share of the vector work items */                                      \
+            if constexpr (AG && NMF == 2 * NV) {   /* one wave per SIMD: at most one transcendental and <= 24 issue cycles per MFMA gap */ \
+                constexpr int v_ = n_ / 2;                                                         \
+                if constexpr (n_ % 2 == 0) {                                                       \
+                    if constexpr (v_ + 1 < NV) { FA_ITEM_EXP1(SC_, v_ + 1, 0, MASK_) }             \
+                    FA_ITEM_SUM(SC_, PC_, v_, MASK_)                                               \
+                } else {                                                                           \
+                    if constexpr (v_ + 1 < NV) { FA_ITEM_EXP1(SC_, v_ + 1, 1, MASK_) }             \
+                    if constexpr (v_ + 2 < NV) { FA_ITEM_FMA(SC_, v_ + 2, MASK_) }                 \
+                }                                                                                  \
+            } else {                                                                               \
             fa_static_for<(n_ * NV) / NMF, ((n_ + 1) * NV) / NMF>([&](auto vi_) {                  \
                 constexpr int v_ = decltype(vi_)::value;                                           \
                 if constexpr (v_ + 1 < NV) { FA_ITEM_EXP(SC_, v_ + 1, MASK_) }                     \
                 FA_ITEM_SUM(SC_, PC_, v_, MASK_)                                                   \
                 if constexpr (v_ + 2 < NV) { FA_ITEM_FMA(SC_, v_ + 2, MASK_) }                     \
             });                                                                                    \
+            }                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         });                                                                                        \
         _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                           \
@@ -512,6 +542,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // S(i+1) -> sb, P(i-1) in pb, P(i) -> pa) and rotate by copying afterwards: one instantiation each instead of
     // one per parity (parity branches make hipcc shuffle the whole accumulator state through phi copies)
 #define FA_ROTATE()                                                                                \
+    if constexpr (AG) FA_MFMA_SETTLE();   /* (the copies below read what the step's last asm MFMAs wrote) */ \
     _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
         sa[b] = sb[b];                                                                             \
         pb[b][0] = pa[b][0];                                                                       \
@@ -672,6 +703,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #undef FA_ITEM_MASKED
 #undef FA_ITEM_DEAD
 #undef FA_ITEM_EXP
+#undef FA_ITEM_EXP1
 #undef FA_ITEM_SUM
 #undef FA_GENERIC
 #undef FA_RUN
@@ -687,6 +719,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     FA_STAMP(st2_)
     // ---- epilogue: O /= l through LDS, whole-row stores (as fa_fwd_dma_kernel; the K ring is free now)
     if (!wave_active) return;
+    if constexpr (AG) FA_MFMA_SETTLE();
     unsigned char* slab = smem + wave * (32 * ROWB);
     constexpr int CPR = D / 8;
     constexpr int RPI = 64 / CPR;
@@ -744,6 +777,13 @@ template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false>
 __global__ __launch_bounds__(NWAVES * 64, QB == 2 ? 2 : 1) void fa_fwd_pipe_kernel(const FwdParams p) {
     fa_fwd_pipe_body<T, D, NWAVES, QB, CAUSAL, FOLD>(p);
 }
+// head_dim 128, two query blocks per wave: 64 rows per wave, 256-row workgroups of 4 waves, ONE wave per SIMD with the whole
+// 512-entry register file (O^T and Q^T in AGPRs) - every K row / V^T fragment read from LDS feeds two MFMAs and a streamed
+// K/V step serves 256 rows: half the LDS operand reads and half the L2 -> LDS DMA per FLOP of the 128-row workgroups.
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void fa_fwd_pipe_ag_kernel(const FwdParams p) {
+    fa_fwd_pipe_body<T, 128, 4, 2, CAUSAL, false, true>(p);
+}
 
 template <typename T, int D, bool CAUSAL>
 static hipError_t launch_pipe_c(const FwdParams& p, int waves, int qb, hipStream_t stream) {
@@ -755,7 +795,8 @@ static hipError_t launch_pipe_c(const FwdParams& p, int waves, int qb, hipStream
             }
             return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         } else {
-            return hipErrorInvalidValue;
+            if (waves != 4) return hipErrorInvalidValue;
+            return launch1((const void*)(fa_fwd_pipe_ag_kernel<T, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         }
     }
     hipError_t e;

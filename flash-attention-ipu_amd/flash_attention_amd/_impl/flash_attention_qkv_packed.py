@@ -6,6 +6,8 @@ import torch
 
 from . import _native, ops
 
+PAD_HEAD_DIM_MIN_ROWS = 4096   # query rows (groups x L) from which a head dim other than 64 / 128 is padded to one
+
 
 def flash_attention_qkv_packed(qkv: torch.Tensor, num_chunks_q: int, num_chunks_kv: int) -> torch.Tensor:
     """
@@ -41,6 +43,13 @@ def flash_attention_qkv_packed(qkv: torch.Tensor, num_chunks_q: int, num_chunks_
         if qkv.dtype not in _native.FA_DTYPE:
             raise TypeError(f"flash_attention_qkv_packed: unsupported dtype {qkv.dtype} on GPU")
         # HIP forward; HIP backward through autograd (an opaque torch.library custom op under torch.compile)
+        D = qkv.shape[3]
+        if D not in (64, 128) and D < 128 and qkv.shape[1] * qkv.shape[2] >= PAD_HEAD_DIM_MIN_ROWS and not torch.compiler.is_compiling():
+            # a head dim the MFMA kernels do not take, on a call too large for the generic (scalar fp32) kernel: zero columns change
+            # neither Q K^T nor the first D columns of P V (the op applies no 1 / sqrt(D) scale, FA.cpp:254), so the call runs at the
+            # next MFMA head dim and the result is sliced; autograd sees pad / slice.  (D > 128 stays on the generic kernel.)
+            padded = torch.nn.functional.pad(qkv, (0, (64 if D < 64 else 128) - D))
+            return ops.attention_qkv_packed(padded, int(num_chunks_q), int(num_chunks_kv))[..., :D].contiguous()
         return ops.attention_qkv_packed(qkv, int(num_chunks_q), int(num_chunks_kv))
 
     # CPU tensors: the op's CPU branch (fa.py:47-53) - dense attention with an additive -10000 mask.

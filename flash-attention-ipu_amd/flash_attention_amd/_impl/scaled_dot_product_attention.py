@@ -31,6 +31,24 @@ def chunk_heuristic(L: int, D: int):
     return int(2 ** (ceil(log2(ratio) / 2))), int(2 ** (floor(log2(ratio) / 2)))
 
 
+# Head dims other than 64 / 128.  The reference's op has no head-dim restriction (FA.cpp:175-195; its own tests run D = 2,
+# t_cpp:245-251) and the C ABI serves every D <= 1024 - but only D in {64, 128} through the MFMA kernels; anything else runs the
+# generic kernel (one workgroup per query row, scalar fp32 arithmetic: a correctness path), which an
+# `import flash_attention_amd.auto` must not silently put under a D = 96 model.  So for calls of at least this many query rows:
+#   D < 128: the operands are zero-padded along D to the next MFMA head dim (zero columns change neither Q K^T nor the first D
+#            columns of P V; the scale stays D^-1/2 of the TRUE head dim) and the result is sliced - forward and backward run the
+#            MFMA kernels, autograd sees pad / slice (three extra copies of q, k, v: ~25 % of the attention time at L = 2048, D = 96,
+#            still well ahead of stock SDPA: tests/test_gpu_head_dims.py asserts it);
+#   D > 128: stock SDPA (`orig_fn`) serves the call.
+# Smaller calls (the reference's own tiny test shapes) stay on the generic kernel: exact fp32 arithmetic, no copies.
+GENERIC_KERNEL_MAX_ROWS = 4096
+
+
+def _mfma_head_dim(D: int):
+    """the head dim the MFMA kernels would run a D-wide call at (None: no such kernel)"""
+    return D if D in (64, 128) else 64 if D < 64 else 128 if D < 128 else None
+
+
 def _gqa_ok(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor) -> bool:
     """[B, H, L, D] query with [B, H_kv, L, D] key / value, H a multiple of H_kv (grouped- / multi-query)."""
     return (query.ndim == 4 and key.ndim == 4 and key.shape == value.shape and query.shape[0] == key.shape[0]
@@ -77,6 +95,11 @@ def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale
     return out.squeeze(1) if query.ndim == 3 else out
 
 
+def _unpad(out: torch.Tensor, D_true: int) -> torch.Tensor:
+    """the first D_true columns of a result computed at a padded head dim (contiguous, as stock SDPA's result is)"""
+    return out if out.shape[-1] == D_true else out[..., :D_true].contiguous()
+
+
 @patch_function(torch.nn.functional.scaled_dot_product_attention, [torch.nn.functional])
 def _scaled_dot_product_attention_amd(
     orig_fn: Callable,
@@ -120,11 +143,22 @@ def _scaled_dot_product_attention_amd(
     # else is stock SDPA's business
     if on_device and scale is not None and not (scale > 0.0 and scale < float("inf")):
         on_device = False
+    D_true = query.shape[-1]
+    if on_device and D_true not in (64, 128) and query.numel() > 0 and query.numel() // D_true >= GENERIC_KERNEL_MAX_ROWS:
+        Dp = _mfma_head_dim(D_true)
+        if Dp is None or torch.compiler.is_compiling():
+            on_device = False       # (no MFMA kernel for this head dim: stock SDPA, not the scalar generic kernel)
+        else:
+            if scale is None:
+                scale = D_true ** -0.5
+            query, key, value = (torch.nn.functional.pad(t, (0, Dp - D_true)) for t in (query, key, value))
     if on_device and (attn_mask is not None or dropout_p > 0.0):
         out = _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale)
         if out is not None:
-            return out
+            return _unpad(out, D_true)
         on_device = False       # (a combination the mask / dropout kernels do not take: stock SDPA serves it)
+        if query.shape[-1] != D_true:
+            query, key, value = (t[..., :D_true] for t in (query, key, value))
     if on_device:
         L, D = query.shape[-2:]
         batch_shape = query.shape[:-2]
@@ -136,11 +170,11 @@ def _scaled_dot_product_attention_amd(
         if not needs_grad and query.ndim == 4 and query.numel() > 0:
             # inference on [B, H, L, D] views (e.g. slices of a fused [B, T, 3C] projection): no copies at all;
             # grouped-query K/V heads are resolved inside the kernel
-            return ops.attention_bhld(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+            return _unpad(ops.attention_bhld(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal), D_true)
         if gqa:   # training with grouped K/V heads: resolved inside the forward AND the backward kernels (no expanded K/V)
-            return ops.attention_gqa(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+            return _unpad(ops.attention_gqa(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal), D_true)
         out = ops.attention(query.reshape(-1, L, D), key.reshape(-1, L, D), value.reshape(-1, L, D),
                             softmax_scale, num_chunks_q, num_chunks_kv, causal)
-        return out.view(*batch_shape, L, D)
+        return _unpad(out.view(*batch_shape, L, D), D_true)
 
     return orig_fn(query, key, value, attn_mask, dropout_p, is_causal, **extra)

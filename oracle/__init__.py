@@ -15,6 +15,7 @@ from .dense_attention import (  # noqa: F401
     dense_causal_attention,
     dense_causal_attention_lse,
     dense_causal_attention_rows,
+    dense_causal_attention_grads_blocked,
     dense_attention_lse,
     sdpa_chunk_heuristic,
     frozen_randn,

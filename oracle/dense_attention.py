@@ -106,6 +106,42 @@ def dense_causal_attention_rows(qkv: torch.Tensor, rows, scale: float = 1.0, com
     return torch.stack(outs), torch.stack(lses)
 
 
+def dense_causal_attention_grads_blocked(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dout: torch.Tensor, scale: float = 1.0,
+                                         slab: int = 2048):
+    """Gradients of ONE group of the causal op - O = softmax(scale Q K^T + mask) V, fa.py:48-53 - evaluated in fp64 by query-row
+    slabs, so that the reference test sizes a dense autograd cannot hold are reachable (t_fa.py:56-93 goes to L = 16384: a dense
+    [L, L] fp64 matrix is 2 GB there, autograd keeps several).  The closed forms are those of the reference's own grad graph
+    (flashAttentionQKVPackedGrad, FA.cpp:375-492): with P the softmax rows of a slab,  Dsum = rowsum(dO o O),
+    dS = P o (dO V^T - Dsum),  dQ = scale dS K,  dK += scale dS^T Q,  dV += P^T dO.
+    q, k, v, dout: [L, D] CPU tensors (any float dtype); returns (out, dq, dk, dv) in fp64.  tests/test_oracle.py pins it against
+    autograd through dense_causal_attention at sizes both can run."""
+    q, k, v, dout = (t.to(torch.float64) for t in (q, k, v, dout))
+    L, D = q.shape
+    out = torch.empty(L, D, dtype=torch.float64)
+    dq = torch.empty(L, D, dtype=torch.float64)
+    dk = torch.zeros(L, D, dtype=torch.float64)
+    dv = torch.zeros(L, D, dtype=torch.float64)
+    cols = torch.arange(L)[None, :]
+    for r0 in range(0, L, slab):
+        r1 = min(L, r0 + slab)
+        n = r1                       # causal: keys 0 .. r1 - 1 are all a slab's rows can see
+        s = (q[r0:r1] @ k[:n].T) * scale
+        s += torch.where(cols[:, :n] > torch.arange(r0, r1)[:, None], torch.tensor(MASK_VALUE, dtype=torch.float64), torch.tensor(0.0, dtype=torch.float64))
+        p = torch.softmax(s, dim=-1)
+        del s
+        o = p @ v[:n]
+        out[r0:r1] = o
+        dp = dout[r0:r1] @ v[:n].T
+        dsum = (dout[r0:r1] * o).sum(dim=-1, keepdim=True)
+        dv[:n] += p.T @ dout[r0:r1]
+        ds = p * (dp - dsum)
+        del p, dp
+        dq[r0:r1] = (ds @ k[:n]) * scale
+        dk[:n] += (ds.T @ q[r0:r1]) * scale
+        del ds
+    return out, dq, dk, dv
+
+
 def sdpa_chunk_heuristic(L: int, D: int):
     """(num_chunks_q, num_chunks_kv) exactly as sdpa.py:52-53 chooses them."""
     r = max(L, D) // D

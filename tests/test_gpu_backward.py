@@ -240,3 +240,72 @@ def test_gradients_from_the_kernels_lse_vs_the_oracles_lse(dtype):
     assert e_k <= 1.5 * e_o + 1e-3, (e_k, e_o)
     for i, n in enumerate("qkv"):
         _close(grads["kernel"][i].to(dtype), ref_grad[i], f"d{n} from the kernel's stash")
+
+
+def _blocked_check(x, dout, groups, scale, what, slab=2048):
+    """gradients of `groups` of a packed launch against the blocked fp64 oracle (one [slab, L] score slab at a time)"""
+    from oracle import dense_causal_attention_grads_blocked
+
+    for g in groups:
+        q, k, v = (x.detach()[i, g].cpu() for i in range(3))
+        _, dq, dk, dv = dense_causal_attention_grads_blocked(q, k, v, dout[g].cpu(), scale=scale, slab=slab)
+        for got, want, name in ((x.grad[0, g], dq, "dq"), (x.grad[1, g], dk, "dk"), (x.grad[2, g], dv, "dv")):
+            _close(got, want, f"{what} group {g} {name}")
+
+
+def test_backward_at_the_benchmarked_shape_cfg2():
+    """`secondary.cfg2_bwd` of bench.py times fa_bwd on packed qkv [3, 128, 4096, 64] bf16: the same launch here, three sampled groups
+    against the fp64 oracle (the dK/dV workgroups sweep 32+ query tiles per key block only from this length on) + determinism and
+    group-permutation equivariance of the WHOLE launch (round-3 verdict: the backward was timed where it was not checked)."""
+    import flash_attention_amd as fa
+
+    G, L, D = 128, 4096, 64
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    qkv = (torch.randn(3, G, L, D, device="cuda", generator=gen) * 0.5).to(torch.bfloat16)
+    dout = torch.randn(G, L, D, device="cuda", generator=gen).to(torch.bfloat16)
+    x = qkv.clone().requires_grad_(True)
+    fa.flash_attention_qkv_packed(x, 8, 8).backward(dout)
+    assert torch.isfinite(x.grad).all()
+    _blocked_check(x, dout, (0, 77, G - 1), 1.0, "cfg2_bwd")
+    x2 = qkv.clone().requires_grad_(True)
+    fa.flash_attention_qkv_packed(x2, 8, 8).backward(dout)
+    assert torch.equal(x2.grad, x.grad), "no atomics: bitwise reproducible"
+    perm = torch.randperm(G, device="cuda", generator=gen)
+    x3 = qkv[:, perm].clone().requires_grad_(True)
+    fa.flash_attention_qkv_packed(x3, 8, 8).backward(dout[perm])
+    assert torch.equal(x3.grad, x.grad[:, perm]), "groups never interact"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("L,nq,nk", [(4096, 8, 4), (16384, 16, 8)])
+def test_backward_at_the_reference_python_test_sizes(dtype, L, nq, nk):
+    """t_fa.py:56-93: N = 4, D = 128, L in {256, 1024, 4096, 16384}, out AND grads (the two short lengths are covered above and in
+    test_packed_backward_vs_oracle).  One group through the blocked fp64 oracle at L = 16384 (268 MB per score slab), two at 4096;
+    chunk counts as the reference's heuristic picks them (sdpa.py:52-53)."""
+    import flash_attention_amd as fa
+
+    N, D = 4, 128
+    gen = torch.Generator(device="cuda").manual_seed(L)
+    qkv = (torch.randn(3, N, L, D, device="cuda", generator=gen) * 0.35).to(dtype)      # unscaled logits: std ~ 1.4
+    dout = torch.randn(N, L, D, device="cuda", generator=gen).to(dtype)
+    x = qkv.clone().requires_grad_(True)
+    out = fa.flash_attention_qkv_packed(x, nq, nk)
+    out.backward(dout)
+    assert torch.isfinite(x.grad).all()
+    _blocked_check(x, dout, (N - 1,) if L > 4096 else (0, N - 1), 1.0, f"t_fa {dtype} L={L}")
+
+
+def test_backward_fp16_at_the_reference_cpp_test_size():
+    """t_cpp:289-295: fp16, G = 8, L = 2048, D = 128 backward (the reference bounds max|delta| by 1.0 there; the bound here is the
+    suite's own, tol * max|ref| + 2e-2 |ref|) - every group against autograd through the fp64 oracle."""
+    import flash_attention_amd as fa
+    from oracle import frozen_randn
+
+    G, L, D = 8, 2048, 128
+    qkv = (frozen_randn(SEED + 2048, (3, G, L, D)) * 0.35).to(torch.float16)
+    dout = frozen_randn(SEED + 2049, (G, L, D)).to(torch.float16)
+    x = qkv.cuda().requires_grad_(True)
+    out = fa.flash_attention_qkv_packed(x, 4, 4)
+    out.backward(dout.cuda())
+    _blocked_check(x, dout, range(G), 1.0, "t_cpp fp16 8x2048x128")
+    assert (x.grad.float() - 0).abs().max().item() < 1e4

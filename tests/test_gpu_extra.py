@@ -247,3 +247,57 @@ def test_generic_kernels_serve_mask_and_dropout_for_everything_else(dtype, D, L)
             assert err <= 1e-4 * max(1.0, want.abs().max().item()), (name, err)
         else:
             _grad_close(got, want, f"{name} generic {dtype} D={D}")
+
+
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.float16, 64), (torch.bfloat16, 128)])
+@pytest.mark.parametrize("mask_shape", ["B11L", "BHLL"])
+def test_finfo_min_padding_mask_with_fully_masked_rows(dtype, D, mask_shape):
+    """The common padding convention: an additive mask filled with torch.finfo(dtype).min (NOT -inf).  bias / softmax_scale overflows
+    fp32 for it (-3.39e38 * 8), which used to turn a row whose keys are all padded into l = 0, O = NaN where the op's definition
+    (softmax of equal logits) gives the uniform average of V (round-3 advisor finding; fa_extras.h bias_term holds the converted
+    term at -2^99).  Left-padded batches
+    have such rows (a padded query position sees only padded keys under a padding + causal mask).  Forward against stock SDPA on
+    every row; gradients with dO = 0 on the fully masked rows (the only well-defined comparison: stock SDPA's backends disagree
+    with each other about such a row's own gradient) - finite everywhere and equal to stock SDPA's."""
+    import flash_attention_amd.auto  # noqa: F401
+
+    B, H, L = 2, 3, 256
+    gen = torch.Generator().manual_seed(SEED + D)
+    q, k, v = ((torch.randn(B, H, L, D, generator=gen) * 0.7).to(dtype).cuda().requires_grad_(True) for _ in range(3))
+    neg = torch.finfo(dtype).min
+    pad = torch.tensor([37, 0])                                  # batch entry 0 is left-padded by 37 positions
+    key_is_pad = torch.arange(L)[None, :] < pad[:, None]         # [B, L]
+    if mask_shape == "B11L":      # key padding only; entry 1 of a second mask pads EVERY key (all rows fully masked)
+        mask = torch.zeros(B, 1, 1, L)
+        mask[key_is_pad[:, None, None, :].expand(B, 1, 1, L)] = neg
+        mask[1] = neg
+        dead_rows = torch.zeros(B, L, dtype=torch.bool)
+        dead_rows[1] = True
+    else:                         # padding + causal as one additive [B, H, L, L] mask: rows 0..36 of entry 0 see padded keys only
+        causal = torch.triu(torch.ones(L, L, dtype=torch.bool), 1)
+        m2 = causal[None] | key_is_pad[:, None, :]
+        mask = torch.zeros(B, 1, L, L).masked_fill(m2[:, None], neg).expand(B, H, L, L).contiguous()
+        dead_rows = key_is_pad.clone()
+    mask = mask.to(dtype).cuda()
+    dout = torch.randn(B, H, L, D, generator=gen).to(dtype)
+    dout[dead_rows[:, None, :].expand(B, H, L)] = 0
+    dout = dout.cuda()
+
+    out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    assert torch.isfinite(out).all(), "a finfo.min mask must not produce NaN / inf rows"
+    gq, gk, gv = torch.autograd.grad(out, (q, k, v), dout)
+    ref = F.scaled_dot_product_attention.__wrapped__(q, k, v, attn_mask=mask)
+    rq, rk, rv = torch.autograd.grad(ref, (q, k, v), dout)
+    live = ~dead_rows[:, None, :, None].expand(B, H, L, D).cuda()
+    torch.testing.assert_close(out[live].float(), ref[live].float(), atol=2e-2, rtol=2e-2)
+    # a fully masked row: the uniform average of V over all its keys (every logit equal), as stock SDPA returns
+    dead = ~live
+    if dead.any():
+        uniform = v.float().mean(dim=2, keepdim=True).expand(B, H, L, D)
+        torch.testing.assert_close(out[dead].float(), uniform[dead], atol=2e-2, rtol=2e-2)
+        # (stock SDPA's own answer for such a row depends on its backend: the math definition gives this uniform average, the
+        #  fused ROCm backend returned something else on the test box - so the yardstick for a dead row is the definition)
+    for got, want, name in ((gq, rq, "dq"), (gk, rk, "dk"), (gv, rv, "dv")):
+        assert torch.isfinite(got).all(), f"{name}: non-finite gradient under a finfo.min mask"
+        sel = live if name == "dq" else torch.ones_like(live)
+        _grad_close(got[sel], want[sel].detach().cpu().double(), f"finfo.min mask {mask_shape} {dtype} D={D} {name}")

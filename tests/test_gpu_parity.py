@@ -160,6 +160,33 @@ def test_pipelined_kernel_on_16x16x32_mfma_head_dim_128(knobs, dtype, scale, G, 
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 128 ** -0.5), (torch.float16, 128 ** -0.5)])
+@pytest.mark.parametrize("G,L", [(2, 32), (3, 100), (2, 257), (2, 1000), (1, 4608), (9, 600), (2, 2304)])
+def test_pipelined_kernel_one_wave_per_simd_head_dim_128(knobs, dtype, scale, G, L, causal):
+    """fa_fwd_pipe_ag_kernel (head_dim 128, two 32-row query blocks per wave, 256-row workgroups of 4 waves, one wave per SIMD with
+    O^T and Q^T in AGPRs - the MFMAs that touch them are asm, fa_device.h MfmaAsm): out and logsumexp against the oracle for
+    ragged / short / long sequences (first step only, left-over steps, groups of four, both diagonal steps, drain), bf16 and
+    1/sqrt(D)-scaled f16, causal and unmasked."""
+    _, native, _ = _mods()
+    from oracle import dense_attention_lse, frozen_randn
+
+    knobs.set("kernel", "pipe")
+    knobs.set("qb", 2)
+    p = native.plan(G, L, 128, dtype, 1, 1, softmax_scale=scale, causal=causal)
+    if L >= 256:      # (shorter sequences fall back to one block per wave, as at head_dim 64)
+        assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (2, 4, 2, 256, 32)
+    x = frozen_randn(SEED + 17 * L + G, (3, G, L, 128)).to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale) if causal else dense_attention_lse(x[0], x[1], x[2], scale=scale, causal=False)
+    q, k, v = x.cuda()
+    out = torch.empty_like(q)
+    lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+    st = (L * 128, 0, 128)
+    native.fwd_strided(q, k, v, out, lse, G, L, 128, 1, st, st, st, st, 1, 1, scale, causal)
+    _check(out, ref, dtype, f"pipe ag {dtype} scale={scale:.3g} causal={causal} {G}x{L}x128")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("D,split", [(64, 2), (64, 4), (128, 2)])
 @pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.float16, 1.0), (torch.float16, 0.125)])
 @pytest.mark.parametrize("G,L", [(2, 32), (3, 100), (2, 257), (2, 1000), (1, 4608), (9, 600), (2, 2049)])

@@ -145,3 +145,22 @@ def test_dropout_generator_restatement_statistics():
     hi = dropout_keep(3, 4, [0], range(65536, 65536 + 64), range(64), 0.5).numpy()
     hi2 = dropout_keep(3, 4, [0], range(64), range(65536, 65536 + 64), 0.5).numpy()
     assert not np.array_equal(lo, hi) and not np.array_equal(lo, hi2) and not np.array_equal(hi, hi2)
+
+
+@pytest.mark.parametrize("L,D,slab,scale", [(96, 16, 32, 1.0), (257, 64, 100, 0.125), (512, 128, 2048, 1.0)])
+def test_blocked_gradient_oracle_equals_autograd_through_the_dense_oracle(L, D, slab, scale):
+    """dense_causal_attention_grads_blocked (the fp64 gradient checker for the reference's large test sizes, t_fa.py:56-93) is the
+    same function as autograd through the pinned dense restatement of fa.py:48-53 - ragged slabs, one slab, scaled and unscaled."""
+    from oracle import dense_causal_attention_grads_blocked, frozen_randn
+    from oracle.dense_attention import MASK_VALUE
+
+    x = (frozen_randn(99 + L, (3, L, D)) * 0.5).double().requires_grad_(True)
+    dout = frozen_randn(98 + L, (L, D)).double()
+    q, k, v = x
+    mask = torch.triu(torch.full((L, L), MASK_VALUE, dtype=torch.float64), 1)
+    out = torch.softmax((q @ k.T) * scale + mask, dim=-1) @ v
+    out.backward(dout)
+    o2, dq, dk, dv = dense_causal_attention_grads_blocked(q.detach(), k.detach(), v.detach(), dout, scale=scale, slab=slab)
+    torch.testing.assert_close(o2, out.detach(), atol=1e-12, rtol=1e-10)
+    for got, want in zip((dq, dk, dv), x.grad):
+        torch.testing.assert_close(got, want, atol=1e-11, rtol=1e-9)
