@@ -48,7 +48,7 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dq_kernel(const Bwd
     // attention mask / bias and dropout (fa_extras.h), as in fa_fwd_generic_kernel
     const bool has_mask = p.ex.mask != nullptr, dropping = p.ex.drop_thr != 0u;
     const char* const mbase = has_mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh) * (p.ex.mask_kind == 2 ? (int)sizeof(T) : 1) : nullptr;
-    const unsigned drop_kg = drop_group_key(p.ex.drop_key0, (unsigned)g);
+    const unsigned drop_kg = drop_group_key(drop_key0_of(p.ex), (unsigned)g);
     float acc[GB_MAXD_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < GB_MAXD_PER_THREAD; ++i) acc[i] = 0.f;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(GB_THREADS) void fa_bwd_generic_dkdv_kernel(const B
         const float* lse = p.lse + ((int64_t)bb * p.H + hq) * L;
         const float* dsum = p.dsum + ((int64_t)bb * p.H + hq) * L;
         const char* const mbase = has_mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hq * p.ex.m_sh) * mask_esz : nullptr;
-        const unsigned drop_kg = drop_group_key(p.ex.drop_key0, (unsigned)(bb * p.H + hq));
+        const unsigned drop_kg = drop_group_key(drop_key0_of(p.ex), (unsigned)(bb * p.H + hq));
         for (int r0 = 0; r0 < nrows; r0 += GB_CHUNK) {
             const int rn = nrows - r0 < GB_CHUNK ? nrows - r0 : GB_CHUNK;
             for (int c = tid; c < rn; c += GB_THREADS) {

@@ -125,7 +125,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     const float lse2 = (EXTRA && lse_row == -INFINITY) ? 0.f : lse_row * LOG2E;
     const int mask_esz = p.ex.mask_kind == 2 ? (int)sizeof(T) : 1;
     const char* const mrow = EXTRA && p.ex.mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh + (int64_t)qr * p.ex.m_sl) * mask_esz : nullptr;
-    const unsigned drop_kg = EXTRA ? drop_group_key(p.ex.drop_key0, (unsigned)g) : 0u;
+    const unsigned drop_kg = EXTRA ? drop_group_key(drop_key0_of(p.ex), (unsigned)g) : 0u;
     // Dsum = rowsum(dO o O) of this lane's row (FA.cpp:375-378), from the dO fragments already in registers and the
     // matching O fragments; the two half-waves hold the two halves of the row.  Published for fa_bwd_dkdv_kernel,
     // which runs after this kernel on the same stream (this replaces a separate pass over dO and O).
@@ -589,7 +589,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 if constexpr (EXTRA) {                                                             \
                     if (p.ex.drop_thr != 0u) {                                                     \
                         const unsigned row0_ = (unsigned)(q0 + 32 * hb);                           \
-                        const unsigned kgq_ = drop_group_key(p.ex.drop_key0, (unsigned)(bb * p.H + hq0 + hqt_)); \
+                        const unsigned kgq_ = drop_group_key(drop_key0_of(p.ex), (unsigned)(bb * p.H + hq0 + hqt_)); \
                         const unsigned base_ = drop_tile_key(kgq_, row0_, (unsigned)key0) ^ (((row0_ & 0xffffu) | (unsigned)(4 * h)) << 16) ^ ((unsigned)key & 0xffffu); \
                         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                         \
                             const f32x4 da = *(const f32x4*)(rc_ + 64 + 32 * hb + 8 * gq + 4 * h);   /* -Dsum[row] */ \

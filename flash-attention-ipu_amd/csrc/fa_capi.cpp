@@ -54,6 +54,7 @@ struct Options {
     std::atomic<int> split{0};      // 0 auto, 1 | 2 | 4 kv split groups per workgroup (fa_fwd_dma.hip)
     std::atomic<int> pair{-1};      // -1 auto, 0 | 1 q-tile pairs per workgroup (fa_fwd_dma.hip, causal)
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
+    std::atomic<int> mirror{-1};    // -1 auto, 0 off, 1 on: mirrored row blocks in the two-block pipelined kernel (causal, head_dim 64, L % 256 == 0)
     std::atomic<int> fold{-1};      // -1 auto (= off), 0 off, 1 on for scaled bf16 calls: the scale fold of the pipelined kernel (fa_fwd_pipe.hip FOLD)
 };
 Options g_opt;
@@ -84,6 +85,7 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_PAIR")) { if (*e) g_opt.pair = atoi(e); }
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
         if (const char* e = getenv("FA_AMD_FOLD")) { if (*e) g_opt.fold = atoi(e); }
+        if (const char* e = getenv("FA_AMD_MIRROR")) { if (*e) g_opt.mirror = atoi(e); }
     });
     return g_opt;
 }
@@ -232,10 +234,11 @@ void apply_overrides(const Request& r, const Options& opt, Choice* c) {
     else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && D == 128) ? 8 : 4; if (!fq) qb = 1; }
     else if (fk == 'P' && pipe_ok && D == 64) { which = 'P'; waves = 4; qb = 2; }
     else if (fk == 'h') { which = 'h'; waves = 4; qb = 1; }
-    else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
+    else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128 || (FA_EXPERIMENTAL && D == 64 && waves == 8 && fq == 2))) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
     if (fq == 1) qb = 1;
     if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
     if (fq == 2 && fk == 'x' && D == 64) qb = 2;
+    if (fq == 2 && fk == 'p' && fw == 8 && D == 64 && pipe_ok && r.causal && L >= 512 && FA_EXPERIMENTAL) qb = 2;   // 512-row workgroups, one shared ring (fa_fwd_pipe_w8_kernel)
     if (fq == 2 && fk == 'p' && D == 128 && pipe_ok && L >= 256 && FA_EXPERIMENTAL) { qb = 2; waves = 4; }   // the one-wave-per-SIMD AGPR variant (fa_fwd_pipe_ag_kernel)
     if (fs == 1) split = 1;
     if (fs > 1 && (fk == 0 || fk == 'd')) { which = 'd'; waves = 4; qb = 1; split = fs; }
@@ -250,13 +253,14 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
     int &waves = c->waves, &qb = c->qb, &split = c->split;
     if (!FA_EXPERIMENTAL && (which == 't' || which == 'P')) which = 'd';      // (not in this build: make EXPERIMENTAL=1)
     if (r.want32 && r.pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
-    if (which == 'p' && ((waves > 4 && D != 128) || !r.pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
+    const bool w8_ = FA_EXPERIMENTAL && which == 'p' && D == 64 && waves == 8 && qb == 2 && r.causal && r.pipe_ok;   // (512-row workgroups: forced only)
+    if (which == 'p' && ((waves > 4 && D != 128 && !w8_) || !r.pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
     if (which == 'x' && !r.pipe_ok) which = 'd';
     if (which == 'P' && !(r.pipe_ok && D == 64)) which = 'd';
     if (which == 'P') { waves = 4; qb = 2; split = 1; }
     if (which == 'h') { waves = 4; qb = 1; if (!(split == 1 || split == 2 || (split == 4 && D == 64))) split = 1; }
     if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
-    if (qb == 2 && !((D == 64 || (D == 128 && which == 'p' && FA_EXPERIMENTAL)) && waves == 4)) qb = 1;
+    if (qb == 2 && !w8_ && !((D == 64 || (D == 128 && which == 'p' && FA_EXPERIMENTAL)) && waves == 4)) qb = 1;
     if (which == 't' && waves > 4) waves = 4;
     if (split > 1 && !((which == 'd' || which == 'h') && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
 }
@@ -414,12 +418,16 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     return FA_OK;
 }
 
+// mirrored row blocks: -1 (auto) = this default
+inline bool kMirrorDefault(int opt) { return opt < 0 ? false : opt != 0; }
+
 struct OptionName { const char* name; std::atomic<int> Options::*field; int lo, hi; };
 const OptionName kOptionNames[] = {
     {"kernel", &Options::kernel, 0, 127}, {"qb", &Options::qb, 0, 2}, {"waves", &Options::waves, 0, 8},
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
     {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"fold", &Options::fold, -1, 1},
+    {"mirror", &Options::mirror, -1, 1},
 };
 
 }  // namespace
@@ -532,7 +540,7 @@ namespace {
 
 // mask / bias / dropout arguments of fa_fwd_ex / fa_bwd_ex, validated into the kernels' ExtraParams (fa_extras.h)
 int make_extra(const void* mask, int32_t mask_kind, const int64_t* mask_strides, int32_t dtype, float softmax_scale,
-               float dropout_p, uint64_t seed, uint64_t offset, fa::ExtraParams* ex) {
+               float dropout_p, uint64_t seed, uint64_t offset, const uint64_t* state_dev, fa::ExtraParams* ex) {
     memset(ex, 0, sizeof(*ex));
     ex->drop_rp = 1.0f;
     ex->inv_scale = 1.0f / softmax_scale;
@@ -557,11 +565,11 @@ int make_extra(const void* mask, int32_t mask_kind, const int64_t* mask_strides,
         const double t = (double)dropout_p * 4294967296.0;
         ex->drop_thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
         ex->drop_rp = 1.0f / (1.0f - dropout_p);
-        uint32_t k0 = fa::mix32((uint32_t)seed ^ 0x9E3779B9u);
-        k0 = fa::mix32(k0 ^ (uint32_t)(seed >> 32));
-        k0 = fa::mix32(k0 ^ (uint32_t)offset);
-        k0 = fa::mix32(k0 ^ (uint32_t)(offset >> 32));
-        ex->drop_key0 = k0;
+        ex->drop_key0 = fa::drop_fold_key0(seed, offset);
+        if (state_dev) {
+            if (reinterpret_cast<uintptr_t>(state_dev) & 7) return fail(FA_ERR_MISALIGNED, "dropout_state must be 8-byte aligned");
+            ex->drop_state = reinterpret_cast<const unsigned long long*>(state_dev);
+        }
     }
     return FA_OK;
 }
@@ -630,6 +638,9 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     // unit-variance logits (every parity case passes) but 3x the logsumexp error at a logit spread of 2-3 and percents of P on sharp heads with
     // logits of 20-30 (tests/tools/fuzz_kernels.py with FUZZ_AMP=5, profiles/r03_fold): +5 % is not worth a result that depends on the input's scale
     p.fold = (sel.which == 'p' && D == 64 && plan.qb == 2 && plan.waves == 4 && dtype == FA_DTYPE_BF16 && softmax_scale <= 0.25f && options().fold == 1) ? 1 : 0;
+    // mirrored row blocks (fa_fwd_pipe.hip MIRROR): the two-block pipelined kernel at head_dim 64, causal, whole 256-row tiles only
+    p.mirror = (FA_EXPERIMENTAL && sel.which == 'p' && D == 64 && plan.qb == 2 && (plan.waves == 4 || plan.waves == 8) && causal == 1 && L % plan.block_q == 0 && !p.fold
+                && kMirrorDefault(options().mirror)) ? 1 : 0;
     p.perm_n = sel.perm_n;
     if (sel.perm_n > 0) memcpy(p.perm, sel.perm, sizeof(p.perm));
     p.stamps = nullptr;
@@ -676,11 +687,11 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse
               const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
               int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, float softmax_scale, int32_t causal,
               const void* mask, int32_t mask_kind, const int64_t mask_strides[3],
-              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, void* stream) {
+              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, const uint64_t* dropout_state, void* stream) {
     if (!(softmax_scale > 0.0f) || !isfinite(softmax_scale)) return fail(FA_ERR_BAD_SCALE, "softmax_scale must be finite and > 0 (got %g)", (double)softmax_scale);
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     fa::ExtraParams ex;
-    const int rc = make_extra(mask, mask_kind, mask_strides, dtype, softmax_scale, dropout_p, dropout_seed, dropout_offset, &ex);
+    const int rc = make_extra(mask, mask_kind, mask_strides, dtype, softmax_scale, dropout_p, dropout_seed, dropout_offset, dropout_state, &ex);
     if (rc != FA_OK) return rc;
     return fwd_impl(q, k, v, out, lse, G, L, D, heads, heads_kv, q_strides, k_strides, v_strides, o_strides,
                     num_chunks_q, num_chunks_kv, dtype, softmax_scale, causal, stream, &ex);
@@ -698,11 +709,11 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* out, cons
               int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
               int32_t dtype, float softmax_scale, int32_t causal,
               const void* mask, int32_t mask_kind, const int64_t mask_strides[3],
-              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, void* stream) {
+              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, const uint64_t* dropout_state, void* stream) {
     if (!(softmax_scale > 0.0f) || !isfinite(softmax_scale)) return fail(FA_ERR_BAD_SCALE, "softmax_scale must be finite and > 0 (got %g)", (double)softmax_scale);
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     fa::ExtraParams ex;
-    const int rc = make_extra(mask, mask_kind, mask_strides, dtype, softmax_scale, dropout_p, dropout_seed, dropout_offset, &ex);
+    const int rc = make_extra(mask, mask_kind, mask_strides, dtype, softmax_scale, dropout_p, dropout_seed, dropout_offset, dropout_state, &ex);
     if (rc != FA_OK) return rc;
     return bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, dsum_workspace, G, L, D, heads, heads_kv, strides, dtype, softmax_scale, causal, stream, &ex);
 }

@@ -24,6 +24,16 @@ __host__ __device__ __forceinline__ unsigned mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
+// (seed, offset) -> key0: on the host for immediate values (fa_capi.cpp), on the device when the two words arrive in a device buffer
+// (ABI 5 `dropout_state`: a launch captured in a HIP graph then sees the offset its caller's captured increment left there, i.e. a
+// fresh mask on every replay - with immediate values the graph would replay ONE mask forever)
+__host__ __device__ __forceinline__ unsigned drop_fold_key0(unsigned long long seed, unsigned long long offset) {
+    unsigned k0 = mix32((unsigned)seed ^ 0x9E3779B9u);
+    k0 = mix32(k0 ^ (unsigned)(seed >> 32));
+    k0 = mix32(k0 ^ (unsigned)offset);
+    k0 = mix32(k0 ^ (unsigned)(offset >> 32));
+    return k0;
+}
 __host__ __device__ __forceinline__ unsigned drop_group_key(unsigned key0, unsigned g) { return mix32(key0 ^ (g * 0x9E3779B1U)); }
 // key of the 65536 x 65536 window holding (row, col): uniform over a kernel tile (tiles are 64-aligned)
 __host__ __device__ __forceinline__ unsigned drop_tile_key(unsigned kg, unsigned row, unsigned col) {
@@ -44,6 +54,11 @@ __host__ __device__ __forceinline__ unsigned drop_tile_key(unsigned kg, unsigned
 __device__ __forceinline__ float bias_term(float bias, float inv_scale) {
     const float t = bias * inv_scale;
     return bias == -INFINITY ? t : __builtin_fmaxf(t, -0x1p99f);
+}
+// key0 of this launch: from the device state when there is one (two uniform 8-byte loads per workgroup), else the folded immediates
+template <typename EX>
+__device__ __forceinline__ unsigned drop_key0_of(const EX& ex) {
+    return ex.drop_state != nullptr ? drop_fold_key0(ex.drop_state[0], ex.drop_state[1]) : ex.drop_key0;
 }
 // four consecutive keys k0 .. k0+3 of one mask row -> additive terms on the raw scores
 template <typename T>

@@ -119,7 +119,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // EXTRA: this group's mask rows (byte addressed) and dropout key
     const int mask_esz = p.ex.mask_kind == 2 ? (int)sizeof(T) : 1;
     const char* const mask_g = EXTRA && p.ex.mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh) * mask_esz : nullptr;
-    const unsigned drop_kg = EXTRA ? drop_group_key(p.ex.drop_key0, (unsigned)g) : 0u;
+    const unsigned drop_kg = EXTRA ? drop_group_key(drop_key0_of(p.ex), (unsigned)g) : 0u;
     // EXTRA: the raw mask data of the NEXT tile is requested as soon as this tile's has been decoded into the scores (one register set):
     // a mask row is global memory nobody else has touched - its latency then runs under this tile's softmax and PV product, the barrier
     // and the next tile's QK^T instead of sitting between QK^T and the softmax

@@ -35,6 +35,9 @@
 #include "fa_device.h"
 #include "fa_extras.h"
 
+#ifndef FA_EXPERIMENTAL
+#define FA_EXPERIMENTAL 0
+#endif
 #ifndef FA_CHAIN_SPLIT
 #define FA_CHAIN_SPLIT 0   // experiment knob: split the max / row-sum dependency chains
 #endif
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fa_fwd_generic_kernel(const FwdPa
     // to the SCALED logit, the dropout decision zeroes the weight the PV product sees while the denominator keeps it
     const bool has_mask = p.ex.mask != nullptr, dropping = p.ex.drop_thr != 0u;
     const char* const mbase = has_mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh) * (p.ex.mask_kind == 2 ? (int)sizeof(T) : 1) : nullptr;
-    const unsigned drop_kg = drop_group_key(p.ex.drop_key0, (unsigned)g);
+    const unsigned drop_kg = drop_group_key(drop_key0_of(p.ex), (unsigned)g);
 
     for (int k0 = 0; k0 < nkeys; k0 += GEN_CHUNK) {
         const int kn = nkeys - k0 < GEN_CHUNK ? nkeys - k0 : GEN_CHUNK;
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fa_fwd_generic_kernel(const FwdPa
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+#if FA_EXPERIMENTAL   /* the register-staged A/B baseline is not product code: make EXPERIMENTAL=1 (fa_capi.cpp) */
 template <typename T, int D, int NWAVES>
 static hipError_t launch_tile(const FwdParams& p, hipStream_t stream) {
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
@@ -462,6 +466,7 @@ hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t
     }
     return p.D == 64 ? launch_tile_w<_Float16, 64>(p, waves, stream) : launch_tile_w<_Float16, 128>(p, waves, stream);
 }
+#endif
 
 hipError_t launch_fwd_generic(const FwdParams& p, int dtype, hipStream_t stream) {
     dim3 grid((unsigned)((int64_t)p.L * p.G));

@@ -34,6 +34,9 @@
 
 #include "fa_device.h"
 
+#ifndef FA_EXPERIMENTAL
+#define FA_EXPERIMENTAL 0
+#endif
 // ring slots per K / V ring (power of two)
 #ifndef FA_PIPE_SLOTS
 #define FA_PIPE_SLOTS(D_, QB_, W_) 4
@@ -85,8 +88,22 @@ namespace fa {
 // (caught by a row sum below 2^-80) - either sends the workgroup through the exact pass, which works on the folded scores with c = 1.
 // AG (one wave per SIMD, the whole 512-entry register file: head_dim 128 with two query blocks per wave): the O^T accumulators and
 // the Q^T fragments live in AGPRs (fa_device.h MfmaAsm), the architectural VGPRs hold the two score tiles, P and the operand fragments.
-template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false, bool AG = false>
+// MIRROR (causal, two blocks per wave, L a multiple of the workgroup's rows): wave w owns the 32-row blocks w and 2 NWAVES - 1 - w of
+// the tile instead of 2 w and 2 w + 1, so every wave carries the same number of block-steps through the tile's diagonal region: once
+// block 0 has passed its diagonal the wave runs ONE-block steps (its dead block's MFMAs are not issued) instead of idling through the
+// last waves' steps - the "~3 step-times" a workgroup loses to waves that finish early.
+constexpr bool pipe_mfma_live(int n, int qb, int npv, bool pv0, bool qk0) {   // MFMA n of a PV-first step: operand n / qb, block n % qb
+    return (n % qb) != 0 || ((n / qb) < npv ? pv0 : qk0);
+}
+constexpr int pipe_live_before(int n, int qb, int npv, bool pv0, bool qk0) {
+    int c = 0;
+    for (int i = 0; i < n; ++i) c += pipe_mfma_live(i, qb, npv, pv0, qk0) ? 1 : 0;
+    return c;
+}
+
+template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false, bool AG = false, bool MIRROR = false>
 __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
+    static_assert(!MIRROR || (QB == 2 && CAUSAL && FA_PIPE_PVFIRST), "mirrored row blocks: causal, two blocks per wave, PV-first steps");
     using E = Elt<T>;
     using MA = MfmaAsm<T>;
     using vec8 = typename E::vec8;
@@ -99,10 +116,14 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     constexpr int VBLK_B = HK * 64 + 64;        // one 32-column d-block of a V slot (+64 B stagger)
     constexpr int VH_B = (D / 32) * VBLK_B;     // V slot
     constexpr int PIECES = KH_B / 1024;         // 1 KiB DMA pieces per K (or V) slot
-    constexpr int PPW = PIECES / NWAVES;
+    // HALF (8 waves at head_dim 64: 4 K pieces + 4 V pieces per step): every wave issues ONE piece per step, waves 0 .. PIECES - 1 a
+    // K piece, the others a V piece - a 512-row workgroup streams K/V through ONE ring
+    constexpr bool HALF = PIECES * 2 == NWAVES;
+    constexpr int PPW = HALF ? 1 : PIECES / NWAVES;
+    constexpr int DPS = HALF ? 1 : 2 * PPW;     // LDS-DMA instructions a wave issues per step
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
-    static_assert(PIECES % NWAVES == 0 && PPW >= 1, "pieces must split evenly over the waves");
+    static_assert(HALF || (PIECES % NWAVES == 0 && PPW >= 1), "pieces must split evenly over the waves");
 
     // ring depth: 4 slots = the DMA of a step has two steps to land (8 slots = six steps were measured 1-2 %
     // slower: the groups of NS steps leave more ragged steps over)
@@ -157,13 +178,15 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
     const int q_row0 = qi * BQ + wave * WQ;
-    const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
-    const bool wave_active = q_row0 < L;
+    int rowb[QB];                                // first row of block b (MIRROR: blocks wave and 2 NWAVES - 1 - wave of the tile)
+#pragma unroll
+    for (int b = 0; b < QB; ++b) rowb[b] = MIRROR ? qi * BQ + 32 * (b == 0 ? wave : 2 * NWAVES - 1 - wave) : q_row0 + 32 * b;
+    const bool wave_active = MIRROR ? true : q_row0 < L;
 
     vec8 qf[QB][KS];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        const int qr = qrow + 32 * b < L ? qrow + 32 * b : L - 1;
+        const int qr = rowb[b] + r < L ? rowb[b] + r : L - 1;
         const T* qp = qg + (int64_t)qr * p.q_sl + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[b][ks] = *(const vec8*)(qp + 16 * ks);
@@ -183,7 +206,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     int k_dst[PPW], v_dst[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int pc = wave + j * NWAVES;
+        const int pc = HALF ? wave % PIECES : wave + j * NWAVES;
         const int row = pc * (1024 / ROWB) + lane / (ROWB / 16);
         const int cp = lane % (ROWB / 16);
         const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
@@ -224,14 +247,14 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     }
 #else
 #define FA_DMA_K(J_, SLOT_)                                                                        \
-    {                                                                                              \
+    if (!HALF || wave < PIECES) {                                                                  \
         const unsigned ko_ = (unsigned)(J_) * HK * k_slb;                                          \
         const i32x4 kr_ = make_raw_rsrc((const char*)kg + ko_, k_bytes - ko_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
             lds_dma_b128(kr_, smem_lds + (SLOT_) * KH_B + k_dst[j], k_vo[j]);                      \
     }
 #define FA_DMA_V(J_, SLOT_)                                                                        \
-    {                                                                                              \
+    if (!HALF || wave >= PIECES) {                                                                 \
         const unsigned vo_ = (unsigned)(J_) * HK * v_slb;                                          \
         const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
@@ -252,12 +275,14 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // A template parameter, not a run-time flag: a run-time branch around the last step costs the causal kernel its
     // register allocation (256 VGPRs + scratch instead of 222).
     constexpr bool causal = CAUSAL;
-#define FA_KLIM(B_) (CAUSAL ? qrow + 32 * (B_) : L - 1)
+#define FA_KLIM(B_) (CAUSAL ? rowb[B_] + r : L - 1)
     const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
     const int nh_wg = (kv_end + HK - 1) / HK;                 // steps the workgroup streams
     // steps this wave computes: block b's diagonal step is q_row0/32 + b, so the last QB steps carry a mask
     // (a block whose rows all lie before a step's keys gets P = 0 there)
-    const int nh_w = wave_active ? (causal ? q_row0 / HK + QB : nh_wg) : 0;
+    const int nh_w = wave_active ? (causal ? (MIRROR ? rowb[QB - 1] / HK + 1 : q_row0 / HK + QB) : nh_wg) : 0;
+    // the step of block 0's diagonal + QB: what bounds the unmasked hand-ordered steps (= nh_w unless MIRROR)
+    const int nh_a = MIRROR ? rowb[0] / HK + QB : nh_w;
 
     f32x16 o[QB][DT];
     float m[QB], l[QB];
@@ -360,7 +385,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         if (dk_ && FA_PIPE_ABL != 2) FA_DMA_K((I_) + NS - 1, KSLOT_)                               \
         if (dv_ && FA_PIPE_ABL != 2) FA_DMA_V((I_) + NS - 2, VSLOT_)
 #define FA_PUBLISH()                                                                               \
-        if (dk_ && dv_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NS - 3)) : "memory");  \
+        if (dk_ && dv_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (NS - 3)) : "memory");      \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
         FA_PIPE_BARRIER();
     // steady-state step I_ (ring index R_ = I_ & 3 at compile time): S(I_) is in SC_, SN_ receives S(I_+1),
@@ -401,8 +426,9 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // MASK_ modes: 0 no mask; 1 causal mask on every block; 2 mask on block 0 only (two blocks: the step of block
     // 0's diagonal); 3 block 0 is dead - all its keys lie after its rows: no softmax, P = 0 - and block 1 is masked
     // (two blocks: the wave's last step)
+// 4 (MIRROR): block 0 is dead, block 1 carries no mask (the one-block steps between the two diagonals of a wave)
 #define FA_ITEM_MASKED(MASK_, B_) ((MASK_) == 1 || ((MASK_) == 2 && (B_) == 0) || ((MASK_) == 3 && (B_) == 1))
-#define FA_ITEM_DEAD(MASK_, B_) ((MASK_) == 3 && (B_) == 0)
+#define FA_ITEM_DEAD(MASK_, B_) (((MASK_) == 3 || (MASK_) == 4) && (B_) == 0)
 #define FA_ITEM_FMA(SC_, V_, MASK_)                                                                \
         {                                                                                          \
             constexpr int b_ = (V_) / 8, e_ = 2 * ((V_) % 8);                                      \
@@ -453,16 +479,22 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #define FA_ISSUE_FAST(I_, KSLOT_, VSLOT_)                                                          \
         if (FA_PIPE_ABL != 2) { FA_DMA_K((I_) + NS - 1, KSLOT_) FA_DMA_V((I_) + NS - 2, VSLOT_) }
 #define FA_PUBLISH_FAST()                                                                          \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NS - 3)) : "memory");                  \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (NS - 3)) : "memory");                      \
         FA_PIPE_BARRIER();
 #else
 #define FA_ISSUE_FAST(I_, KSLOT_, VSLOT_) FA_ISSUE(I_, KSLOT_, VSLOT_)
 #define FA_PUBLISH_FAST() FA_PUBLISH()
 #endif
-#define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_)                             \
+// PV0_ / QK0_ (MIRROR's one-block steps): whether block 0's PV / QK^T MFMAs are issued at all - a dead block needs neither, except
+// the PV of its diagonal step's P in the step right after that diagonal.  The vector items of the live block(s) are spread
+// over the MFMAs that ARE issued.
+#define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_) FA_FASTX(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_, true, true)
+#define FA_FASTX(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_, PV0_, QK0_)                \
     {                                                                                              \
         FA_ISSUE_FAST(I_, KI_, VI_)                                                                \
         constexpr int NK = (QK_) ? KS : 0, NM = NK + 2 * DT, NMF = NM * QB, NV = 8 * QB;           \
+        constexpr int VB = (QB == 2 && FA_ITEM_DEAD(MASK_, 0)) ? 8 : 0, NVL = NV - VB;             /* live vector items: VB .. NV - 1 */ \
+        constexpr int NMFL = pipe_live_before(NMF, QB, 2 * DT, PV0_, QK0_);                        /* MFMAs issued */ \
         constexpr int PF_ = FA_PIPE_PF < NM ? FA_PIPE_PF : NM;                                     \
         const unsigned char* kb_ = smem + (KN_) * KH_B;                                            \
         const unsigned char* vb_ = smem_v + (VP_) * VH_B;                                          \
@@ -475,13 +507,20 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         fa_static_for<NPRE, (NPRE > PF_ ? NPRE : PF_)>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; FA_OPND_LOAD(x_, NK) }); \
         float mc[QB], ls[QB];                                                                      \
         _Pragma("unroll") for (int b = 0; b < QB; ++b) { mc[b] = m[b] * c; ls[b] = 0.f; }          \
-        FA_ITEM_FMA(SC_, 0, MASK_)                                                                 \
-        FA_ITEM_EXP(SC_, 0, MASK_)                                                                 \
-        FA_ITEM_FMA(SC_, 1, MASK_)                                                                 \
+        if constexpr (VB != 0 && (MASK_) == 3) {   /* the wave's last step: the dead block's P must read as 0 in the drain step's PV */ \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) { PC_[0][0][j] = (T)0.f; PC_[0][1][j] = (T)0.f; } \
+        }                                                                                          \
+        FA_ITEM_FMA(SC_, VB + 0, MASK_)                                                            \
+        FA_ITEM_EXP(SC_, VB + 0, MASK_)                                                            \
+        FA_ITEM_FMA(SC_, VB + 1, MASK_)                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         fa_static_for<0, NMF>([&](auto gi_) {                                                      \
             constexpr int n_ = decltype(gi_)::value, g_ = n_ / QB, b_ = n_ % QB;                   \
-            if constexpr (FA_OPND_IS_K(g_, NK)) {                                                  \
+            constexpr bool live_ = pipe_mfma_live(n_, QB, 2 * DT, PV0_, QK0_);                     \
+            constexpr int l_ = pipe_live_before(n_, QB, 2 * DT, PV0_, QK0_);                       \
+            if constexpr (!live_) {                                                                \
+                /* (a dead block's MFMA: not issued) */                                            \
+            } else if constexpr (FA_OPND_IS_K(g_, NK)) {                                           \
                 constexpr int kx_ = FA_OPND_KIDX(g_, NK);                                          \
                 if constexpr (AG) {                                                                \
                     if constexpr (kx_ == 0) MA::bq0(SN_[b_], opnd[g_], qf[b_][kx_ < KS ? kx_ : 0]); \
@@ -504,7 +543,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 FA_PRE_LOAD(g_ - NPRE, vnext_)                                                     \
             }                                                                                      \
             /* this MFMA's share of the vector work items */                                      \
-            if constexpr (AG && NMF == 2 * NV) {   /* one wave per SIMD: at most one transcendental and <= 24 issue cycles per MFMA gap */ \
+            if constexpr (!live_) {                                                                \
+            } else if constexpr (AG && NMF == 2 * NV) {   /* one wave per SIMD: at most one transcendental and <= 24 issue cycles per MFMA gap */ \
                 constexpr int v_ = n_ / 2;                                                         \
                 if constexpr (n_ % 2 == 0) {                                                       \
                     if constexpr (v_ + 1 < NV) { FA_ITEM_EXP1(SC_, v_ + 1, 0, MASK_) }             \
@@ -514,7 +554,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                     if constexpr (v_ + 2 < NV) { FA_ITEM_FMA(SC_, v_ + 2, MASK_) }                 \
                 }                                                                                  \
             } else {                                                                               \
-            fa_static_for<(n_ * NV) / NMF, ((n_ + 1) * NV) / NMF>([&](auto vi_) {                  \
+            fa_static_for<VB + (l_ * NVL) / NMFL, VB + ((l_ + 1) * NVL) / NMFL>([&](auto vi_) {    \
                 constexpr int v_ = decltype(vi_)::value;                                           \
                 if constexpr (v_ + 1 < NV) { FA_ITEM_EXP(SC_, v_ + 1, MASK_) }                     \
                 FA_ITEM_SUM(SC_, PC_, v_, MASK_)                                                   \
@@ -550,6 +590,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     }
 #define FA_RAGGED(I_, MASK_, QK_)                                                                  \
     FA_FAST(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, MASK_, QK_)
+#define FA_RAGGEDX(I_, MASK_, QK_, PV0_, QK0_)                                                     \
+    FA_FASTX(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, MASK_, QK_, PV0_, QK0_)
     // generic step (runtime ring slots, compiler's own schedule): the first step, the up to three steps left
     // over by the groups of four, the diagonal step, the drain step and the idle steps of a finished wave.
     // SAFE_ = the fallback pass: a step whose P outgrew the safe range is redone with an exact max.
@@ -561,7 +603,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         if (i_ >= 1 && i_ <= nh_w) FA_PV_H(PP_, (i_ + NS - 1) & NSM)                               \
         if (i_ < nh_w) {                                                                           \
             float ls[QB];                                                                          \
-            const bool diag_ = i_ >= nh_w - QB;                                                    \
+            const bool diag_ = i_ >= nh_a - QB;                                                    \
             if (diag_) FA_MASK_H(SC_, i_)                                                          \
             if (i_ == 0 && !(FOLD && !(SAFE_))) FA_MAXR_H(SC_)                                     \
             FA_SM_H(SC_)                                                                           \
@@ -603,7 +645,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         if (!(SAFE_)) FA_STAMP(sta_)                                                               \
         int i = 1;                                                                                 \
         if (!(SAFE_)) {                                                                            \
-            for (; i + NS - 1 + QB < nh_w; i += NS) {  /* steps i .. i+NS-1 carry no mask */        \
+            for (; i + NS - 1 + QB < nh_a; i += NS) {  /* steps i .. i+NS-1 carry no mask */        \
                 fa_static_for<0, NS>([&](auto ki_) {                                               \
                     constexpr int k_ = decltype(ki_)::value, R_ = (1 + k_) % NS;                   \
                     if constexpr (k_ % 2 == 0) FA_STEADY(i + k_, R_, sb, sa, pa, pb)               \
@@ -614,16 +656,33 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         FA_ROTATE()                                            /* i is odd: S(i) sb -> sa, P(i-1) pa -> pb */ \
         if (!(SAFE_)) FA_STAMP(stb_)                                                               \
         if (!(SAFE_)) {                                                                            \
-            for (; i + QB < nh_w; ++i) {                       /* steps the groups left over */    \
+            for (; i + QB < nh_a; ++i) {                       /* steps the groups left over */    \
                 FA_RAGGED(i, 0, true)                                                              \
                 FA_ROTATE()                                                                        \
             }                                                                                      \
-            if (QB == 2 && i + 1 < nh_w) {                     /* block 0's diagonal step */       \
+            if (QB == 2 && i + 1 < nh_a) {                     /* block 0's diagonal step */       \
                 FA_RAGGED(i, 2, true)                                                              \
                 FA_ROTATE()                                                                        \
                 ++i;                                                                               \
             }                                                                                      \
-            if (i < nh_w) {                                    /* the wave's last step */          \
+            if constexpr (MIRROR) {                            /* i = block 0's diagonal step + 1: one-block steps up to block 1's diagonal */ \
+                const bool first_is_last_ = i + 1 == nh_w;     /* (waves NWAVES - 1: the two blocks are neighbours) */ \
+                if (i + 1 < nh_w) {                            /* the step right after block 0's diagonal still owes the PV of that diagonal's P */ \
+                    FA_RAGGEDX(i, 4, true, true, false)                                            \
+                    FA_ROTATE()                                                                    \
+                    ++i;                                                                           \
+                }                                                                                  \
+                for (; i + 1 < nh_w; ++i) {                                                        \
+                    FA_RAGGEDX(i, 4, true, false, false)                                           \
+                    FA_ROTATE()                                                                    \
+                }                                                                                  \
+                if (i < nh_w) {                                /* block 1's diagonal = the wave's last step */ \
+                    if (first_is_last_) { FA_RAGGEDX(i, 3, false, true, true) }                    \
+                    else { FA_RAGGEDX(i, 3, false, false, true) }                                  \
+                    FA_ROTATE()                                                                    \
+                    ++i;                                                                           \
+                }                                                                                  \
+            } else if (i < nh_w) {                             /* the wave's last step */          \
                 if constexpr (CAUSAL) { FA_RAGGED(i, (QB == 2 ? 3 : 1), false) }   /* (block 0 lies wholly before this step's keys) */ \
                 else { FA_RAGGED(i, 1, false) }                                    /* unmasked attention: only keys past L are masked */ \
                 FA_ROTATE()                                                                        \
@@ -692,6 +751,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #undef FA_PUBLISH_FAST
 #undef FA_STEADY
 #undef FA_FAST
+#undef FA_FASTX
+#undef FA_RAGGEDX
 #undef FA_RAGGED
 #undef FA_ROTATE
 #undef FA_OPND_LOAD
@@ -739,13 +800,13 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 *(vec4*)(slab + r * ROWB + ((ch ^ (r & (CPR - 1))) << 4) + 8 * h) = w;
             }
         }
-        const int row_b = qrow + 32 * b;
+        const int row_b = rowb[b] + r;
         if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * (FOLD ? 0.69314718f : p.scale) + __logf(lt);   /* (FOLD: m is in log2 units) */
 #pragma unroll
         for (int i = 0; i < 32 / RPI; ++i) {
             const int rr = i * RPI + lane / CPR, ch = lane % CPR;
             const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
-            const int orow = q_row0 + 32 * b + rr;
+            const int orow = rowb[b] + rr;
             if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
         }
     }
@@ -777,6 +838,17 @@ template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false>
 __global__ __launch_bounds__(NWAVES * 64, QB == 2 ? 2 : 1) void fa_fwd_pipe_kernel(const FwdParams p) {
     fa_fwd_pipe_body<T, D, NWAVES, QB, CAUSAL, FOLD>(p);
 }
+// the headline shape's kernel with mirrored row blocks (MIRROR above): causal, head_dim 64, 4 waves x 2 blocks, L a multiple of 256
+template <typename T>
+__global__ __launch_bounds__(256, 2) void fa_fwd_pipe_mirror_kernel(const FwdParams p) {
+    fa_fwd_pipe_body<T, 64, 4, 2, true, false, false, true>(p);
+}
+// 8 waves x 2 blocks = 512-row workgroups at head_dim 64 with ONE shared K/V ring (one LDS-DMA piece per wave and step, half the
+// L2 -> LDS traffic per FLOP of the 256-row workgroups), one workgroup per CU, its waves two per SIMD; with or without mirrored blocks
+template <typename T, bool MIRROR>
+__global__ __launch_bounds__(512, 2) void fa_fwd_pipe_w8_kernel(const FwdParams p) {
+    fa_fwd_pipe_body<T, 64, 8, 2, true, false, false, MIRROR>(p);
+}
 // head_dim 128, two query blocks per wave: 64 rows per wave, 256-row workgroups of 4 waves, ONE wave per SIMD with the whole
 // 512-entry register file (O^T and Q^T in AGPRs) - every K row / V^T fragment read from LDS feeds two MFMAs and a streamed
 // K/V step serves 256 rows: half the LDS operand reads and half the L2 -> LDS DMA per FLOP of the 128-row workgroups.
@@ -793,10 +865,22 @@ static hipError_t launch_pipe_c(const FwdParams& p, int waves, int qb, hipStream
             if constexpr (!Elt<T>::is_f16) {   // (the scale fold is selected for bf16 only: fa_capi.cpp)
                 if (p.fold) return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
             }
+#if FA_EXPERIMENTAL   /* A/B material: mirrored row blocks; 512-row workgroups on one shared ring */
+            if constexpr (CAUSAL) {
+                if (waves == 8) return p.mirror ? launch1((const void*)(fa_fwd_pipe_w8_kernel<T, true>), dim3((unsigned)grid), dim3(512), 0, stream, p)
+                                                : launch1((const void*)(fa_fwd_pipe_w8_kernel<T, false>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+                if (p.mirror) return launch1((const void*)(fa_fwd_pipe_mirror_kernel<T>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+            }
+#endif
+            if (waves != 4) return hipErrorInvalidValue;
             return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         } else {
+#if FA_EXPERIMENTAL   /* the one-wave-per-SIMD AGPR variant is A/B material: make EXPERIMENTAL=1 */
             if (waves != 4) return hipErrorInvalidValue;
             return launch1((const void*)(fa_fwd_pipe_ag_kernel<T, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+#else
+            return hipErrorInvalidValue;
+#endif
         }
     }
     hipError_t e;

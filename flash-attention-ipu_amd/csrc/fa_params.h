@@ -14,7 +14,8 @@ struct ExtraParams {
     int32_t mask_kind;     // 0 none, 1 boolean bytes (non-zero = keep), 2 additive bias in the operand dtype
     int32_t mask_vec;      // 1 = four consecutive keys may be fetched with one aligned load
     float inv_scale;       // 1 / softmax_scale (a bias is added to the RAW scores as bias / scale)
-    uint32_t drop_key0;    // seed and offset folded (fa_capi.cpp)
+    uint32_t drop_key0;    // seed and offset folded (fa_capi.cpp); ignored when drop_state is set
+    const unsigned long long* drop_state;   // device {seed, offset} (ABI 5: graph-safe dropout), nullptr = drop_key0 holds the folded immediates
     uint32_t drop_thr;     // floor(p * 2^32); 0 = no dropout
     float drop_rp;         // 1 / (1 - p)
 };
@@ -40,6 +41,7 @@ struct FwdParams {
     int32_t nq_tiles;      // q tiles per group
     int32_t sched;         // groups per XCD bunch (>= 1): heavy-first order inside a bunch
     int32_t skipmax;       // f16 only: 1 = reference max from the first tile + overflow-triggered redo
+    int32_t mirror;        // fa_fwd_pipe_kernel, head_dim 64, two blocks per wave, causal, L % 256 == 0: 1 = wave w owns row blocks w and 7 - w (fa_fwd_pipe.hip MIRROR)
     int32_t fold;          // fa_fwd_pipe_kernel, head_dim 64, two blocks per wave: 1 = scale log2(e) folded into Q, reference max 0 (scaled calls)
     float scale;           // softmax scale
     float scale_log2;      // scale * log2(e)

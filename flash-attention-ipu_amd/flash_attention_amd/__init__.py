@@ -12,3 +12,12 @@ _native.load_native_library()
 
 from ._impl.flash_attention_qkv_packed import *  # noqa: E402,F401,F403
 from ._impl.flash_attention_qkv_packed import __all__  # noqa: E402,F401
+
+
+def init_graph_dropout_state(device=None, seed=None):
+    """Create (or re-seed) the device-resident dropout generator state that graph-captured dropout launches read
+    (`_impl/ops.py`; not part of the reference's surface: the reference rejects dropout, sdpa.py:25-28).  Call it - or run one
+    eager dropout call - before `torch.cuda.graph` captures a model with attention dropout."""
+    from ._impl import ops
+
+    return ops.init_graph_dropout_state(device, seed)

@@ -17,7 +17,7 @@ _LIB = None
 _LIB_PATH = None
 
 FA_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class FaPlan(ctypes.Structure):
@@ -76,6 +76,8 @@ def _declare(lib):
     p64 = ctypes.POINTER(ctypes.c_int64)
     lib.fa_abi_version.restype = ctypes.c_int
     lib.fa_abi_version.argtypes = []
+    lib.fa_experimental_kernels.restype = ctypes.c_int
+    lib.fa_experimental_kernels.argtypes = []
     lib.fa_last_error.restype = ctypes.c_char_p
     lib.fa_last_error.argtypes = []
     lib.fa_error_string.restype = ctypes.c_char_p
@@ -96,10 +98,10 @@ def _declare(lib):
     u64 = ctypes.c_uint64
     lib.fa_fwd_ex.restype = ctypes.c_int
     lib.fa_fwd_ex.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, p64, p64, p64, p64,
-                              i32, i32, i32, ctypes.c_float, i32, vp, i32, p64, ctypes.c_float, u64, u64, vp]
+                              i32, i32, i32, ctypes.c_float, i32, vp, i32, p64, ctypes.c_float, u64, u64, vp, vp]
     lib.fa_bwd_ex.restype = ctypes.c_int
     lib.fa_bwd_ex.argtypes = [vp] * 10 + [i64, i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32,
-                                          vp, i32, p64, ctypes.c_float, u64, u64, vp]
+                                          vp, i32, p64, ctypes.c_float, u64, u64, vp, vp]
     lib.fa_probe_clock.restype = ctypes.c_int
     lib.fa_probe_clock.argtypes = [ctypes.c_void_p, i32, ctypes.c_void_p]
     lib.fa_probe_mfma_peak.restype = ctypes.c_double
@@ -131,7 +133,12 @@ def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale: float = 1.0
 
 _KERNEL_CODE = {"auto": 0, "": 0, None: 0, "dma": ord("d"), "pipe": ord("p"), "pipe16": ord("x"), "pp": ord("P"), "kh": ord("h"), "tile": ord("t")}
 _OPTION_AUTO = {"kernel": 0, "qb": 0, "waves": 0, "sched": 0, "skipmax": -1, "f32_generic": 0, "table": 1, "split": 0, "pair": -1,
-                "balance": -1, "fold": -1}
+                "balance": -1, "fold": -1, "mirror": -1}
+
+
+def experimental_kernels() -> bool:
+    """True when the loaded library was built with `make EXPERIMENTAL=1` (kernels 'tile', 'pp' and the head_dim-128 AGPR variant)."""
+    return bool(load_native_library().fa_experimental_kernels())
 
 
 def set_debug_option(name: str, value) -> None:
@@ -281,8 +288,9 @@ def _mask_args(mask, q):
     return mask.data_ptr(), kind, _strides3((mask.stride(0), mask.stride(1), mask.stride(2)))
 
 
-def fwd_ex(q, k, v, out, lse, L, D, scale, causal, mask, dropout_p, seed, offset):
-    """fa_fwd_ex on [B, H, L, D] views (k, v may carry fewer heads); mask: None or a [B, H, L, L] view (see _mask_args)."""
+def fwd_ex(q, k, v, out, lse, L, D, scale, causal, mask, dropout_p, seed, offset, state=None):
+    """fa_fwd_ex on [B, H, L, D] views (k, v may carry fewer heads); mask: None or a [B, H, L, L] view (see _mask_args);
+    state: None or an int64 [2] DEVICE tensor {seed, offset} read by the kernels instead of the two integers (graph-safe dropout)."""
     lib = load_native_library()
     B, H = q.shape[0], q.shape[1]
     st = lambda t: _strides3((t.stride(0), t.stride(1), t.stride(2)))  # noqa: E731
@@ -290,12 +298,13 @@ def fwd_ex(q, k, v, out, lse, L, D, scale, causal, mask, dropout_p, seed, offset
     with _on_device_of(q) as stream:
         rc = lib.fa_fwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
                            B * H, L, D, H, k.shape[1], st(q), st(k), st(v), st(out), 1, 1, FA_DTYPE[q.dtype], float(scale),
-                           int(bool(causal)), mptr, kind, mst, float(dropout_p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), stream)
+                           int(bool(causal)), mptr, kind, mst, float(dropout_p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+                           state.data_ptr() if state is not None else None, stream)
     if rc != 0:
         _raise(rc)
 
 
-def bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, L, D, scale, causal, mask, dropout_p, seed, offset):
+def bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, L, D, scale, causal, mask, dropout_p, seed, offset, state=None):
     """fa_bwd_ex on [B, H, L, D] views (k, v, dk, dv [B, H_kv, L, D])."""
     lib = load_native_library()
     B, H = q.shape[0], q.shape[1]
@@ -307,6 +316,7 @@ def bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, L, D, scale, causal, mask, dropo
         rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
                            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dsum.data_ptr(), B * H, L, D, H, k.shape[1],
                            ctypes.cast(arr, _P_I64x3), FA_DTYPE[q.dtype], float(scale), int(bool(causal)),
-                           mptr, kind, mst, float(dropout_p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), stream)
+                           mptr, kind, mst, float(dropout_p), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+                           state.data_ptr() if state is not None else None, stream)
     if rc != 0:
         _raise(rc)

@@ -8,7 +8,7 @@ registered autograd formula: eager, autograd and `torch.compile` all see one opa
 into the C ABI stays out of the traced graph.
 """
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -363,45 +363,156 @@ def supports_extra(q: torch.Tensor) -> bool:
     return q.dtype in (torch.float16, torch.bfloat16) and q.shape[-1] in (64, 128)
 
 
+def _fwd_ex_impl(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state):
+    q, k, v = _rows(q), _rows(k), _rows(v)
+    B, H, L, D = q.shape
+    out = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B * H, L), dtype=torch.float32, device=q.device)
+    if out.numel() > 0:
+        _native.fwd_ex(q, k, v, out, lse, L, D, softmax_scale, causal, mask, dropout_p, seed, offset, state)
+    return out, lse
+
+
+def _bwd_ex_impl(q, k, v, out, dout, lse, mask, softmax_scale, causal, dropout_p, seed, offset, state):
+    q, k, v, out, dout = (_rows(t) for t in (q, k, v, out, dout))
+    B, H, L, D = q.shape
+    dq = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
+    dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+    dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+    if dq.numel() > 0:
+        _native.bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, L, D, softmax_scale, causal, mask, dropout_p, seed, offset, state)
+    return dq, dk, dv
+
+
 class _ExtraAttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset):
-        q, k, v = _rows(q), _rows(k), _rows(v)
-        B, H, L, D = q.shape
-        out = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
-        lse = torch.empty((B * H, L), dtype=torch.float32, device=q.device)
-        if out.numel() > 0:
-            _native.fwd_ex(q, k, v, out, lse, L, D, softmax_scale, causal, mask, dropout_p, seed, offset)
-        ctx.save_for_backward(q, k, v, out, lse, *(() if mask is None else (mask,)))
-        ctx.args = (softmax_scale, causal, dropout_p, seed, offset, mask is not None)
+    def forward(ctx, q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state):
+        out, lse = _fwd_ex_impl(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state)
+        extra = tuple(t for t in (mask, state) if t is not None)
+        ctx.save_for_backward(q, k, v, out, lse, *extra)
+        ctx.args = (softmax_scale, causal, dropout_p, seed, offset, mask is not None, state is not None)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors[:5]
-        softmax_scale, causal, dropout_p, seed, offset, has_mask = ctx.args
-        mask = ctx.saved_tensors[5] if has_mask else None
-        B, H, L, D = q.shape
-        dout = _rows(dout)
-        dq = torch.empty((B, H, L, D), dtype=q.dtype, device=q.device)
-        dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
-        dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
-        if dq.numel() > 0:
-            _native.bwd_ex(q, k, v, out, dout, lse, dq, dk, dv, L, D, softmax_scale, causal, mask, dropout_p, seed, offset)
-        return dq, dk, dv, None, None, None, None, None, None
+        softmax_scale, causal, dropout_p, seed, offset, has_mask, has_state = ctx.args
+        rest = list(ctx.saved_tensors[5:])
+        mask = rest.pop(0) if has_mask else None
+        state = rest.pop(0) if has_state else None
+        dq, dk, dv = _bwd_ex_impl(q, k, v, out, dout, lse, mask, softmax_scale, causal, dropout_p, seed, offset, state)
+        return dq, dk, dv, None, None, None, None, None, None, None
 
 
-def attention_extra(q, k, v, mask, softmax_scale, causal, dropout_p=0.0, seed=0, offset=0):
-    """[B, H, L, D] attention with an attention mask / bias and / or dropout -> out [B, H, L, D], differentiable in q, k, v."""
-    return _ExtraAttentionFn.apply(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset)
+# the same two implementations as opaque custom ops: what torch.compile traces (fake implementations for shape inference, registered
+# autograd) - the counterpart, for the mask / dropout entry points, of the reference's op registration (FA.cpp:609-625)
+@custom_op("flash_attention_amd::fwd_ex", mutates_args=())
+def fwd_ex(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Optional[torch.Tensor], softmax_scale: float, causal: bool,
+           dropout_p: float, seed: int, offset: int, state: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    return _fwd_ex_impl(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state)
+
+
+@fwd_ex.register_fake
+def _(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state):
+    B, H, L, D = q.shape
+    return q.new_empty((B, H, L, D)), q.new_empty((B * H, L), dtype=torch.float32)
+
+
+@custom_op("flash_attention_amd::bwd_ex", mutates_args=())
+def bwd_ex(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor,
+           mask: Optional[torch.Tensor], softmax_scale: float, causal: bool, dropout_p: float, seed: int, offset: int,
+           state: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    return _bwd_ex_impl(q, k, v, out, dout, lse, mask, softmax_scale, causal, dropout_p, seed, offset, state)
+
+
+@bwd_ex.register_fake
+def _(q, k, v, out, dout, lse, mask, softmax_scale, causal, dropout_p, seed, offset, state):
+    return q.new_empty(q.shape), k.new_empty(k.shape), v.new_empty(v.shape)
+
+
+def _ex_setup(ctx, inputs, output):
+    q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state = inputs
+    out, lse = output
+    extra = tuple(t for t in (mask, state) if t is not None)
+    ctx.save_for_backward(q, k, v, out, lse, *extra)
+    ctx.args = (softmax_scale, causal, dropout_p, seed, offset, mask is not None, state is not None)
+
+
+def _ex_backward(ctx, dout, _dlse):
+    q, k, v, out, lse = ctx.saved_tensors[:5]
+    softmax_scale, causal, dropout_p, seed, offset, has_mask, has_state = ctx.args
+    rest = list(ctx.saved_tensors[5:])
+    mask = rest.pop(0) if has_mask else None
+    state = rest.pop(0) if has_state else None
+    dq, dk, dv = bwd_ex(q, k, v, out, dout, lse, mask, softmax_scale, causal, dropout_p, seed, offset, state)
+    return dq, dk, dv, None, None, None, None, None, None, None
+
+
+fwd_ex.register_autograd(_ex_backward, setup_context=_ex_setup)
+
+
+def attention_extra(q, k, v, mask, softmax_scale, causal, dropout_p=0.0, seed=0, offset=0, state=None):
+    """[B, H, L, D] attention with an attention mask / bias and / or dropout -> out [B, H, L, D], differentiable in q, k, v.
+    `state`: None, or an int64 [2] device tensor {seed, offset} the kernels read instead of the two integers (graph-safe dropout)."""
+    if torch.compiler.is_compiling():
+        return fwd_ex(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state)[0]
+    return _ExtraAttentionFn.apply(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state)
+
+
+# ---- dropout randomness ------------------------------------------------------------------------------------------------------
+# Eager calls take (seed, offset) from torch's CUDA generator on the HOST (next_dropout_seed) and pass them as immediates.  A launch
+# captured in a HIP graph (torch.cuda.graph) would bake those two integers into every replay - one mask forever - so under capture the
+# kernels read them from DEVICE memory instead (ABI 5 `dropout_state`): a per-device generator state {seed, offset} lives in an int64 [2]
+# tensor; a capturing call copies it to a snapshot of its own (which its backward reads too) and advances the live state by the number
+# of decisions it consumes - both are captured device operations, so every replay draws fresh decisions and forward / backward of
+# one replay agree.  The state is created OUTSIDE capture (an H2D copy cannot be captured): by the first eager dropout call on the
+# device - the usual warm-up run before a capture - or explicitly by init_graph_dropout_state().
+_GRAPH_DROPOUT_STATE = {}
+
+
+def _device_index(device) -> int:
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def init_graph_dropout_state(device=None, seed: Optional[int] = None) -> torch.Tensor:
+    """Create (or re-seed) the device-resident dropout state of `device`: seed from torch's CUDA generator unless given."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = _device_index(device)
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("flash_attention_amd: the graph-safe dropout state must be created outside graph capture - run one eager "
+                           "dropout call (the usual warm-up) or flash_attention_amd.init_graph_dropout_state() before torch.cuda.graph")
+    gen = torch.cuda.default_generators[idx]
+    s = gen.initial_seed() if seed is None else int(seed)
+    try:
+        off = gen.get_offset()
+    except RuntimeError:
+        off = 0
+    st = torch.tensor([s & (2 ** 63 - 1), off & (2 ** 63 - 1)], dtype=torch.int64, device=torch.device("cuda", idx))
+    _GRAPH_DROPOUT_STATE[idx] = st
+    return st
+
+
+def capture_dropout_state(device, numel: int) -> torch.Tensor:
+    """Inside graph capture: this call's snapshot of the device-resident state (what its kernels read), the live state advanced past the
+    `numel` decisions of the launch - two captured device operations."""
+    st = _GRAPH_DROPOUT_STATE.get(_device_index(device))
+    if st is None:
+        raise RuntimeError("flash_attention_amd: dropout under graph capture needs the device-resident generator state - run one eager "
+                           "dropout call (the usual warm-up) or flash_attention_amd.init_graph_dropout_state() before torch.cuda.graph")
+    snap = st.clone()
+    st[1:].add_(((numel + 3) // 4) * 4)
+    return snap
 
 
 def next_dropout_seed(device, numel: int):
     """(seed, offset) for one dropout launch, drawn from torch's generator of `device` the way its own dropout kernels do: the
     generator's seed and its running offset, which is advanced past the `numel` decisions of this launch - so torch.manual_seed
     makes runs repeatable and successive calls see different masks."""
-    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    idx = _device_index(device)
+    gen = torch.cuda.default_generators[idx]
+    if idx not in _GRAPH_DROPOUT_STATE:      # (the warm-up call before a capture creates the device-resident state)
+        init_graph_dropout_state(torch.device("cuda", idx))
     seed = gen.initial_seed()
     try:
         offset = gen.get_offset()

@@ -59,8 +59,10 @@ def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale
     """attn_mask and / or dropout through the mask / dropout kernels; None when this call is not one they take (the caller then
     hands it to stock SDPA): operands other than f16 / bf16 at head_dim 64 / 128, more than two batch dimensions, a mask that
     wants a gradient or does not broadcast to [B, H, L, L], attn_mask together with is_causal (torch's own error), tracing."""
-    if not ops.supports_extra(query) or query.ndim not in (3, 4) or torch.compiler.is_compiling():
+    if not ops.supports_extra(query) or query.ndim not in (3, 4):
         return None
+    if torch.compiler.is_compiling() and dropout_p > 0.0:
+        return None       # (the generator state is host state: a traced graph gets stock SDPA's dropout; masks trace through fwd_ex)
     if attn_mask is not None and (is_causal or attn_mask.requires_grad or not attn_mask.is_cuda):
         return None
     if not (0.0 <= dropout_p < 1.0):
@@ -90,8 +92,13 @@ def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale
             m = m.contiguous()
         mask = m.view(torch.uint8) if m.dtype == torch.bool else m
     softmax_scale = D ** -0.5 if scale is None else scale
-    seed, offset = ops.next_dropout_seed(query.device, B * H * L * L) if dropout_p > 0.0 else (0, 0)
-    out = ops.attention_extra(q4, k4, v4, mask, softmax_scale, bool(is_causal), float(dropout_p), seed, offset)
+    seed, offset, state = 0, 0, None
+    if dropout_p > 0.0:
+        if torch.cuda.is_current_stream_capturing():     # graph capture: (seed, offset) from device memory, fresh on every replay
+            state = ops.capture_dropout_state(query.device, B * H * L * L)
+        else:
+            seed, offset = ops.next_dropout_seed(query.device, B * H * L * L)
+    out = ops.attention_extra(q4, k4, v4, mask, softmax_scale, bool(is_causal), float(dropout_p), seed, offset, state)
     return out.squeeze(1) if query.ndim == 3 else out
 
 

@@ -47,8 +47,9 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 4   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
-                              fa_fwd_ex / fa_bwd_ex (attention mask or bias, dropout) */
+#define FA_ABI_VERSION 5   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
+                              fa_fwd_ex / fa_bwd_ex (attention mask or bias, dropout); 5: fa_fwd_ex / fa_bwd_ex take `dropout_state`
+                              (seed and offset in DEVICE memory: graph-safe dropout), fa_experimental_kernels() */
 
 /* element types (reference allows FLOAT16 and FLOAT, FA.cpp:609; bf16 is new here) */
 enum { FA_DTYPE_F16 = 0, FA_DTYPE_BF16 = 1, FA_DTYPE_F32 = 2 };
@@ -103,6 +104,11 @@ typedef struct fa_plan_t {
 } fa_plan_t;
 
 int fa_abi_version(void);
+
+/* 1 when the library was built with `make EXPERIMENTAL=1`: it then also carries the kernels no rule and no table row selects
+ * (register-staged baseline 't', complementary-phase workgroups 'P', the one-wave-per-SIMD variant of the pipelined kernel at head_dim
+ * 128) and fa_debug_set_option("kernel", 't' | 'P') is accepted; 0 in the product build.  [ABI 5]  (No reference counterpart.) */
+int fa_experimental_kernels(void);
 
 /* thread-local text of the last failure on this thread ("" if none) */
 const char* fa_last_error(void);
@@ -221,6 +227,11 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
  *   dropout_p     : probability in [0, 1) of dropping an attention weight (0 = off); kept weights are scaled by 1 / (1 - p).
  *                   The decision for (g, row, key) is a pure function of (dropout_seed, dropout_offset, g, row, key)
  *                   (csrc/fa_extras.h), so fa_bwd_ex given the same three values regenerates the forward's mask.
+ *   dropout_state : NULL, or a DEVICE pointer to two uint64 {seed, offset} that the kernels read INSTEAD of the two immediate values
+ *                   [ABI 5].  A launch captured in a HIP graph bakes its immediates into every replay - one dropout mask forever;
+ *                   with the two words in device memory the caller captures its own update of them (copy the generator's state to
+ *                   a per-call snapshot, advance the generator) and every replay sees fresh values.  fa_bwd_ex must be given the
+ *                   snapshot its forward read.  8-byte aligned; read on `stream`, never written.
  * f16 / bf16 operands at head_dim 64 or 128 with 16-byte aligned rows run MFMA kernels (csrc/fa_fwd_extra.hip, fa_bwd_extra.hip);
  * everything else fa_fwd serves (fp32, other head dims <= 1024, unaligned rows) runs the generic fp32-arithmetic kernels with the same
  * mask and the same dropout decisions (a bias then has the operand dtype, fp32 included).  With mask = NULL and dropout_p = 0 they
@@ -232,13 +243,13 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse
               const int64_t o_strides[3],
               int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, float softmax_scale, int32_t causal,
               const void* mask, int32_t mask_kind, const int64_t mask_strides[3],
-              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, void* stream);
+              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, const uint64_t* dropout_state, void* stream);
 int fa_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
               void* dq, void* dk, void* dv, float* dsum_workspace,
               int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv, const int64_t strides[8][3],
               int32_t dtype, float softmax_scale, int32_t causal,
               const void* mask, int32_t mask_kind, const int64_t mask_strides[3],
-              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, void* stream);
+              float dropout_p, uint64_t dropout_seed, uint64_t dropout_offset, const uint64_t* dropout_state, void* stream);
 
 /* Forward on a contiguous packed qkv [3,G,L,D] -> out [G,L,D] (scale 1, causal). */
 int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,

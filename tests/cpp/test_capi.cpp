@@ -95,7 +95,7 @@ int main() {
         const int64_t st[3] = {L * D, 0, D}, mst[3] = {0, 0, 0};
         const char* base = static_cast<const char*>(d_qkv);
         rc = fa_fwd_ex(base, base + G * L * D * 2, base + 2 * G * L * D * 2, d_out, d_lse, G, L, D, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16,
-                       0.125f, 0, d_mask, FA_MASK_BOOL, mst, pdrop, seed, offset, nullptr);
+                       0.125f, 0, d_mask, FA_MASK_BOOL, mst, pdrop, seed, offset, nullptr, nullptr);
         if (rc != FA_OK) { std::printf("fa_fwd_ex: %s\n", fa_last_error()); return 1; }
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipMemcpy(out.data(), d_out, out.size() * 2, hipMemcpyDeviceToHost));

@@ -55,6 +55,67 @@ int main() {
                     EXPECT(plan.block_q >= 1 && plan.grid >= 1 && plan.waves >= 1 && plan.sched >= 1);
                     if (plan.kernel == 0 || plan.kernel == 2) EXPECT(plan.block_q == 32 * plan.waves * plan.qb && (plan.block_q <= 4096 / nq || plan.block_q == 32));
                 }
+    // ---- the plan grid: every request x every debug override must come out as something the kernels can launch (round-3 verdict,
+    // item 7: select_plan = rules -> table -> overrides -> ONE constraints pass; these are the invariants of that pass)
+    {
+        struct Ov { const char* name; int32_t value; };
+        const std::vector<std::vector<Ov>> overrides = {
+            {}, {{"kernel", 'd'}}, {{"kernel", 'p'}}, {{"kernel", 'x'}}, {{"kernel", 'h'}}, {{"waves", 1}}, {{"waves", 2}}, {{"waves", 4}}, {{"waves", 8}},
+            {{"qb", 1}}, {{"qb", 2}}, {{"split", 2}}, {{"split", 4}}, {{"table", 0}}, {{"pair", 1}}, {{"balance", 1}}, {{"balance", 0}}, {{"sched", 3}},
+            {{"skipmax", 0}}, {{"skipmax", 1}}, {{"kernel", 'p'}, {"qb", 2}}, {{"kernel", 'x'}, {"qb", 2}}, {{"kernel", 'x'}, {"waves", 8}},
+            {{"kernel", 'h'}, {"split", 2}}, {{"kernel", 'h'}, {"split", 4}}, {{"kernel", 'd'}, {"split", 4}}, {{"kernel", 'p'}, {"waves", 8}},
+            {{"kernel", 'd'}, {"qb", 2}}, {{"kernel", 'h'}, {"balance", 1}}, {{"kernel", 'd'}, {"pair", 1}}, {{"f32_generic", 1}}};
+        const char* names[] = {"kernel", "qb", "waves", "sched", "skipmax", "f32_generic", "table", "split", "pair", "balance", "fold"};
+        const int32_t autos[] = {0, 0, 0, 0, -1, 0, 1, 0, -1, -1, -1};
+        long checked = 0;
+        for (const auto& ov : overrides) {
+            for (int i = 0; i < 11; ++i) EXPECT(fa_debug_set_option(names[i], autos[i]) == FA_OK);
+            for (const Ov& o : ov) EXPECT(fa_debug_set_option(o.name, o.value) == FA_OK);
+            for (int64_t G : {1, 7, 8, 12, 96, 128, 2048})
+                for (int64_t L : {1, 6, 32, 100, 256, 1000, 1024, 2048, 4096, 32768})
+                    for (int64_t D : {2, 64, 96, 128})
+                        for (int dt : {FA_DTYPE_F16, FA_DTYPE_BF16, FA_DTYPE_F32})
+                            for (int32_t nc : {1, 2, 8, 64})
+                                for (float scale : {1.0f, 0.125f})
+                                    for (int causal : {0, 1}) {
+                                        if (L % nc) continue;
+                                        fa_plan_t pl;
+                                        if (fa_plan(G, L, D, dt, nc, nc == 8 ? 4 : nc, scale, causal, &pl) != FA_OK) { EXPECT(L % (nc == 8 ? 4 : nc) != 0); continue; }
+                                        ++checked;
+                                        const bool mfma16 = (D == 64 || D == 128) && dt != FA_DTYPE_F32;
+                                        const int64_t chunk = L / nc;
+                                        EXPECT(pl.grid >= 1 && pl.grid <= 0x7fffffffll && pl.waves >= 1 && pl.sched >= 1 && pl.block_q >= 1 && pl.block_kv >= 1);
+                                        EXPECT(pl.lds_bytes > 0 && pl.lds_bytes <= 160 * 1024);                  // one workgroup must fit a CU's LDS
+                                        EXPECT(pl.chunk_q == chunk);
+                                        if (!mfma16) { EXPECT(pl.kernel == 1 || pl.kernel == 3); continue; }
+                                        EXPECT(pl.kernel == 0 || pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 6);   // nothing experimental in this build
+                                        EXPECT(pl.qb == 1 || pl.qb == 2);
+                                        EXPECT(pl.waves == 1 || pl.waves == 2 || pl.waves == 4 || pl.waves == 8 || pl.waves == 16);
+                                        EXPECT(pl.waves <= 16 && 64 * pl.waves <= 1024);                            // a workgroup is at most 1024 threads
+                                        EXPECT(pl.skipmax == (dt == FA_DTYPE_BF16 || pl.skipmax));                  // bf16 always runs the skip-max arithmetic
+                                        if (pl.kernel == 2 || pl.kernel == 4) EXPECT(pl.skipmax == 1 && pl.block_kv == 32);
+                                        if (pl.kernel == 6) { EXPECT(pl.block_q == 64 && pl.qb == 1 && (pl.waves == 4 || pl.waves == 8 || (pl.waves == 16 && D == 64))); }
+                                        else {
+                                            const int64_t rows = 32ll * pl.waves * pl.qb;
+                                            EXPECT(rows % pl.block_q == 0);
+                                            const int64_t split = rows / pl.block_q;
+                                            EXPECT(split == 1 || ((split == 2 || (split == 4 && D == 64)) && pl.kernel == 0 && pl.qb == 1));
+                                        }
+                                        if (pl.qb == 2) EXPECT(D == 64 && (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 0) && pl.block_q == 256);
+                                        // an unforced plan honours the q chunk as an upper bound on the workgroup's rows
+                                        if (ov.empty()) EXPECT(pl.block_q <= (chunk > 32 ? chunk : 32) || pl.kernel == 6);
+                                        // the grid covers every (group, q tile): 8-aligned groups x tiles (pairs: two tiles per workgroup)
+                                        const int64_t g8 = (G + 7) / 8 * 8, tiles = (L + pl.block_q - 1) / pl.block_q;
+                                        EXPECT(pl.grid == (pl.pair ? g8 * ((tiles + 1) / 2) : g8 * tiles));
+                                        if (pl.pair) EXPECT(pl.kernel == 0 && causal == 1 && pl.qb == 1);
+                                        if (pl.balanced) EXPECT(causal == 1 && (pl.kernel == 0 || pl.kernel == 6));
+                                    }
+        }
+        for (int i = 0; i < 11; ++i) EXPECT(fa_debug_set_option(names[i], autos[i]) == FA_OK);
+        EXPECT(checked > 100000);
+        EXPECT(fa_experimental_kernels() == 0);
+        EXPECT(fa_debug_set_option("kernel", 't') == FA_ERR_BAD_OPTION && fa_debug_set_option("kernel", 'P') == FA_ERR_BAD_OPTION);   // not in the product build
+    }
     // ---- debug options
     int32_t v = -7;
     EXPECT(fa_debug_set_option(nullptr, 1) == FA_ERR_NULL_POINTER);
@@ -115,29 +176,29 @@ int main() {
     {
         const int64_t ms[3] = {0, 0, 128}, ms_neg[3] = {0, -1, 128};
         const int n0 = g_stub_launches;
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last == 'E');
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F16, 0.125f, 0, p, FA_MASK_BIAS, ms, 0.25f, 7, 9, nullptr) == FA_OK && g_stub_last == 'E');
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.1f, 1ull << 63, ~0ull, nullptr) == FA_OK && g_stub_last == 'E');
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last != 'E');   // nothing extra = fa_fwd
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'E');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F16, 0.125f, 0, p, FA_MASK_BIAS, ms, 0.25f, 7, 9, nullptr, nullptr) == FA_OK && g_stub_last == 'E');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.1f, 1ull << 63, ~0ull, nullptr, nullptr) == FA_OK && g_stub_last == 'E');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last != 'E');   // nothing extra = fa_fwd
         EXPECT(g_stub_launches == n0 + 4);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_NONE, ms, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_MASK);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_MASK);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, 3, ms, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_MASK);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, nullptr, 0.0f, 0, 0, nullptr) == FA_ERR_NULL_POINTER);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms_neg, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_STRIDE);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, buf + 1, FA_MASK_BIAS, ms, 0.0f, 0, 0, nullptr) == FA_ERR_MISALIGNED);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 1.0f, 0, 0, nullptr) == FA_ERR_BAD_DROPOUT);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, -0.5f, 0, 0, nullptr) == FA_ERR_BAD_DROPOUT);
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 0.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr) == FA_ERR_BAD_SCALE);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_NONE, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_MASK);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_MASK);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, 3, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_MASK);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, nullptr, 0.0f, 0, 0, nullptr, nullptr) == FA_ERR_NULL_POINTER);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms_neg, 0.0f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_STRIDE);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, buf + 1, FA_MASK_BIAS, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_ERR_MISALIGNED);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 1.0f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_DROPOUT);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, -0.5f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_DROPOUT);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 0.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_SCALE);
         // operands the MFMA mask kernels do not take go to the generic kernels (never to the fp32 MFMA kernel, which has no mask path)
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr) == FA_OK && g_stub_last == 'g');
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 80, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last == 'g');
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 2048, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr) == FA_ERR_BAD_SHAPE);   // (head_dim > 1024: as fa_fwd)
-        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BIAS, ms, 0.1f, 3, 4, nullptr) == FA_OK && g_stub_last == 'e');
-        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last == 'B');
-        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.3f, 0, 0, nullptr) == FA_OK && g_stub_last == 'b');
-        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr) == FA_OK && g_stub_last == 'F');   // nothing extra: the fp32 MFMA kernels
-        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 2.0f, 0, 0, nullptr) == FA_ERR_BAD_DROPOUT);
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'g');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 80, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'g');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 2048, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_SHAPE);   // (head_dim > 1024: as fa_fwd)
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BIAS, ms, 0.1f, 3, 4, nullptr, nullptr) == FA_OK && g_stub_last == 'e');
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'B');
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.3f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'b');
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'F');   // nothing extra: the fp32 MFMA kernels
+        EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 2.0f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_DROPOUT);
     }
     st8[3][1] = -5;
     EXPECT(fa_bwd(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_ERR_BAD_STRIDE);

@@ -171,6 +171,8 @@ def test_pipelined_kernel_one_wave_per_simd_head_dim_128(knobs, dtype, scale, G,
     _, native, _ = _mods()
     from oracle import dense_attention_lse, frozen_randn
 
+    if not native.experimental_kernels():
+        pytest.skip("the one-wave-per-SIMD AGPR variant is A/B material, not in the product library (make EXPERIMENTAL=1)")
     knobs.set("kernel", "pipe")
     knobs.set("qb", 2)
     p = native.plan(G, L, 128, dtype, 1, 1, softmax_scale=scale, causal=causal)
@@ -185,6 +187,72 @@ def test_pipelined_kernel_one_wave_per_simd_head_dim_128(knobs, dtype, scale, G,
     native.fwd_strided(q, k, v, out, lse, G, L, 128, 1, st, st, st, st, 1, 1, scale, causal)
     _check(out, ref, dtype, f"pipe ag {dtype} scale={scale:.3g} causal={causal} {G}x{L}x128")
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.float16, 0.125)])
+@pytest.mark.parametrize("G,L", [(3, 512), (9, 1024), (2, 2560), (1, 4608), (2, 4096), (2, 700)])
+def test_512_row_workgroups_on_one_shared_ring(knobs, dtype, scale, G, L):
+    """fa_fwd_pipe_w8_kernel (A/B material): 8 waves x 2 blocks = 512-row workgroups at head_dim 64 streaming K/V through
+    ONE ring (one LDS-DMA piece per wave and step), with and without mirrored row blocks (blocks w and 15 - w): bit-identical to the
+    256-row kernel - every row runs the same program - and equal to the oracle."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    if not native.experimental_kernels():
+        pytest.skip("A/B material, not in the product library (make EXPERIMENTAL=1)")
+    x = frozen_randn(SEED + 29 * L + G, (3, G, L, 64)).to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale)
+    q, k, v = x.cuda()
+    st = (L * 64, 0, 64)
+    res = []
+    for waves, mirror in ((4, 0), (8, 0), (8, 1)):
+        knobs.set("kernel", "pipe")
+        knobs.set("qb", 2)
+        knobs.set("waves", waves)
+        knobs.set("mirror", mirror)
+        p = native.plan(G, L, 64, dtype, 1, 1, softmax_scale=scale)
+        assert (p.kernel, p.waves, p.qb, p.block_q) == (2, waves, 2, 64 * waves)
+        out = torch.empty_like(q)
+        lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+        native.fwd_strided(q, k, v, out, lse, G, L, 64, 1, st, st, st, st, 1, 1, scale)
+        res.append((out, lse))
+    _check(res[1][0], ref, dtype, f"512-row workgroups {dtype} scale={scale:.3g} {G}x{L}x64")
+    torch.testing.assert_close(res[1][1].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+    for o, l_ in res[1:]:
+        assert torch.equal(res[0][0], o) and torch.equal(res[0][1], l_), "512-row workgroups / mirroring must not change a single bit"
+
+
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 0.125), (torch.float16, 0.125)])
+@pytest.mark.parametrize("G,L", [(2, 256), (3, 512), (9, 1024), (2, 2304), (1, 4608), (2, 4096)])
+def test_mirrored_row_blocks_of_the_two_block_pipelined_kernel(knobs, dtype, scale, G, L):
+    """fa_fwd_pipe_mirror_kernel: wave w of a 256-row workgroup owns the 32-row blocks w and 7 - w instead of 2 w and 2 w + 1, runs
+    one-block steps (the dead block's MFMAs are not issued) between its two diagonals, the PV of block 0's diagonal P one step
+    later.  Every row runs the same program as in the unmirrored kernel, so the results are BIT-IDENTICAL to it, and both match
+    the oracle; one-tile, two-tile and many-tile sequences (first step only / left-over steps / groups of four in front of the
+    diagonal region)."""
+    _, native, _ = _mods()
+    from oracle import frozen_randn
+
+    if not native.experimental_kernels():
+        pytest.skip("A/B material, not in the product library (make EXPERIMENTAL=1)")
+    knobs.set("kernel", "pipe")
+    knobs.set("qb", 2)
+    p = native.plan(G, L, 64, dtype, 1, 1, softmax_scale=scale)
+    assert (p.kernel, p.waves, p.qb, p.block_q) == (2, 4, 2, 256)
+    x = frozen_randn(SEED + 23 * L + G, (3, G, L, 64)).to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale)
+    q, k, v = x.cuda()
+    st = (L * 64, 0, 64)
+    res = []
+    for mirror in (0, 1):
+        knobs.set("mirror", mirror)
+        out = torch.empty_like(q)
+        lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+        native.fwd_strided(q, k, v, out, lse, G, L, 64, 1, st, st, st, st, 1, 1, scale)
+        res.append((out, lse))
+    _check(res[1][0], ref, dtype, f"mirrored {dtype} scale={scale:.3g} {G}x{L}x64")
+    torch.testing.assert_close(res[1][1].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "mirroring must not change a single bit"
 
 
 @pytest.mark.parametrize("D,split", [(64, 2), (64, 4), (128, 2)])

@@ -43,13 +43,13 @@ def test_library_exports_every_declared_symbol(native):
     lib = native.load_native_library()
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/flash_attention_amd.h but not exported"
-    assert lib.fa_abi_version() == 4
+    assert lib.fa_abi_version() == 5
     assert native.library_path().name == "libflash_attention.so"
 
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 4;}\n')
+    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 5;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
 
 
@@ -204,7 +204,12 @@ def _check_builtin_rules(native):
     assert native.plan(5, 200, 64, torch.bfloat16, 1, 1).grid == 8 * 2       # G padded to the 8 XCDs
     # the complementary-phase kernel (fa_fwd_pp.hip) is a forced variant only: head_dim 64, skip-max arithmetic; one workgroup =
     # 8 waves = two 256-row halves (the same q tile of two groups of one XCD class); groups per bunch are counted in pairs
-    with native.debug_options(kernel="pp"):
+    if not native.experimental_kernels():      # the product build: the forced variant is refused, nothing changes
+        with pytest.raises(ValueError, match="not in this build"):
+            native.set_debug_option("kernel", "pp")
+        assert native.plan(128, 4096, 64, torch.bfloat16, 8, 8).kernel == 2
+    else:
+      with native.debug_options(kernel="pp"):
         p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)
         assert (p.kernel, p.block_q, p.block_kv, p.waves, p.qb, p.source) == (5, 256, 32, 8, 2, 2)
         assert p.grid == 8 * 8 * 16 and p.lds_bytes == 2 * (4 * 4096 + 8 * (2048 + 64)) + 32 and p.sched == 4
