@@ -317,13 +317,17 @@ GQA_NATIVE_MIN_WORKGROUPS = 512
 
 def attention_gqa(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
     """[B, H, L, D] query with [B, H_kv, L, D] key / value (H a multiple of H_kv) -> out [B, H, L, D], differentiable.
-    K and V are never copied on either route."""
+    The native route never copies K or V.  The small-grid route works on (batch x K/V head, rep, L, D) VIEWS - free for tensors
+    laid out [B, H, L, D] (the head stride splits into (K/V head, rep) and K / V are read through a head stride of 0); for head-inner
+    layouts ([B, L, H, D] viewed [B, H, L, D]: the usual slices of a fused projection) batch and head strides do not merge, so
+    `reshape` materialises q, k and v once there (and autograd keeps those copies for the backward) - the price of the faster
+    kernels on a grid the native dK / dV kernel would under-fill."""
     B, H, L, D = q.shape
     Hkv = k.shape[1]
     if B * Hkv * ((L + 127) // 128) < GQA_NATIVE_MIN_WORKGROUPS and Hkv != H:
         # small K/V grid: the multi-head kernels on VIEWS - the batch axis becomes (batch, K/V head), the head axis the `rep` query
-        # heads of one group, and K / V are read through a head stride of 0 (round 3: no repeat_interleave copies of K and V, neither
-        # for the forward nor kept for the backward; only dK / dV exist per query head until autograd's expand-backward sums them)
+        # heads of one group, and K / V are read through a head stride of 0 (no repeat_interleave copies of K and V; only dK / dV
+        # exist per query head until autograd's expand-backward sums them).  (Head-inner operands: `reshape` copies - see the docstring.)
         rep = H // Hkv
         q5 = q.reshape(B * Hkv, rep, L, D)
         k5 = k.reshape(B * Hkv, 1, L, D).expand(B * Hkv, rep, L, D)

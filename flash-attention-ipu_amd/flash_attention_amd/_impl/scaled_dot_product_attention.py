@@ -90,7 +90,7 @@ def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale
             return None
         if m.stride(-1) != 1:      # (a mask broadcast along the keys: materialise that row once)
             m = m.contiguous()
-        mask = m.view(torch.uint8) if m.dtype == torch.bool else m
+        mask = m      # (boolean masks go down as they are: one byte per element; no dtype view - inductor cannot lower bool.view(uint8))
     softmax_scale = D ** -0.5 if scale is None else scale
     seed, offset, state = 0, 0, None
     if dropout_p > 0.0:
