@@ -109,15 +109,23 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     const bool wave_active = q_row0 < L;
     const int qr = qrow < L ? qrow : L - 1;
 
+    const int dchunks = p.Dr >> 3;
     // B operands: Q^T and dO^T fragments of this lane's query row; per-row constants
     vec8 qf[KS], dof[KS];
     {
-        const T* qp = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh + (int64_t)qr * p.q_sl + 8 * h;
-        const T* gp = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh + (int64_t)qr * p.do_sl + 8 * h;
+        // (columns past the operands' true head dim - BwdParams::Dr, in 16-byte chunks - read as zeros: predicated here, out-of-range
+        //  LDS-DMA chunks below; the gradients' columns past it are not stored)
+        const T* qp = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh + (int64_t)qr * p.q_sl;
+        const T* gp = (const T*)p.dout + (int64_t)bb * p.do_sb + (int64_t)hh * p.do_sh + (int64_t)qr * p.do_sl;
+        vec8 z_;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z_[j] = (T)0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = *(const vec8*)(qp + 16 * ks);
-            dof[ks] = *(const vec8*)(gp + 16 * ks);
+            const int ch_ = 2 * ks + h, cc_ = ch_ < dchunks ? ch_ : 0;
+            const vec8 ql_ = *(const vec8*)(qp + 8 * cc_), gl_ = *(const vec8*)(gp + 8 * cc_);
+            qf[ks] = ch_ < dchunks ? ql_ : z_;
+            dof[ks] = ch_ < dchunks ? gl_ : z_;
         }
     }
     // (a row whose every key was masked has lse = -inf and P = 0: its exponent offset is taken as 0, never inf - inf)
@@ -131,11 +139,11 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     // which runs after this kernel on the same stream (this replaces a separate pass over dO and O).
     float dsum;
     {
-        const T* op = (const T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)qr * p.o_sl + 8 * h;
+        const T* op = (const T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)qr * p.o_sl;
         float acc = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const vec8 of = *(const vec8*)(op + 16 * ks);
+            const vec8 of = *(const vec8*)(op + 8 * ((2 * ks + h) < dchunks ? 2 * ks + h : 0));   // (times a zero dO fragment past the head dim)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc += (float)of[j] * (float)dof[ks][j];
         }
@@ -154,12 +162,12 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
         const int pc = wave + j * NWAVES;
         const int row = (2 * (pc & 3) + (lane >> 5)) * 8 + ((lane >> 2) & 7);
         const int chunk = (pc >> 2) * 4 + ((lane & 3) ^ ((row >> 2) & 3));
-        k_vo[j] = (unsigned)row * k_slb + (chunk << 4);
-        v_vo[j] = (unsigned)row * v_slb + (chunk << 4);
+        k_vo[j] = chunk < dchunks ? (unsigned)row * k_slb + (chunk << 4) : 0x80000000u;   // (past the true head dim: zeros)
+        v_vo[j] = chunk < dchunks ? (unsigned)row * v_slb + (chunk << 4) : 0x80000000u;
         dst[j] = (pc >> 2) * 4096 + (pc & 3) * 1024;
     }
-    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;
-    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
+    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + (unsigned)p.Dr) * 2;
+    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + (unsigned)p.Dr) * 2;
 #define FA_DMA_KV(T_, BUF_)                                                                        \
     {                                                                                              \
         const unsigned ko_ = (unsigned)(T_) * BK * k_slb, vo_ = (unsigned)(T_) * BK * v_slb;       \
@@ -381,7 +389,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             vec4 w;
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = (T)(dq[dt][4 * rg + j] * p.scale);
-            *(vec4*)(og + 32 * dt + 8 * rg + 4 * h) = w;
+            if (4 * dt + rg < dchunks) *(vec4*)(og + 32 * dt + 8 * rg + 4 * h) = w;
         }
     }
 }
@@ -430,15 +438,21 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     const bool wave_active = key0 < L;
     const int kr = key < L ? key : L - 1;
 
+    const int dchunks = p.Dr >> 3;
     // B operands: K^T and V^T fragments of this lane's key
     vec8 kf[KS], vf[KS];
     {
-        const T* kp = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh + (int64_t)kr * p.k_sl + 8 * h;
-        const T* vp = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh + (int64_t)kr * p.v_sl + 8 * h;
+        const T* kp = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)hh * p.k_sh + (int64_t)kr * p.k_sl;
+        const T* vp = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)hh * p.v_sh + (int64_t)kr * p.v_sl;
+        vec8 z_;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = *(const vec8*)(kp + 16 * ks);
-            vf[ks] = *(const vec8*)(vp + 16 * ks);
+        for (int j = 0; j < 8; ++j) z_[j] = (T)0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {     // (columns past the true head dim, BwdParams::Dr: zeros)
+            const int ch_ = 2 * ks + h, cc_ = ch_ < dchunks ? ch_ : 0;
+            const vec8 kl_ = *(const vec8*)(kp + 8 * cc_), vl_ = *(const vec8*)(vp + 8 * cc_);
+            kf[ks] = ch_ < dchunks ? kl_ : z_;
+            vf[ks] = ch_ < dchunks ? vl_ : z_;
         }
     }
     const float c = p.scale_log2;
@@ -452,12 +466,12 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         const int pc = wave + j * NWAVES;
         const int row = (2 * (pc & 3) + (lane >> 5)) * 8 + ((lane >> 2) & 7);
         const int chunk = (pc >> 2) * 4 + ((lane & 3) ^ ((row >> 2) & 3));
-        q_vo[j] = (unsigned)row * q_slb + (chunk << 4);
-        g_vo[j] = (unsigned)row * g_slb + (chunk << 4);
+        q_vo[j] = chunk < dchunks ? (unsigned)row * q_slb + (chunk << 4) : 0x80000000u;   // (past the true head dim: zeros)
+        g_vo[j] = chunk < dchunks ? (unsigned)row * g_slb + (chunk << 4) : 0x80000000u;
         dst[j] = (pc >> 2) * 4096 + (pc & 3) * 1024;
     }
-    const unsigned q_bytes = ((unsigned)(L - 1) * (unsigned)p.q_sl + D) * 2;
-    const unsigned g_bytes = ((unsigned)(L - 1) * (unsigned)p.do_sl + D) * 2;
+    const unsigned q_bytes = ((unsigned)(L - 1) * (unsigned)p.q_sl + (unsigned)p.Dr) * 2;
+    const unsigned g_bytes = ((unsigned)(L - 1) * (unsigned)p.do_sl + (unsigned)p.Dr) * 2;
     // item J_ of the stream = query tile i0 + J_ % n_sweep of query head hq0 + J_ / n_sweep
 #define FA_ITEM(J_, HQ_, I_)                                                                       \
         const int HQ_ = p.kv_div == 1 ? 0 : (J_) / n_sweep;                                        \
@@ -763,8 +777,10 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 wk[j] = (T)(dk[dt][4 * rg + j] * p.scale);
                 wv[j] = (T)dv[dt][4 * rg + j];
             }
-            *(vec4*)(dkg + 32 * dt + 8 * rg + 4 * h) = wk;
-            *(vec4*)(dvg + 32 * dt + 8 * rg + 4 * h) = wv;
+            if (4 * dt + rg < dchunks) {
+                *(vec4*)(dkg + 32 * dt + 8 * rg + 4 * h) = wk;
+                *(vec4*)(dvg + 32 * dt + 8 * rg + 4 * h) = wv;
+            }
         }
     }
 }

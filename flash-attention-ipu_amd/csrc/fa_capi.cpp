@@ -100,6 +100,15 @@ const Options& options() {
 // wave at head_dim 64, 8 waves at head_dim 128).
 int waves_for_chunk(int64_t want) { return want >= 128 ? 4 : want >= 64 ? 2 : 1; }
 
+// Head dims the MFMA kernels serve: 64 and 128 natively; for 16-bit operands every other multiple of 8 below 128 runs ZERO-EXTENDED at the
+// next of the two (FwdParams::Dr: out-of-range LDS-DMA chunks and predicated register loads read the missing columns as zeros, stores
+// stop at the true head dim) - the reference's op has no head-dim restriction (FA.cpp:175-195).  Returns 0 when there is no such kernel.
+int64_t kernel_head_dim(int64_t D, int32_t dtype) {
+    if (D == 64 || D == 128) return D;
+    if ((dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D < 128 && D % 8 == 0) return D < 64 ? 64 : 128;
+    return 0;
+}
+
 bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* const strides[4]) {
     if (!(D == 64 || D == 128)) return false;
     for (int i = 0; i < 4; ++i) {
@@ -178,6 +187,7 @@ struct Request {
     float scale;
     int es, skip, wmax;            // element size; 1 = skip-max arithmetic; waves the q chunk allows
     bool pipe_ok, want32;          // the pipelined kernels implement skip-max only; a kv chunk below 64 keys wants 32-key steps
+    bool d_only;                   // the operands' true head dim is below the kernel's (zero-extended call): fa_fwd_dma_kernel only
 };
 struct Choice {
     char which;                    // 'd' | 'p' | 'x' | 'P' | 'h' | 't'
@@ -252,6 +262,7 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
     char& which = c->which;
     int &waves = c->waves, &qb = c->qb, &split = c->split;
     if (!FA_EXPERIMENTAL && (which == 't' || which == 'P')) which = 'd';      // (not in this build: make EXPERIMENTAL=1)
+    if (r.d_only && which != 'd') { which = 'd'; qb = 1; split = 1; if (waves > 4) waves = 4; }   // (only the 64-key-tile LDS-DMA kernel reads a narrower head dim)
     if (r.want32 && r.pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
     const bool w8_ = FA_EXPERIMENTAL && which == 'p' && D == 64 && waves == 8 && qb == 2 && r.causal && r.pipe_ok;   // (512-row workgroups: forced only)
     if (which == 'p' && ((waves > 4 && D != 128 && !w8_) || !r.pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
@@ -350,7 +361,7 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
 }
 
 int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int32_t nk, float scale, int32_t causal,
-                bool mfma16_ok, bool f32_ok, Selection* sel) {
+                bool mfma16_ok, bool f32_ok, bool d_only, Selection* sel) {
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1 (got %lld, %lld, %lld)", (long long)G, (long long)L, (long long)D);
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     if (nq < 1 || L % nq != 0) return fail(FA_ERR_CHUNKS_Q, "sequence length %lld is not divisible by num_chunks_q=%d", (long long)L, nq);
@@ -379,7 +390,8 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         r.ck = plan->chunk_kv < L ? plan->chunk_kv : L;
         r.wmax = waves_for_chunk(r.cq);            // the q chunk bounds the workgroup's rows
         r.pipe_ok = r.skip != 0;                   // (the pipelined kernels implement the skip-max arithmetic only)
-        r.want32 = r.ck < 64;                      // a kv chunk below 64 keys is served by 32-key steps
+        r.want32 = r.ck < 64 && !d_only;           // a kv chunk below 64 keys is served by 32-key steps
+        r.d_only = d_only;
         Choice c = rules_choice(r);
         if (opt.table) table_choice(r, &c);
         apply_overrides(r, opt, &c);
@@ -525,11 +537,12 @@ int fa_infer_output_shape(const int64_t* qkv_shape, int32_t rank, int64_t out_sh
 int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q, int32_t num_chunks_kv,
             float softmax_scale, int32_t causal, fa_plan_t* plan) {
     if (!plan) return fail(FA_ERR_NULL_POINTER, "null plan pointer");
-    const bool d_ok = D == 64 || D == 128;
+    const int64_t Dk = (dtype >= 0 && dtype <= 2 && D >= 1) ? kernel_head_dim(D, dtype) : 0;   // the head dim the MFMA kernels would run this call at
+    const bool d_ok = Dk != 0;
     Selection sel;
-    const int rc = select_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal,
+    const int rc = select_plan(G, L, d_ok ? Dk : D, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal,
                                d_ok && (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16),
-                               d_ok && dtype == FA_DTYPE_F32 && !options().f32_generic, &sel);
+                               d_ok && dtype == FA_DTYPE_F32 && !options().f32_generic, d_ok && Dk != D, &sel);
     if (rc == FA_OK) *plan = sel.plan;
     return rc;
 }
@@ -598,14 +611,16 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     if (k_strides[2] > (1ll << 32) || v_strides[2] > (1ll << 32)) wide_rows = true;
 
     // the MFMA kernels need 16-byte rows and address K/V rows with 32-bit element offsets from the group base
-    const bool wide_ok = !wide_rows && aligned16(D, elt_size(dtype), ptrs, strides) && L * k_strides[2] < (1ll << 31) && L * v_strides[2] < (1ll << 31);
+    const int64_t Dk0 = kernel_head_dim(D, dtype);
+    const bool wide_ok = !wide_rows && Dk0 != 0 && aligned16(Dk0, elt_size(dtype), ptrs, strides) && L * k_strides[2] < (1ll << 31) && L * v_strides[2] < (1ll << 31);
+    const int64_t Dk = wide_ok ? Dk0 : D;          // the head dim the launched kernel runs at (D itself on the generic path)
     const bool mfma16_ok = wide_ok && (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16);
     const bool f32_ok = wide_ok && dtype == FA_DTYPE_F32 && !options().f32_generic;
     // mask / dropout: the MFMA mask kernel (fa_fwd_extra.hip) for 16-bit operands it takes, the generic kernel for everything else
     // fa_fwd serves (fp32, other head dims, unaligned rows) - never the fp32 MFMA kernel, which has no mask path
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     Selection sel;
-    const int rc = select_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal, mfma16_ok, f32_ok && !extra, &sel);
+    const int rc = select_plan(G, L, Dk, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal, mfma16_ok, f32_ok && !extra, Dk != D, &sel);
     if (rc != FA_OK) return rc;
     const fa_plan_t& plan = sel.plan;
     const bool extra_mfma = extra && mfma16_ok;
@@ -623,7 +638,8 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     p.H = (int32_t)heads;
     p.kv_div = (int32_t)(heads / heads_kv);
     p.L = (int32_t)L;
-    p.D = (int32_t)D;
+    p.D = (int32_t)Dk;
+    p.Dr = (int32_t)D;
     p.causal = causal;
     p.nq_tiles = plan.kernel != 1 ? (int32_t)((L + plan.block_q - 1) / plan.block_q) : 0;
     if (extra_mfma) p.nq_tiles = (int32_t)((L + 127) / 128);     // fa_fwd_extra_kernel: 4 waves x 32 rows, exact-max arithmetic
@@ -738,7 +754,8 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
     const void* const ptrs[8] = {q, k, v, out, dout, dq, dk, dv};
     // MFMA kernels: head_dim 64/128, 16-byte aligned rows - 16-bit dtypes (fa_bwd_kernels.hip) and fp32
     // (fa_bwd_f32.hip, v_mfma_f32_32x32x2_f32); everything else -> generic kernels
-    bool mfma = (D == 64 || D == 128) && !(dtype == FA_DTYPE_F32 && options().f32_generic);
+    const int64_t Dk0 = kernel_head_dim(D, dtype);
+    bool mfma = Dk0 != 0 && !(dtype == FA_DTYPE_F32 && options().f32_generic);
     const int64_t row_align = 16 / elt_size(dtype);
     for (int i = 0; i < 8; ++i) {
         if (reinterpret_cast<uintptr_t>(ptrs[i]) % elt_size(dtype)) return fail(FA_ERR_MISALIGNED, "fa_bwd: tensor %d is not element aligned", i);
@@ -766,7 +783,9 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
     p.dq_sb = strides[5][0]; p.dq_sh = strides[5][1]; p.dq_sl = strides[5][2];
     p.dk_sb = strides[6][0]; p.dk_sh = strides[6][1]; p.dk_sl = strides[6][2];
     p.dv_sb = strides[7][0]; p.dv_sh = strides[7][1]; p.dv_sl = strides[7][2];
-    p.G = (int32_t)G; p.G8 = (int32_t)((G + 7) / 8 * 8); p.H = (int32_t)heads; p.L = (int32_t)L; p.D = (int32_t)D;
+    p.G = (int32_t)G; p.G8 = (int32_t)((G + 7) / 8 * 8); p.H = (int32_t)heads; p.L = (int32_t)L;
+    p.D = (int32_t)(mfma ? Dk0 : D);      // the head dim the kernels run at; the operands' own is Dr (zero-extended 16-bit calls)
+    p.Dr = (int32_t)D;
     p.Hkv = (int32_t)heads_kv; p.kv_div = (int32_t)(heads / heads_kv);
     p.Gkv = (int32_t)(G / p.kv_div); p.G8kv = (int32_t)((p.Gkv + 7) / 8 * 8);
     p.causal = causal;

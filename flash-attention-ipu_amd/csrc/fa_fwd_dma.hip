@@ -128,13 +128,21 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     bool mpre_ok = false;
     (void)mraw; (void)mpre_ok;
 
+    // the operands' true head dim in 16-byte chunks (= D / 8 unless the call runs zero-extended: FwdParams::Dr)
+    const int dchunks = p.Dr >> 3;
     // Q^T fragments of q tile QI_ (B operands of S^T = K Q^T): block b of this wave owns row QI_ * BQ + wave * WQ + 32 b + r
     vec8 qf[QB][KS];
 #define FA_LOAD_Q(QI_)                                                                             \
     _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
         const int qr0_ = (QI_) * BQ + wave * WQ + r + 32 * b;                                      \
-        const T* qp = qg + (int64_t)(qr0_ < L ? qr0_ : L - 1) * p.q_sl + 8 * h;                    \
-        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) qf[b][ks] = *(const vec8*)(qp + 16 * ks); \
+        const T* qp = qg + (int64_t)(qr0_ < L ? qr0_ : L - 1) * p.q_sl;                            \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                        \
+            const int ch_ = 2 * ks + h;            /* 16-byte chunk of the row: columns 8 ch_ ..+7 */ \
+            const vec8 ld_ = *(const vec8*)(qp + 8 * (ch_ < dchunks ? ch_ : 0));                   \
+            vec8 z_;                                                                               \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) z_[j] = (T)0.f;                          \
+            qf[b][ks] = ch_ < dchunks ? ld_ : z_;  /* (columns past the true head dim: zeros) */   \
+        }                                                                                          \
     }
     FA_LOAD_Q(nq - 1 - qd)
 
@@ -149,16 +157,17 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         const int row = pc * (1024 / ROWB) + lane / (ROWB / 16);
         const int cp = lane % (ROWB / 16);
         const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
-        k_vo[j] = (unsigned)row * k_slb + ((cp ^ sw) << 4);
+        // (a chunk past the true head dim: an offset beyond any descriptor's extent - the DMA writes zeros for it, as for rows past L)
+        k_vo[j] = (cp ^ sw) < dchunks ? (unsigned)row * k_slb + ((cp ^ sw) << 4) : 0x80000000u;
         k_dst[j] = pc * 1024;
         // V: piece = two 8-key blocks of one 32-column d-block
         const int dblk = pc >> 2, q2 = pc & 3;
         const int key = (2 * q2 + (lane >> 5)) * 8 + ((lane >> 2) & 7);
-        v_vo[j] = (unsigned)key * v_slb + ((dblk * 4 + (lane & 3)) << 4);
+        v_vo[j] = (dblk * 4 + (lane & 3)) < dchunks ? (unsigned)key * v_slb + ((dblk * 4 + (lane & 3)) << 4) : 0x80000000u;
         v_dst[j] = dblk * VBLK_B + q2 * 1024;
     }
-    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;   // extent of this group's K
-    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
+    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + (unsigned)p.Dr) * 2;   // extent of this group's K
+    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + (unsigned)p.Dr) * 2;
 
     // tile T_ -> buffer BUF_: descriptors start at the tile's first row; rows past L read as zeros
 #define FA_DMA_TILE(T_, BUF_)                                                                      \
@@ -547,7 +556,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             const int rr = i * RPI + lane / CPR, ch = lane % CPR;
             const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
             const int orow = q_row0 + 32 * b + rr;
-            if (orow < L && (FA_DMA_ABL != 6 || val.x == 0x12345u)) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
+            if (orow < L && ch < dchunks && (FA_DMA_ABL != 6 || val.x == 0x12345u)) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
         }
     }
     }   // wave_active

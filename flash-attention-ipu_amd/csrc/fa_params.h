@@ -37,7 +37,9 @@ struct FwdParams {
     int32_t kv_div;        // query heads per key/value head (1 = multi-head attention): K/V head = head / kv_div
     int32_t causal;        // 1 causal mask, 0 none
     int32_t L;
-    int32_t D;
+    int32_t D;             // head dim the kernel runs at (64 | 128 for the MFMA kernels)
+    int32_t Dr;            // the operands' true head dim (<= D, a multiple of 8): fa_fwd_dma_kernel reads the columns Dr .. D - 1 as zeros
+                           // (out-of-range LDS-DMA chunks, predicated Q loads) and stores Dr columns - rows are Dr elements wide in memory
     int32_t nq_tiles;      // q tiles per group
     int32_t sched;         // groups per XCD bunch (>= 1): heavy-first order inside a bunch
     int32_t skipmax;       // f16 only: 1 = reference max from the first tile + overflow-triggered redo
@@ -60,6 +62,7 @@ struct BwdParams {
     int64_t q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl, do_sb, do_sh, do_sl;
     int64_t dq_sb, dq_sh, dq_sl, dk_sb, dk_sh, dk_sl, dv_sb, dv_sh, dv_sl;
     int32_t G, G8, H, L, D;
+    int32_t Dr;            // true head dim (<= D, multiple of 8), as FwdParams::Dr
     int32_t Hkv, kv_div;   // K/V heads per batch entry, query heads per K/V head (grouped-query attention: H = Hkv * kv_div)
     int32_t Gkv, G8kv;     // K/V groups (G / kv_div) and that count rounded up to a multiple of 8: the dK/dV grid
     int32_t causal;        // 1 causal mask, 0 none

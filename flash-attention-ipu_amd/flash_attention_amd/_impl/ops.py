@@ -362,9 +362,9 @@ def attention_bhld(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=T
 # logits; no gradient flows to it); dropout decisions are a pure function of (seed, offset, group, row, key), so the backward
 # regenerates them from the two integers saved here.
 def supports_extra(q: torch.Tensor) -> bool:
-    """What the mask / dropout kernels take: f16 / bf16, head_dim 64 or 128, 16-byte aligned rows (the override lets stock SDPA
-    serve everything else)."""
-    return q.dtype in (torch.float16, torch.bfloat16) and q.shape[-1] in (64, 128)
+    """What the mask / dropout MFMA kernels take: f16 / bf16, head_dim a multiple of 8 up to 128 (zero-extended at 64 / 128 inside the
+    kernels), 16-byte aligned rows (the override lets stock SDPA serve everything else)."""
+    return q.dtype in (torch.float16, torch.bfloat16) and q.shape[-1] % 8 == 0 and 8 <= q.shape[-1] <= 128
 
 
 def _fwd_ex_impl(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state):

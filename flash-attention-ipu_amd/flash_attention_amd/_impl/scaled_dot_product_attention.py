@@ -32,21 +32,28 @@ def chunk_heuristic(L: int, D: int):
 
 
 # Head dims other than 64 / 128.  The reference's op has no head-dim restriction (FA.cpp:175-195; its own tests run D = 2,
-# t_cpp:245-251) and the C ABI serves every D <= 1024 - but only D in {64, 128} through the MFMA kernels; anything else runs the
-# generic kernel (one workgroup per query row, scalar fp32 arithmetic: a correctness path), which an
-# `import flash_attention_amd.auto` must not silently put under a D = 96 model.  So for calls of at least this many query rows:
-#   D < 128: the operands are zero-padded along D to the next MFMA head dim (zero columns change neither Q K^T nor the first D
-#            columns of P V; the scale stays D^-1/2 of the TRUE head dim) and the result is sliced - forward and backward run the
-#            MFMA kernels, autograd sees pad / slice (three extra copies of q, k, v: ~25 % of the attention time at L = 2048, D = 96,
-#            still well ahead of stock SDPA: tests/test_gpu_head_dims.py asserts it);
-#   D > 128: stock SDPA (`orig_fn`) serves the call.
+# t_cpp:245-251).  The C ABI serves
+#   * f16 / bf16 with D a multiple of 8 below 128 through the MFMA kernels themselves, ZERO-EXTENDED at the next MFMA head dim inside the
+#     kernels (round 4, `FwdParams::Dr`: out-of-range LDS-DMA chunks and predicated register loads read the missing columns as zeros,
+#     stores stop at D - no copies, forward and backward, masks and dropout included);
+#   * everything else (D > 128, D not a multiple of 8, fp32 off 64 / 128) through the generic kernel: one workgroup per query row, scalar
+#     fp32 arithmetic, 1-2 TFLOP/s - a correctness path that an `import flash_attention_amd.auto` must not silently put
+#     under a model.  For calls of at least GENERIC_KERNEL_MAX_ROWS query rows the override therefore pads D < 128 to the next head dim the
+#     MFMA kernels take (zero columns change neither Q K^T nor the first D columns of P V; the scale stays D^-1/2 of the TRUE head dim;
+#     autograd sees pad / slice) and hands D > 128 to stock SDPA (`orig_fn`).
 # Smaller calls (the reference's own tiny test shapes) stay on the generic kernel: exact fp32 arithmetic, no copies.
 GENERIC_KERNEL_MAX_ROWS = 4096
 
 
-def _mfma_head_dim(D: int):
-    """the head dim the MFMA kernels would run a D-wide call at (None: no such kernel)"""
-    return D if D in (64, 128) else 64 if D < 64 else 128 if D < 128 else None
+def _mfma_head_dim(D: int, dtype):
+    """(served natively?, head dim to pad to or None): what the MFMA kernels make of a D-wide call"""
+    if D in (64, 128) or (dtype in (torch.float16, torch.bfloat16) and D < 128 and D % 8 == 0):
+        return True, D
+    if D > 128:
+        return False, None
+    if dtype in (torch.float16, torch.bfloat16):
+        return False, (D + 7) // 8 * 8            # the next multiple of 8: the kernels zero-extend from there
+    return False, 64 if D < 64 else 128           # fp32: the fp32 MFMA kernels take 64 and 128 only
 
 
 def _gqa_ok(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor) -> bool:
@@ -151,8 +158,8 @@ def _scaled_dot_product_attention_amd(
     if on_device and scale is not None and not (scale > 0.0 and scale < float("inf")):
         on_device = False
     D_true = query.shape[-1]
-    if on_device and D_true not in (64, 128) and query.numel() > 0 and query.numel() // D_true >= GENERIC_KERNEL_MAX_ROWS:
-        Dp = _mfma_head_dim(D_true)
+    native_ok, Dp = _mfma_head_dim(D_true, query.dtype) if on_device else (True, None)
+    if on_device and not native_ok and query.numel() > 0 and query.numel() // D_true >= GENERIC_KERNEL_MAX_ROWS:
         if Dp is None or torch.compiler.is_compiling():
             on_device = False       # (no MFMA kernel for this head dim: stock SDPA, not the scalar generic kernel)
         else:

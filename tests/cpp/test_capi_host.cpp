@@ -82,26 +82,28 @@ int main() {
                                         fa_plan_t pl;
                                         if (fa_plan(G, L, D, dt, nc, nc == 8 ? 4 : nc, scale, causal, &pl) != FA_OK) { EXPECT(L % (nc == 8 ? 4 : nc) != 0); continue; }
                                         ++checked;
-                                        const bool mfma16 = (D == 64 || D == 128) && dt != FA_DTYPE_F32;
+                                        const bool mfma16 = (D == 64 || D == 128 || D == 96) && dt != FA_DTYPE_F32;    // (96: zero-extended at 128 by the 64-key-tile kernel)
+                                        const int64_t Dk = D == 96 ? 128 : D;
                                         const int64_t chunk = L / nc;
                                         EXPECT(pl.grid >= 1 && pl.grid <= 0x7fffffffll && pl.waves >= 1 && pl.sched >= 1 && pl.block_q >= 1 && pl.block_kv >= 1);
                                         EXPECT(pl.lds_bytes > 0 && pl.lds_bytes <= 160 * 1024);                  // one workgroup must fit a CU's LDS
                                         EXPECT(pl.chunk_q == chunk);
                                         if (!mfma16) { EXPECT(pl.kernel == 1 || pl.kernel == 3); continue; }
+                                        if (D == 96) EXPECT(pl.kernel == 0 && pl.qb == 1);                          // only fa_fwd_dma_kernel reads a narrower head dim
                                         EXPECT(pl.kernel == 0 || pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 6);   // nothing experimental in this build
                                         EXPECT(pl.qb == 1 || pl.qb == 2);
                                         EXPECT(pl.waves == 1 || pl.waves == 2 || pl.waves == 4 || pl.waves == 8 || pl.waves == 16);
                                         EXPECT(pl.waves <= 16 && 64 * pl.waves <= 1024);                            // a workgroup is at most 1024 threads
                                         EXPECT(pl.skipmax == (dt == FA_DTYPE_BF16 || pl.skipmax));                  // bf16 always runs the skip-max arithmetic
                                         if (pl.kernel == 2 || pl.kernel == 4) EXPECT(pl.skipmax == 1 && pl.block_kv == 32);
-                                        if (pl.kernel == 6) { EXPECT(pl.block_q == 64 && pl.qb == 1 && (pl.waves == 4 || pl.waves == 8 || (pl.waves == 16 && D == 64))); }
+                                        if (pl.kernel == 6) { EXPECT(pl.block_q == 64 && pl.qb == 1 && (pl.waves == 4 || pl.waves == 8 || (pl.waves == 16 && Dk == 64))); }
                                         else {
                                             const int64_t rows = 32ll * pl.waves * pl.qb;
                                             EXPECT(rows % pl.block_q == 0);
                                             const int64_t split = rows / pl.block_q;
-                                            EXPECT(split == 1 || ((split == 2 || (split == 4 && D == 64)) && pl.kernel == 0 && pl.qb == 1));
+                                            EXPECT(split == 1 || ((split == 2 || (split == 4 && Dk == 64)) && pl.kernel == 0 && pl.qb == 1));
                                         }
-                                        if (pl.qb == 2) EXPECT(D == 64 && (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 0) && pl.block_q == 256);
+                                        if (pl.qb == 2) EXPECT(Dk == 64 && (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 0) && pl.block_q == 256);
                                         // an unforced plan honours the q chunk as an upper bound on the workgroup's rows
                                         if (ov.empty()) EXPECT(pl.block_q <= (chunk > 32 ? chunk : 32) || pl.kernel == 6);
                                         // the grid covers every (group, q tile): 8-aligned groups x tiles (pairs: two tiles per workgroup)
@@ -192,7 +194,8 @@ int main() {
         EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 0.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_SCALE);
         // operands the MFMA mask kernels do not take go to the generic kernels (never to the fp32 MFMA kernel, which has no mask path)
         EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 64, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_F32, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.5f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'g');
-        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 80, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'g');
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 80, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'E');   // head_dim 80: zero-extended at 128 by the MFMA mask kernel
+        EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 84, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'g');   // not a multiple of 8: generic
         EXPECT(fa_fwd_ex(p, p, p, p, nullptr, 1, 128, 2048, 1, 1, st, st, st, st, 1, 1, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BOOL, ms, 0.0f, 0, 0, nullptr, nullptr) == FA_ERR_BAD_SHAPE);   // (head_dim > 1024: as fa_fwd)
         EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, p, FA_MASK_BIAS, ms, 0.1f, 3, 4, nullptr, nullptr) == FA_OK && g_stub_last == 'e');
         EXPECT(fa_bwd_ex(p, p, p, p, p, fbuf, p, p, p, fbuf, 1, 128, 64, 1, 1, st8, FA_DTYPE_BF16, 1.0f, 1, nullptr, FA_MASK_NONE, nullptr, 0.0f, 0, 0, nullptr, nullptr) == FA_OK && g_stub_last == 'B');

@@ -220,7 +220,10 @@ def _check_builtin_rules(native):
     assert native.plan(4, 6, 2, torch.float32, 3, 3).kernel == 1             # generic kernel
     assert native.plan(4, 256, 64, torch.float32, 1, 1).kernel == 3             # fp32 MFMA kernel (D 64 / 128)
     assert native.plan(4, 256, 80, torch.float32, 1, 1).kernel == 1
-    assert native.plan(4, 256, 96, torch.bfloat16, 1, 1).kernel == 1
+    p96 = native.plan(4, 256, 96, torch.bfloat16, 1, 1)      # 16-bit, a multiple of 8 below 128: zero-extended at 128 by the 64-key-tile MFMA kernel
+    assert (p96.kernel, p96.block_kv, p96.qb) == (0, 64, 1)
+    assert native.plan(4, 256, 100, torch.bfloat16, 1, 1).kernel == 1      # not a multiple of 8: generic
+    assert native.plan(4, 256, 256, torch.bfloat16, 1, 1).kernel == 1
 
 
 def test_value_errors_match_reference_text(fa, meta):
