@@ -55,34 +55,48 @@ template <> struct Elt<_Float16> {
 //   compiler-scheduled steps call FA_MFMA_SETTLE() between the product and its first reader;
 //   P / K / V^T operands: LDS waits are the compiler's own (its s_waitcnt bookkeeping tracks registers, asm operands included);
 //   a VALU-written operand (hipcc is free to put a register copy right in front of the statement: it does, in the ragged steps)
-//   needs two wait states before an MFMA reads it, so every statement opens with `s_nop 1`.
+//   needs two wait states before an MFMA reads it, so every statement opens with `s_nop 1` - except (PAD = false) in the four steady
+//   steps of the loop, whose streams carry no copy and no VALU write to an operand of the MFMA behind it (8 issue cycles a gap
+//   matter to a wave that is alone on its SIMD): the audit below is what licenses that.
 // scripts/audit_asm_mfma.py checks the generated ISA for both directions after every build of such a kernel.
 #define FA_MFMA_SETTLE() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")   /* 8-pass XDL result -> any reader: 12+ states */
 template <typename T> struct MfmaAsm;
 template <> struct MfmaAsm<__bf16> {
     typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
     // acc (AGPR) += a (VGPR) x b (VGPR)
+    template <bool PAD = true>
     static __device__ __forceinline__ void acc_a(float __attribute__((ext_vector_type(16)))& acc, vec8 a, vec8 b) {
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     }
     // d (VGPR) = a (VGPR) x b (AGPR) + c (VGPR)
+    template <bool PAD = true>
     static __device__ __forceinline__ void bq(float __attribute__((ext_vector_type(16)))& d, vec8 a, vec8 b_acc) {
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
+        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
     }
+    template <bool PAD = true>
     static __device__ __forceinline__ void bq0(float __attribute__((ext_vector_type(16)))& d, vec8 a, vec8 b_acc) {
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
+        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
     }
 };
 template <> struct MfmaAsm<_Float16> {
     typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
+    template <bool PAD = true>
     static __device__ __forceinline__ void acc_a(float __attribute__((ext_vector_type(16)))& acc, vec8 a, vec8 b) {
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     }
+    template <bool PAD = true>
     static __device__ __forceinline__ void bq(float __attribute__((ext_vector_type(16)))& d, vec8 a, vec8 b_acc) {
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
+        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
     }
+    template <bool PAD = true>
     static __device__ __forceinline__ void bq0(float __attribute__((ext_vector_type(16)))& d, vec8 a, vec8 b_acc) {
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
+        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
     }
 };
 

@@ -50,6 +50,9 @@
 #define FA_PIPE_ABL 0
 #endif
 // 1: the row sums of P in the hand-scheduled steps run on the matrix pipe (fa_device.h, rowsum_selector)
+#ifndef FA_PIPE_AG_VSUM
+#define FA_PIPE_AG_VSUM 0   /* measured: 1 246 vs 1 286 TFLOP/s at cfg3 - the matrix-pipe sums stay */
+#endif
 #ifndef FA_PIPE_MFMASUM
 #define FA_PIPE_MFMASUM 1
 #endif
@@ -74,7 +77,8 @@
 #elif FA_PIPE_BARE_BARRIER
 #define FA_PIPE_BARRIER() asm volatile("s_barrier" ::: "memory")
 #else
-#define FA_PIPE_BARRIER() __syncthreads()
+// (AG - one wave per SIMD - takes the bare barrier: nobody else issues while this wave drains the next step's V^T fragment reads)
+#define FA_PIPE_BARRIER() { if constexpr (AG) asm volatile("s_barrier" ::: "memory"); else __syncthreads(); }
 #endif
 
 namespace fa {
@@ -106,6 +110,9 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     static_assert(!MIRROR || (QB == 2 && CAUSAL && FA_PIPE_PVFIRST), "mirrored row blocks: causal, two blocks per wave, PV-first steps");
     using E = Elt<T>;
     using MA = MfmaAsm<T>;
+    // row sums of the hand-ordered steps on the matrix pipe (fa_device.h rowsum_selector) - except AG (FA_PIPE_AG_VSUM): a lone wave's stream is
+    // bound by the matrix pipe, its vector issue has slack, so there the 32 v_add per step are cheaper than 4 row-sum MFMAs (64 matrix cycles)
+    constexpr bool MSUM = FA_PIPE_MFMASUM && !(AG && FA_PIPE_AG_VSUM);
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
     constexpr int WQ = 32 * QB;                 // query rows per wave
@@ -220,6 +227,11 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;
     const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
     const unsigned smem_lds = lds_offset(smem);
+    // one descriptor per operand for the whole workgroup (AG: the steady steps issue their LDS-DMA pieces inside MFMA gaps, a step's
+    // rows reached through the lane offset - no per-step descriptor arithmetic in a stream that has its SIMD to itself)
+    const i32x4 krw_ = make_raw_rsrc((const char*)kg, k_bytes);
+    const i32x4 vrw_ = make_raw_rsrc((const char*)vg, v_bytes);
+    (void)krw_; (void)vrw_;
 
 #ifndef FA_PIPE_LEAN
 #define FA_PIPE_LEAN 0   /* 1: ~35 fewer scalar instructions per step - one buffer descriptor per operand for the whole workgroup (a step's
@@ -459,13 +471,13 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         {                                                                                          \
             constexpr int b_ = (V_) / 8, p_ = (V_) % 8, e_ = 2 * p_;                               \
             if constexpr (!FA_ITEM_DEAD(MASK_, b_)) {                                              \
-                if constexpr (!FA_PIPE_MFMASUM) {                                                  \
+                if constexpr (!MSUM) {                                                             \
                     ls[b_] += SC_[b_][e_];                                                         \
                     ls[b_] += SC_[b_][e_ + 1];                                                     \
                 }                                                                                  \
                 PC_[b_][p_ >> 2][2 * (p_ & 3)] = (T)SC_[b_][e_];                                   \
                 PC_[b_][p_ >> 2][2 * (p_ & 3) + 1] = (T)SC_[b_][e_ + 1];                           \
-                if constexpr (FA_PIPE_MFMASUM && (p_ & 3) == 3)   /* a B fragment of P is complete */ \
+                if constexpr (MSUM && (p_ & 3) == 3)   /* a B fragment of P is complete */            \
                     lsum[b_] = E::mfma16(asel, PC_[b_][p_ >> 2], lsum[b_]);                        \
             } else {                                                                               \
                 PC_[b_][p_ >> 2][2 * (p_ & 3)] = (T)0.f;                                           \
@@ -485,13 +497,32 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #define FA_ISSUE_FAST(I_, KSLOT_, VSLOT_) FA_ISSUE(I_, KSLOT_, VSLOT_)
 #define FA_PUBLISH_FAST() FA_PUBLISH()
 #endif
+#define FA_ISSUE_FASTX(I_, KSLOT_, VSLOT_, DMAG_)                                                  \
+        bool dk_ = true, dv_ = true;                                                               \
+        if constexpr (!(DMAG_)) {                                                                  \
+            dk_ = (I_) + NS - 1 < nh_wg; dv_ = (I_) + NS - 2 < nh_wg;                              \
+            if (dk_ && FA_PIPE_ABL != 2) FA_DMA_K((I_) + NS - 1, KSLOT_)                           \
+            if (dv_ && FA_PIPE_ABL != 2) FA_DMA_V((I_) + NS - 2, VSLOT_)                           \
+        }
+// piece PI_ (0 .. 2 PPW - 1: K pieces first) of the step's DMA, issued from inside an MFMA gap
+#define FA_DMA_PIECE(I_, KSLOT_, VSLOT_, PI_)                                                      \
+        if constexpr ((PI_) < PPW) {                                                               \
+            lds_dma_b128_m0(krw_, smem_lds + (KSLOT_) * KH_B + k_dst[(PI_)], k_vo[(PI_)] + (unsigned)((I_) + NS - 1) * HK * k_slb); \
+        } else {                                                                                   \
+            lds_dma_b128_m0(vrw_, smem_lds + NS * KH_B + (VSLOT_) * VH_B + v_dst[(PI_) - PPW], v_vo[(PI_) - PPW] + (unsigned)((I_) + NS - 2) * HK * v_slb); \
+        }
 // PV0_ / QK0_ (MIRROR's one-block steps): whether block 0's PV / QK^T MFMAs are issued at all - a dead block needs neither, except
 // the PV of its diagonal step's P in the step right after that diagonal.  The vector items of the live block(s) are spread
 // over the MFMAs that ARE issued.
-#define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_) FA_FASTX(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_, true, true)
-#define FA_FASTX(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_, PV0_, QK0_)                \
+// STEADY_ (the four steps of the loop): AG only - the asm MFMAs drop their leading `s_nop 1` (fa_device.h) and the step's LDS-DMA pieces
+// are issued inside MFMA gaps instead of in front of the first MFMA (unconditionally: a steady step is at least NS steps from the
+// workgroup's last, so K(i + NS - 1) and V(i + NS - 2) always exist).
+#define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_) FA_FASTX(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_, true, true, false)
+#define FA_FASTX(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_, PV0_, QK0_, STEADY_)       \
     {                                                                                              \
-        FA_ISSUE_FAST(I_, KI_, VI_)                                                                \
+        constexpr bool DMAG_ = AG && (STEADY_) && FA_PIPE_ABL != 2;                                \
+        constexpr bool PAD_ = !(AG && (STEADY_));                                                  \
+        FA_ISSUE_FASTX(I_, KI_, VI_, DMAG_)                                                        \
         constexpr int NK = (QK_) ? KS : 0, NM = NK + 2 * DT, NMF = NM * QB, NV = 8 * QB;           \
         constexpr int VB = (QB == 2 && FA_ITEM_DEAD(MASK_, 0)) ? 8 : 0, NVL = NV - VB;             /* live vector items: VB .. NV - 1 */ \
         constexpr int NMFL = pipe_live_before(NMF, QB, 2 * DT, PV0_, QK0_);                        /* MFMAs issued */ \
@@ -523,8 +554,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             } else if constexpr (FA_OPND_IS_K(g_, NK)) {                                           \
                 constexpr int kx_ = FA_OPND_KIDX(g_, NK);                                          \
                 if constexpr (AG) {                                                                \
-                    if constexpr (kx_ == 0) MA::bq0(SN_[b_], opnd[g_], qf[b_][kx_ < KS ? kx_ : 0]); \
-                    else MA::bq(SN_[b_], opnd[g_], qf[b_][kx_ < KS ? kx_ : 0]);                    \
+                    if constexpr (kx_ == 0) MA::template bq0<PAD_>(SN_[b_], opnd[g_], qf[b_][kx_ < KS ? kx_ : 0]); \
+                    else MA::template bq<PAD_>(SN_[b_], opnd[g_], qf[b_][kx_ < KS ? kx_ : 0]);     \
                 } else if constexpr (kx_ == 0) {                                                   \
                     f32x16 z_;                                                                     \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) z_[e] = 0.f;                    \
@@ -534,9 +565,11 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 }                                                                                  \
             } else {                                                                               \
                 constexpr int t_ = FA_OPND_VIDX(g_, NK);                                           \
-                if constexpr (AG) MA::acc_a(o[b_][t_ % DT], opnd[g_], PP_[b_][t_ / DT]);           \
+                if constexpr (AG) MA::template acc_a<PAD_>(o[b_][t_ % DT], opnd[g_], PP_[b_][t_ / DT]); \
                 else o[b_][t_ % DT] = E::mfma(opnd[g_], PP_[b_][t_ / DT], o[b_][t_ % DT]);         \
             }                                                                                      \
+            /* (AG steady steps) the step's LDS-DMA pieces, one per gap behind the MFMAs 0, 2, 4, ... (the gaps that carry exp + cvt only) */ \
+            if constexpr (DMAG_ && (n_ % 2) == 0 && (n_ / 2) < 2 * PPW) { FA_DMA_PIECE(I_, KI_, VI_, n_ / 2) } \
             if constexpr (b_ == QB - 1 && g_ + PF_ < NM && g_ + PF_ >= NPRE) { FA_OPND_LOAD(g_ + PF_, NK) } \
             /* the NEXT step's V^T fragments, requested once this step's have been consumed */     \
             if constexpr (FA_PIPE_PVFIRST && (QK_) && b_ == QB - 1 && g_ >= NPRE && g_ < 2 * NPRE) { \
@@ -564,8 +597,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             __builtin_amdgcn_sched_barrier(0);                                                     \
         });                                                                                        \
         _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                           \
-            if constexpr (!FA_PIPE_MFMASUM) {                                                      \
-                bad |= !(ls[b] <= P_LIMIT);                                                        \
+            if constexpr (!MSUM) {                                                                 \
+                if constexpr (!AG) bad |= !(ls[b] <= P_LIMIT);   /* (AG: one check per pass on l, as for the matrix-pipe sums) */ \
                 l[b] += ls[b];                                                                     \
             }                                                                                      \
             /* pin this step's vector work to this step (hipcc otherwise sinks it below the       \
@@ -577,7 +610,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         FA_STEP_STAMP_B()                                                                          \
     }
 #define FA_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                      \
-    FA_FAST(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, 0, true)
+    FA_FASTX(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, 0, true, true, true, true)
     // The ragged steps and the generic steps after the groups of four use FIXED register roles (S(i) in sa,
     // S(i+1) -> sb, P(i-1) in pb, P(i) -> pa) and rotate by copying afterwards: one instantiation each instead of
     // one per parity (parity branches make hipcc shuffle the whole accumulator state through phi copies)
@@ -591,7 +624,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #define FA_RAGGED(I_, MASK_, QK_)                                                                  \
     FA_FAST(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, MASK_, QK_)
 #define FA_RAGGEDX(I_, MASK_, QK_, PV0_, QK0_)                                                     \
-    FA_FASTX(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, MASK_, QK_, PV0_, QK0_)
+    FA_FASTX(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, MASK_, QK_, PV0_, QK0_, false)
     // generic step (runtime ring slots, compiler's own schedule): the first step, the up to three steps left
     // over by the groups of four, the diagonal step, the drain step and the idle steps of a finished wave.
     // SAFE_ = the fallback pass: a step whose P outgrew the safe range is redone with an exact max.
@@ -719,6 +752,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         bad |= sum_left_safe_range(lsum[b][0]);
+        if constexpr (AG && !MSUM) bad |= sum_left_safe_range(l[b]);   // (vector-pipe sums of non-negative P: an overflowed P left them inf for good)
         // (FOLD: with the reference max at 0 a row whose logits are all far below 0 would underflow; a row owns its diagonal key at least)
         if constexpr (FOLD) bad |= wave_active && (half_swap_sum(l[b]) + lsum[b][0]) < 8.2718061e-25f;   /* 2^-80 */
     }
@@ -748,6 +782,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #undef FA_ISSUE
 #undef FA_PUBLISH
 #undef FA_ISSUE_FAST
+#undef FA_ISSUE_FASTX
+#undef FA_DMA_PIECE
 #undef FA_PUBLISH_FAST
 #undef FA_STEADY
 #undef FA_FAST

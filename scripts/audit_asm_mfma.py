@@ -78,7 +78,7 @@ def audit(path, want=""):
         if cur:
             blocks.append(cur)
         n_asm = 0
-        for blk in blocks:
+        for bi, blk in enumerate(blocks):
             n_mfma = sum(1 for op, _, _ in blk if op.startswith("v_mfma"))
             for op, ops, ia in blk:
                 if op.startswith("scratch_"):
@@ -104,26 +104,37 @@ def audit(path, want=""):
                         findings += 1
                     st += states(pop, pops)
                     j -= 1
-                # (2) result touched within the settle window
+                # (2) result touched within the settle window.  Time is counted in wait states since the MFMA's issue: one per instruction,
+                # N + 1 for `s_nop N`, and a following MFMA cannot issue before the matrix pipe has taken the previous one's passes
+                # (back-to-back MFMAs issue `passes` states apart).  The scan runs on into the blocks that follow in program order
+                # (fall-through; a loop's back edge re-enters a block already covered from its own start).
                 need = 12 if passes == 8 else 8
-                st, j = 0, i + 1
-                while j < len(blk) and st < need:
-                    nop, nops, _ = blk[j]
+                t, j = 0, i + 1
+                last_mfma_t, last_mfma_passes = 0, passes
+                stream = blk[i + 1:] + [x for nb in blocks[bi + 1:bi + 4] for x in nb]
+                for nop, nops, _ in stream:
+                    if t >= need:
+                        break
                     if nop.startswith(("v_mfma", "v_smfmac")):
-                        # legal: takes the result whole as C (accumulate chain) or does not touch it
-                        touched = set().union(*(regs(t) for t in nops[:4])) & dst
+                        t = max(t + 1, last_mfma_t + last_mfma_passes)
+                        last_mfma_t, last_mfma_passes = t, (8 if "32x32" in nop else 4)
+                        if t >= need:
+                            break
+                        touched = set().union(*(regs(x) for x in nops[:4])) & dst
                         whole_c = len(nops) >= 4 and regs(nops[3]) == dst and regs(nops[0]) == dst
-                        a_b = set().union(*(regs(t) for t in nops[1:3])) & dst
+                        a_b = set().union(*(regs(x) for x in nops[1:3])) & dst
                         if touched and (not whole_c or a_b):
-                            print(f"{name}: MFMA `{nop} {', '.join(nops)}` touches the result of asm `{op} {', '.join(ops)}` after {st} states")
+                            print(f"{name}: MFMA `{nop} {', '.join(nops)}` touches the result of asm `{op} {', '.join(ops)}` after {t} states")
                             findings += 1
-                    elif not nop.startswith("s_"):
-                        touched = set().union(*(regs(t) for t in nops)) & dst if nops else set()
+                        continue
+                    t += states(nop, nops)
+                    if t >= need:
+                        break
+                    if not nop.startswith("s_"):
+                        touched = set().union(*(regs(x) for x in nops)) & dst if nops else set()
                         if touched:
-                            print(f"{name}: `{nop} {', '.join(nops)}` touches the result of asm `{op} {', '.join(ops)}` after {st} states (need {need})")
+                            print(f"{name}: `{nop} {', '.join(nops)}` touches the result of asm `{op} {', '.join(ops)}` after {t} states (need {need})")
                             findings += 1
-                    st += states(nop, nops) + (passes - 1 if nop.startswith("v_mfma") else 0) * 0
-                    j += 1
         if n_asm:
             print(f"{name}: {n_asm} asm MFMAs audited")
     return findings
