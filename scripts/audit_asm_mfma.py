@@ -9,6 +9,8 @@ script checks, on the straight-line code of its basic block:
       12 wait states behind an 8-pass result (4-pass: 8) - instructions count one state each, `s_nop N` counts N + 1;
   (3) scratch accesses anywhere are findings; compiler v_accvgpr_* copies inside a block of >= 30 MFMAs are REPORTED per block
       (a ragged step may carry a few; the four steady steps of the loop must carry none - read the report).
+  (4) M0: the LDS-DMA statements of these kernels write M0 without restoring it (fa_device.h lds_dma_b128_m0) - legal only while nothing
+      else in the kernel reads M0, so any `s_movrel*` / `v_movrel*` / `s_set_gpr_idx*` / `s_sendmsg` / `ds_*_gs*` in it is a finding.
 usage:  python scripts/audit_asm_mfma.py flash-attention-ipu_amd/build/asm/fa_fwd_pipe-hip-amdgcn-amd-amdhsa-gfx950.s [kernel-name-substring]
 exit code 1 on a finding.  (`make -C flash-attention-ipu_amd asm SRC=fa_fwd_pipe` writes the .s)
 """
@@ -78,6 +80,11 @@ def audit(path, want=""):
         if cur:
             blocks.append(cur)
         n_asm = 0
+        for blk in blocks:
+            for op, ops, ia in blk:
+                if op.startswith(("s_movrel", "v_movrel", "s_set_gpr_idx", "s_sendmsg")) or "_gs_" in op:
+                    print(f"{name}: `{op} {', '.join(ops)}` reads M0, which the kernel's LDS-DMA statements clobber")
+                    findings += 1
         for bi, blk in enumerate(blocks):
             n_mfma = sum(1 for op, _, _ in blk if op.startswith("v_mfma"))
             for op, ops, ia in blk:

@@ -190,11 +190,15 @@ def test_sdpa_override_serves_attn_mask_and_dropout():
         qg = q.clone().requires_grad_(True)
         patched(qg, k, v, attn_mask=_masks("bool_padding", B, H, L, dtype, gen).cuda(), dropout_p=0.1).float().square().sum().backward()
         assert torch.isfinite(qg.grad).all() and qg.grad.abs().max() > 0
-        # not the kernels' business: fp32 operands, head_dim 80, a mask that wants a gradient -> stock SDPA (no raise)
+        # head_dim 80 IS the kernels' business since round 4 (a 16-bit multiple of 8 below 128 runs zero-extended inside the MFMA kernels)
+        n = len(calls)
+        q80 = torch.randn(1, 2, 64, 80, device="cuda", dtype=dtype)
+        assert torch.isfinite(patched(q80, q80, q80, dropout_p=0.1)).all() and len(calls) == n + 1
+        # not the kernels' business: fp32 operands, head_dim 84, a mask that wants a gradient -> stock SDPA (no raise)
         n = len(calls)
         patched(q.float(), k.float(), v.float(), attn_mask=_masks("bool_LL", B, H, L, dtype, gen).cuda())
-        q80 = torch.randn(1, 2, 64, 80, device="cuda", dtype=dtype)
-        patched(q80, q80, q80, dropout_p=0.1)
+        q84 = torch.randn(1, 2, 64, 84, device="cuda", dtype=dtype)
+        patched(q84, q84, q84, dropout_p=0.1)
         bias = torch.zeros(L, L, device="cuda", dtype=dtype, requires_grad=True)
         assert patched(q, k, v, attn_mask=bias).grad_fn is not None and len(calls) == n      # (stock SDPA's graph: it owns the bias gradient)
         # attn_mask together with is_causal is stock SDPA's business (its documentation promises an error; this build computes
