@@ -1,0 +1,38 @@
+"""The driver-visible line of bench.py (round-3 verdict, item 3): ONE JSON line that fits the 8 KB tail the driver keeps of stdout and carries
+every BASELINE config - in `secondary` (BASELINE configs last) and once more, shorter, in `roofline.other_configs`."""
+
+import json
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def test_default_bench_line_fits_the_drivers_tail_and_carries_every_baseline_config():
+    env = dict(os.environ)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "1", "--ramp-ms", "100", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    # (the cpu_baseline object this run skips adds ~650 bytes)
+    assert len(lines[0]) + 700 < 8000, f"{len(lines[0])} bytes: the driver keeps an 8 KB tail of stdout"
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["metric"] == "fwd_attention_tflops_causal_L4096_D64" and rec["n_gpus"] == 1 and rec["dtype"] == "bf16"
+    assert "cfg2: packed qkv [3,128,4096,64]" in rec["config"]["workload"]
+    roof = rec["roofline"]
+    assert roof["bound"] == "mfma" and roof["peak"] == 2500.0 and abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-3
+    others = roof["other_configs"]
+    for name in ("cfg3", "cfg5_shard", "cfg2_f16", "cfg4_attn", "cfg2_sdpa", "cfg2_bwd", "cfg4_gpt2_fwd", "small_grid", "l1024", "nb_65536"):
+        assert name in others and "error" not in others[name], (name, others.get(name))
+        assert name in rec["secondary"]
+    assert list(rec["secondary"])[-4:-2] == ["cfg5_shard", "cfg3"], "the BASELINE configs come last among the forward records"
+    assert others["cfg3"]["kernel"] == "fwd_pipe16" and others["cfg3"]["tflops"] > 0 and others["cfg2_f16"]["frac"] > 0
