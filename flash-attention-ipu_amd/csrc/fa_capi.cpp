@@ -241,7 +241,7 @@ void apply_overrides(const Request& r, const Options& opt, Choice* c) {
     if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
     if (fk == 't') { which = 't'; qb = 1; }
     else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
-    else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && D == 128) ? 8 : 4; if (!fq) qb = 1; }
+    else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && (D == 128 || FA_EXPERIMENTAL)) ? 8 : 4; if (!fq) qb = 1; }
     else if (fk == 'P' && pipe_ok && D == 64) { which = 'P'; waves = 4; qb = 2; }
     else if (fk == 'h') { which = 'h'; waves = 4; qb = 1; }
     else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128 || (FA_EXPERIMENTAL && D == 64 && waves == 8 && fq == 2))) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
@@ -270,7 +270,8 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
     if (which == 'P' && !(r.pipe_ok && D == 64)) which = 'd';
     if (which == 'P') { waves = 4; qb = 2; split = 1; }
     if (which == 'h') { waves = 4; qb = 1; if (!(split == 1 || split == 2 || (split == 4 && D == 64))) split = 1; }
-    if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
+    // (head_dim 64 with 8 waves = the experimental 16-row-wave form: 128-row workgroups, plan.qb 1, block_q set in finish_mfma_plan)
+    if (which == 'x') { waves = (waves == 8 && (D == 128 || (FA_EXPERIMENTAL && opt.kernel == 'x' && opt.waves == 8))) ? 8 : 4; if (D == 128 || waves == 8) qb = 1; }
     if (qb == 2 && !w8_ && !((D == 64 || (D == 128 && which == 'p' && FA_EXPERIMENTAL)) && waves == 4)) qb = 1;
     if (which == 't' && waves > 4) waves = 4;
     if (split > 1 && !((which == 'd' || which == 'h') && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
@@ -331,6 +332,10 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
     plan->source = c.source;
     plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
     if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
+    if (which == 'x' && D == 64 && waves == 8) {   // 8 waves x 16 rows (experimental)
+        plan->block_q = 128;
+        plan->grid = g8 * ((L + 127) / 128);
+    }
     if (which == 'h') {   // 4 waves = 2 row blocks x 2 key halves per kv split group: 64-row workgroups
         plan->block_q = 64;
         plan->grid = g8 * ((L + 63) / 64);

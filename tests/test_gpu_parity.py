@@ -189,6 +189,33 @@ def test_pipelined_kernel_one_wave_per_simd_head_dim_128(knobs, dtype, scale, G,
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 0.125), (torch.float16, 0.125)])
+@pytest.mark.parametrize("G,L", [(2, 16), (2, 32), (3, 100), (2, 257), (9, 600), (2, 1000), (1, 4608), (12, 1024)])
+def test_pipelined_16x16x32_kernel_with_16_row_waves(knobs, dtype, scale, G, L, causal):
+    """fa_fwd_pipe16_kernel<T, 64, 8, 1> (A/B material): 128-row workgroups of EIGHT waves x 16 rows on v_mfma_f32_16x16x32 -
+    twice the waves per row block, half the dependency chain per step, one LDS-DMA piece per wave and step - for launches with fewer
+    workgroups than the chip has slots.  Out and logsumexp against the oracle (a wave's diagonal step covers half a step's keys)."""
+    _, native, _ = _mods()
+    from oracle import dense_attention_lse, frozen_randn
+
+    if not native.experimental_kernels():
+        pytest.skip("A/B material, not in the product library (make EXPERIMENTAL=1)")
+    knobs.set("kernel", "pipe16")
+    knobs.set("waves", 8)
+    p = native.plan(G, L, 64, dtype, 1, 1, softmax_scale=scale, causal=causal)
+    assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (4, 8, 1, 128, 32)
+    x = frozen_randn(SEED + 31 * L + G, (3, G, L, 64)).to(dtype)
+    ref, ref_lse = _oracle(x, scale=scale) if causal else dense_attention_lse(x[0][None], x[1][None], x[2][None], scale=scale, causal=False)
+    q, k, v = x.cuda()
+    out = torch.empty_like(q)
+    lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+    st = (L * 64, 0, 64)
+    native.fwd_strided(q, k, v, out, lse, G, L, 64, 1, st, st, st, st, 1, 1, scale, causal)
+    _check(out, ref.reshape(G, L, 64), dtype, f"pipe16 16-row waves {dtype} scale={scale:.3g} causal={causal} {G}x{L}x64")
+    torch.testing.assert_close(lse.cpu().double(), ref_lse.reshape(G, L), atol=LSE_ATOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.float16, 0.125)])
 @pytest.mark.parametrize("G,L", [(3, 512), (9, 1024), (2, 2560), (1, 4608), (2, 4096), (2, 700)])
 def test_512_row_workgroups_on_one_shared_ring(knobs, dtype, scale, G, L):
