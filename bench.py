@@ -716,14 +716,13 @@ def main():
         else:
             line["cpu_baseline"] = None
         # the driver keeps an 8 KB tail of stdout: the line must fit (shed detail, never the contract keys)
-        for drop in ("secondary", "ramp"):
-            if len(json.dumps(line)) > 7600 and drop in line and drop != "secondary":
-                line.pop(drop)
-            elif len(json.dumps(line)) > 7600 and drop == "secondary" and isinstance(line.get("secondary"), dict):
-                for v in line["secondary"].values():
-                    if isinstance(v, dict):
-                        for k2 in ("median_ms", "min_ms", "alg_bytes", "shape", "tile"):
-                            v.pop(k2, None)
+        if len(json.dumps(line)) > 7600 and isinstance(line.get("secondary"), dict):
+            for v in line["secondary"].values():
+                if isinstance(v, dict):
+                    for k2 in ("median_ms", "min_ms", "alg_bytes", "shape", "tile"):
+                        v.pop(k2, None)
+        if len(json.dumps(line)) > 7600:
+            line.pop("ramp", None)
     # (rank 0's line is complete except for the exchange comparison below)
     # ---- N > 1: the three ways to move O, measured in THIS launch after the headline (one driver run tells the whole story):
     # per mode the exchange alone (a fixed shard, no kernel: what the links deliver) and kernel + exchange per step, overlapped the
