@@ -190,13 +190,21 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     for (int b = 0; b < QB; ++b) rowb[b] = MIRROR ? qi * BQ + 32 * (b == 0 ? wave : 2 * NWAVES - 1 - wave) : q_row0 + 32 * b;
     const bool wave_active = MIRROR ? true : q_row0 < L;
 
+    const int dchunks = p.Dr >> 3;               // the operands' true head dim in 16-byte chunks (= D / 8 unless the call runs zero-extended)
     vec8 qf[QB][KS];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         const int qr = rowb[b] + r < L ? rowb[b] + r : L - 1;
-        const T* qp = qg + (int64_t)qr * p.q_sl + 8 * h;
+        const T* qp = qg + (int64_t)qr * p.q_sl;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[b][ks] = *(const vec8*)(qp + 16 * ks);
+        for (int ks = 0; ks < KS; ++ks) {       // (columns past the operands' true head dim, FwdParams::Dr: zeros)
+            const int ch_ = 2 * ks + h;
+            const vec8 ld_ = *(const vec8*)(qp + 8 * (ch_ < dchunks ? ch_ : 0));
+            vec8 z_;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z_[j] = (T)0.f;
+            qf[b][ks] = ch_ < dchunks ? ld_ : z_;
+        }
     }
     if constexpr (FOLD) {
 #pragma unroll
@@ -217,15 +225,16 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         const int row = pc * (1024 / ROWB) + lane / (ROWB / 16);
         const int cp = lane % (ROWB / 16);
         const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
-        k_vo[j] = (unsigned)row * k_slb + ((cp ^ sw) << 4);
+        // (a chunk past the true head dim: an offset beyond the descriptor's extent - the DMA writes zeros, as for rows past L)
+        k_vo[j] = (cp ^ sw) < dchunks ? (unsigned)row * k_slb + ((cp ^ sw) << 4) : 0x80000000u;
         k_dst[j] = pc * 1024;
         const int dblk = pc >> 1, q2 = pc & 1;   // a piece = two 8-key blocks of one d-block
         const int key = (2 * q2 + (lane >> 5)) * 8 + ((lane >> 2) & 7);
-        v_vo[j] = (unsigned)key * v_slb + ((dblk * 4 + (lane & 3)) << 4);
+        v_vo[j] = (dblk * 4 + (lane & 3)) < dchunks ? (unsigned)key * v_slb + ((dblk * 4 + (lane & 3)) << 4) : 0x80000000u;
         v_dst[j] = dblk * VBLK_B + q2 * 1024;
     }
-    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;
-    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
+    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + (unsigned)p.Dr) * 2;
+    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + (unsigned)p.Dr) * 2;
     const unsigned smem_lds = lds_offset(smem);
     // one descriptor per operand for the whole workgroup (AG: the steady steps issue their LDS-DMA pieces inside MFMA gaps, a step's
     // rows reached through the lane offset - no per-step descriptor arithmetic in a stream that has its SIMD to itself)
@@ -843,7 +852,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             const int rr = i * RPI + lane / CPR, ch = lane % CPR;
             const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
             const int orow = rowb[b] + rr;
-            if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
+            if (orow < L && ch < dchunks) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
         }
     }
 #ifdef FA_STAMPS

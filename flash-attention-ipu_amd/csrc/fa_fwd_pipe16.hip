@@ -107,15 +107,23 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
 
     const int q_row0 = qi * BQ + wave * RW;
     const bool wave_active = q_row0 < L;
+    const int dchunks = p.Dr >> 3;               // the operands' true head dim in 16-byte chunks (= D / 8 unless the call runs zero-extended)
     int qrow[NQH];                               // this lane's query row in each 16-row block
     vec8 qf[NQH][NDS];
 #pragma unroll
     for (int qh = 0; qh < NQH; ++qh) {
         qrow[qh] = q_row0 + 16 * qh + n;
         const int qr = qrow[qh] < L ? qrow[qh] : L - 1;
-        const T* qp = qg + (int64_t)qr * p.q_sl + 8 * gq;
+        const T* qp = qg + (int64_t)qr * p.q_sl;
 #pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) qf[qh][ds] = *(const vec8*)(qp + 32 * ds);
+        for (int ds = 0; ds < NDS; ++ds) {      // (columns past the operands' true head dim, FwdParams::Dr: zeros)
+            const int ch_ = 4 * ds + gq;
+            const vec8 ld_ = *(const vec8*)(qp + 8 * (ch_ < dchunks ? ch_ : 0));
+            vec8 z_;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z_[j] = (T)0.f;
+            qf[qh][ds] = ch_ < dchunks ? ld_ : z_;
+        }
     }
 
     // ---- LDS-DMA geometry: piece pc = wave + j NWAVES = rows 4 pc .. 4 pc + 3 of a slot; the lane's LDS destination is
@@ -127,12 +135,13 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     for (int j = 0; j < PPW; ++j) {
         const int pc = HALF ? wave % PIECES : wave + j * NWAVES;
         const int row = RPP * pc + lane / CPR, cp = lane % CPR;
-        k_vo[j] = (unsigned)row * k_slb + ((cp ^ kswz(row)) << 4);
-        v_vo[j] = (unsigned)row * v_slb + ((cp ^ vswz(row)) << 4);
+        // (a chunk past the true head dim: an offset beyond the descriptor's extent - the DMA writes zeros, as for rows past L)
+        k_vo[j] = (cp ^ kswz(row)) < dchunks ? (unsigned)row * k_slb + ((cp ^ kswz(row)) << 4) : 0x80000000u;
+        v_vo[j] = (cp ^ vswz(row)) < dchunks ? (unsigned)row * v_slb + ((cp ^ vswz(row)) << 4) : 0x80000000u;
         dst[j] = pc * 1024;
     }
-    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;
-    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
+    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + (unsigned)p.Dr) * 2;
+    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + (unsigned)p.Dr) * 2;
     const unsigned smem_lds = lds_offset(smem);
 
 #define P16_DMA_K(J_, SLOT_)                                                                       \
@@ -488,7 +497,7 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
         const int rr = RPI * i + lane / CPR, ch = lane % CPR;
         const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
         const int orow = q_row0 + rr;
-        if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
+        if (orow < L && ch < dchunks) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
     }
 }
 
