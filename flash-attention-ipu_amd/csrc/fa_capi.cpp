@@ -188,7 +188,7 @@ struct Request {
     int es, skip, wmax;            // element size; 1 = skip-max arithmetic; waves the q chunk allows
     bool pipe_ok, want32;          // the pipelined kernels implement skip-max only; a kv chunk below 64 keys wants 32-key steps
     bool d_only;                   // the operands' true head dim is below the kernel's (zero-extended call): the kernels that read FwdParams::Dr only
-                                   // (fa_fwd_dma_kernel, fa_fwd_pipe_kernel, fa_fwd_pipe16_kernel - not the key-halves kernel)
+                                   // (every product forward kernel does; the experimental 'P' / 't' kernels do not)
 };
 struct Choice {
     char which;                    // 'd' | 'p' | 'x' | 'P' | 'h' | 't'
@@ -263,7 +263,7 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
     char& which = c->which;
     int &waves = c->waves, &qb = c->qb, &split = c->split;
     if (!FA_EXPERIMENTAL && (which == 't' || which == 'P')) which = 'd';      // (not in this build: make EXPERIMENTAL=1)
-    if (r.d_only && !(which == 'd' || which == 'p' || which == 'x')) { which = 'd'; qb = 1; split = 1; if (waves > 4) waves = 4; }   // (the key-halves kernel does not read a narrower head dim)
+    if (r.d_only && (which == 'P' || which == 't')) { which = 'd'; qb = 1; split = 1; if (waves > 4) waves = 4; }   // (the experimental kernels do not read a narrower head dim)
     if (r.want32 && r.pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
     const bool w8_ = FA_EXPERIMENTAL && which == 'p' && D == 64 && waves == 8 && qb == 2 && r.causal && r.pipe_ok;   // (512-row workgroups: forced only)
     if (which == 'p' && ((waves > 4 && D != 128 && !w8_) || !r.pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)

@@ -84,11 +84,19 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
     const int qrow = q_row0 + r;
     const bool wave_active = q_row0 < L;
 
+    const int dchunks = p.Dr >> 3;     // the operands' true head dim in 16-byte chunks (= D / 8 unless the call runs zero-extended: FwdParams::Dr)
     vec8 qf[KS];
     {
-        const T* qp = qg + (int64_t)(qrow < L ? qrow : L - 1) * p.q_sl + 8 * h;
+        const T* qp = qg + (int64_t)(qrow < L ? qrow : L - 1) * p.q_sl;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const vec8*)(qp + 16 * ks);
+        for (int ks = 0; ks < KS; ++ks) {       // (columns past the true head dim: zeros)
+            const int ch_ = 2 * ks + h;
+            const vec8 ld_ = *(const vec8*)(qp + 8 * (ch_ < dchunks ? ch_ : 0));
+            vec8 z_;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z_[j] = (T)0.f;
+            qf[ks] = ch_ < dchunks ? ld_ : z_;
+        }
     }
 
     // ---- LDS-DMA geometry (fa_fwd_dma.hip): piece pc = wave + j NW of a tile, lane -> source byte offset
@@ -101,15 +109,16 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
         const int row = pc * (1024 / ROWB) + lane / (ROWB / 16);
         const int cp = lane % (ROWB / 16);
         const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
-        k_vo[j] = (unsigned)row * k_slb + ((cp ^ sw) << 4);
+        // (a chunk past the true head dim: an offset beyond the descriptor's extent - the DMA writes zeros, as for rows past L)
+        k_vo[j] = (cp ^ sw) < dchunks ? (unsigned)row * k_slb + ((cp ^ sw) << 4) : 0x80000000u;
         k_dst[j] = pc * 1024;
         const int dblk = pc >> 2, q2 = pc & 3;
         const int key = (2 * q2 + (lane >> 5)) * 8 + ((lane >> 2) & 7);
-        v_vo[j] = (unsigned)key * v_slb + ((dblk * 4 + (lane & 3)) << 4);
+        v_vo[j] = (dblk * 4 + (lane & 3)) < dchunks ? (unsigned)key * v_slb + ((dblk * 4 + (lane & 3)) << 4) : 0x80000000u;
         v_dst[j] = dblk * VBLK_B + q2 * 1024;
     }
-    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + D) * 2;
-    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + D) * 2;
+    const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + (unsigned)p.Dr) * 2;
+    const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + (unsigned)p.Dr) * 2;
     const unsigned smem_lds = lds_offset(smem);
     auto dma_tile = [&](int t, int buf) {          // descriptors start at the tile's first row; rows past L read as zeros
         const unsigned ko = (unsigned)t * BK * k_slb, vo = (unsigned)t * BK * v_slb;
@@ -310,7 +319,7 @@ __device__ __forceinline__ void fa_fwd_kh_body(const FwdParams& p) {
         const int rr = i * RPI + lane / CPR, ch = lane % CPR;
         const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
         const int orow = q_row0 + rr;
-        if (orow < L) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
+        if (orow < L && ch < dchunks) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
     }
 }
 

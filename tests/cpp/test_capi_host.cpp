@@ -89,7 +89,7 @@ int main() {
                                         EXPECT(pl.lds_bytes > 0 && pl.lds_bytes <= 160 * 1024);                  // one workgroup must fit a CU's LDS
                                         EXPECT(pl.chunk_q == chunk);
                                         if (!mfma16) { EXPECT(pl.kernel == 1 || pl.kernel == 3); continue; }
-                                        if (D == 96) EXPECT(pl.kernel != 6);                                        // (the key-halves kernel does not read a narrower head dim)
+                                        
                                         EXPECT(pl.kernel == 0 || pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 6);   // nothing experimental in this build
                                         EXPECT(pl.qb == 1 || pl.qb == 2);
                                         EXPECT(pl.waves == 1 || pl.waves == 2 || pl.waves == 4 || pl.waves == 8 || pl.waves == 16);

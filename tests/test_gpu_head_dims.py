@@ -95,7 +95,7 @@ def test_zero_extended_head_dims_through_the_mfma_kernels(dtype, D, B, H, Hkv, L
     from oracle import dense_attention_lse, frozen_randn
 
     p = _native.plan(B * H, L, D, dtype, 1, 1, softmax_scale=D ** -0.5, causal=causal)
-    assert p.kernel in (0, 2, 4), "a 16-bit head dim that is a multiple of 8 below 128 must be served by an MFMA kernel"
+    assert p.kernel in (0, 2, 4, 6), "a 16-bit head dim that is a multiple of 8 below 128 must be served by an MFMA kernel"
     q = (frozen_randn(SEED + L + D, (B, H, L, D)) * 0.8).to(dtype)
     k = (frozen_randn(SEED + L + D + 1, (B, Hkv, L, D)) * 0.8).to(dtype)
     v = (frozen_randn(SEED + L + D + 2, (B, Hkv, L, D)) * 0.8).to(dtype)
@@ -130,7 +130,8 @@ def test_zero_extended_head_dims_through_the_mfma_kernels(dtype, D, B, H, Hkv, L
         assert torch.equal(o2.view(B, H, L, D), out.detach())
 
 
-@pytest.mark.parametrize("kernel,waves,qb", [("pipe", 4, 1), ("pipe", 4, 2), ("pipe", 8, 1), ("pipe16", 4, 1), ("pipe16", 4, 2), ("pipe16", 8, 1), ("dma", 8, 1), ("dma", 4, 2)])
+@pytest.mark.parametrize("kernel,waves,qb", [("pipe", 4, 1), ("pipe", 4, 2), ("pipe", 8, 1), ("pipe16", 4, 1), ("pipe16", 4, 2), ("pipe16", 8, 1), ("dma", 8, 1), ("dma", 4, 2),
+                                             ("kh", 4, 1), ("kh2", 4, 1)])
 @pytest.mark.parametrize("D,G,L", [(96, 2, 1000), (72, 3, 2304), (40, 2, 1000), (24, 9, 600), (56, 2, 2304), (120, 1, 4608)])
 def test_zero_extended_head_dims_through_every_kernel_that_reads_them(knobs, kernel, waves, qb, D, G, L):
     """`FwdParams::Dr` in the software-pipelined kernels too (32x32x16 and 16x16x32 forms, one and two query blocks per wave, 4 and 8
@@ -142,12 +143,17 @@ def test_zero_extended_head_dims_through_every_kernel_that_reads_them(knobs, ker
     Dk = 64 if D < 64 else 128
     if (qb == 2 and Dk == 128) or (waves == 8 and Dk == 64 and kernel != "dma") or (kernel == "dma" and qb == 2 and Dk == 128):
         pytest.skip("no such form at this head dim")
-    knobs.set("kernel", kernel)
-    knobs.set("waves", waves)
-    knobs.set("qb", qb)
+    if kernel.startswith("kh"):         # 64-row workgroups of (row block, key half) waves, alone or with two kv split groups
+        knobs.set("kernel", "kh")
+        if kernel == "kh2":
+            knobs.set("split", 2)
+    else:
+        knobs.set("kernel", kernel)
+        knobs.set("waves", waves)
+        knobs.set("qb", qb)
     dtype = torch.bfloat16
     p = _native.plan(G, L, D, dtype, 1, 1)
-    assert p.kernel == {"dma": 0, "pipe": 2, "pipe16": 4}[kernel], (p.kernel, p.waves, p.qb)
+    assert p.kernel == {"dma": 0, "pipe": 2, "pipe16": 4, "kh": 6, "kh2": 6}[kernel], (p.kernel, p.waves, p.qb)
     x = (frozen_randn(SEED + 37 * L + D, (3, G, L, D)) * 0.8).to(dtype)
     ref, ref_lse = dense_causal_attention_lse(x, scale=D ** -0.5, compute_dtype=torch.float64)
     q, k, v = x.cuda()

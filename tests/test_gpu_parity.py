@@ -674,7 +674,7 @@ def test_generic_kernel(knobs, dtype, G, L, D):
     # (round 4: a 16-bit head dim that is a multiple of 8 below 128 - 24, 32, 80 here - runs zero-extended inside the MFMA kernel instead;
     #  the same shapes, the same oracle: tests/test_gpu_head_dims.py has the dedicated cases)
     zero_extended = dtype != torch.float32 and D % 8 == 0 and D < 128
-    assert native.plan(G, L, D, dtype, 1, 1).kernel == (0 if zero_extended else 1)
+    assert native.plan(G, L, D, dtype, 1, 1).kernel in ((0, 2, 4, 6) if zero_extended else (1,))
     ref, ref_lse = _oracle(qkv)
     out = fa.flash_attention_qkv_packed(qkv.cuda(), 1, 1)
     _check(out, ref, dtype, f"generic {dtype} {G}x{L}x{D}")
