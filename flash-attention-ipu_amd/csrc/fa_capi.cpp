@@ -100,17 +100,18 @@ const Options& options() {
 // wave at head_dim 64, 8 waves at head_dim 128).
 int waves_for_chunk(int64_t want) { return want >= 128 ? 4 : want >= 64 ? 2 : 1; }
 
-// Head dims the MFMA kernels serve: 64 and 128 natively; for 16-bit operands every other multiple of 8 below 128 runs ZERO-EXTENDED at the
-// next of the two (FwdParams::Dr: out-of-range LDS-DMA chunks and predicated register loads read the missing columns as zeros, stores
-// stop at the true head dim) - the reference's op has no head-dim restriction (FA.cpp:175-195).  Returns 0 when there is no such kernel.
+// Head dims the MFMA kernels serve: 64 and 128 natively (16-bit and fp32), 256 for 16-bit operands (the 64-key-tile kernels alone: one
+// 4-wave workgroup per CU, fa_fwd_dma.hip / fa_bwd_kernels.hip); for 16-bit operands every other multiple of 8 up to 256 runs ZERO-EXTENDED
+// at the next of the three (FwdParams::Dr: out-of-range LDS-DMA chunks and predicated register loads read the missing columns as zeros,
+// stores stop at the true head dim) - the reference's op has no head-dim restriction (FA.cpp:175-195).  Returns 0 when there is no such kernel.
 int64_t kernel_head_dim(int64_t D, int32_t dtype) {
     if (D == 64 || D == 128) return D;
-    if ((dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D < 128 && D % 8 == 0) return D < 64 ? 64 : 128;
+    if ((dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D <= 256 && D % 8 == 0) return D < 64 ? 64 : D < 128 ? 128 : 256;
     return 0;
 }
 
 bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* const strides[4]) {
-    if (!(D == 64 || D == 128)) return false;
+    if (!(D == 64 || D == 128 || D == 256)) return false;
     for (int i = 0; i < 4; ++i) {
         if (ptrs[i] && (reinterpret_cast<uintptr_t>(ptrs[i]) & 15)) return false;
         if (strides[i]) {
@@ -262,6 +263,7 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
     const int64_t D = r.D;
     char& which = c->which;
     int &waves = c->waves, &qb = c->qb, &split = c->split;
+    if (D == 256) { which = 'd'; waves = 4; qb = 1; split = 1; return; }      // head_dim 256: the 64-key-tile kernel in its 4-wave form (132 KB of LDS, the whole register file)
     if (!FA_EXPERIMENTAL && (which == 't' || which == 'P')) which = 'd';      // (not in this build: make EXPERIMENTAL=1)
     if (r.d_only && (which == 'P' || which == 't')) { which = 'd'; qb = 1; split = 1; if (waves > 4) waves = 4; }   // (the experimental kernels do not read a narrower head dim)
     if (r.want32 && r.pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
@@ -288,7 +290,7 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
     int pair = 0;
     {
         const int64_t nq128 = (L + 127) / 128;
-        const bool pair_ok = which == 'd' && r.causal && waves == 4 && qb == 1 && split == 1 && nq128 >= 2;
+        const bool pair_ok = which == 'd' && r.causal && waves == 4 && qb == 1 && split == 1 && nq128 >= 2 && D != 256;
         // measured (profiles/r03_short/sweep_*.txt): pairs LOSE 2..10 % at L = 1024 .. 4096 (4 resident workgroups per CU already hide each
         // other's prologues; the pair's second tile waits for the first tile's stores at its first barrier) - built-in rule: off
         if (c.table_pair && pair_ok && c.source == 1) pair = 1;          // (a measured row may switch them on)
@@ -303,7 +305,7 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
         const int64_t nqt = (L + rows - 1) / rows, ng = g8 / 8;
         const int64_t nitem = nqt;                                                          // workgroups per group
         // resident workgroups per XCD: by LDS (33 KB per 4-wave group at head_dim 64, 66 KB at 128; 160 KB per CU)
-        const int per_cu = which == 'h' ? (D == 64 ? (split == 1 ? 4 : split == 2 ? 2 : 1) : (split == 1 ? 2 : 1)) : (D == 64 ? 4 : 2);
+        const int per_cu = which == 'h' ? (D == 64 ? (split == 1 ? 4 : split == 2 ? 2 : 1) : (split == 1 ? 2 : 1)) : (D == 64 ? 4 : D == 128 ? 2 : 1);
         const int64_t slots_per_xcd = (int64_t)per_cu * kCusPerXcd;
         if (ng * nitem <= slots_per_xcd && ng * nitem <= 128) {
             int bunch_sz = (int)((8ll << 20) / (2 * L * D * es));
@@ -617,14 +619,15 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     if (k_strides[2] > (1ll << 32) || v_strides[2] > (1ll << 32)) wide_rows = true;
 
     // the MFMA kernels need 16-byte rows and address K/V rows with 32-bit element offsets from the group base
-    const int64_t Dk0 = kernel_head_dim(D, dtype);
+    // mask / dropout: the MFMA mask kernel (fa_fwd_extra.hip) for 16-bit operands it takes (head dims up to 128), the generic kernel for
+    // everything else fa_fwd serves (fp32, other head dims, unaligned rows) - never the fp32 MFMA kernel, which has no mask path
+    const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
+    int64_t Dk0 = kernel_head_dim(D, dtype);
+    if (extra && Dk0 == 256) Dk0 = 0;              // (the mask / dropout kernels stop at head_dim 128: their dK/dV form does not fit the register file at 256)
     const bool wide_ok = !wide_rows && Dk0 != 0 && aligned16(Dk0, elt_size(dtype), ptrs, strides) && L * k_strides[2] < (1ll << 31) && L * v_strides[2] < (1ll << 31);
     const int64_t Dk = wide_ok ? Dk0 : D;          // the head dim the launched kernel runs at (D itself on the generic path)
     const bool mfma16_ok = wide_ok && (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16);
     const bool f32_ok = wide_ok && dtype == FA_DTYPE_F32 && !options().f32_generic;
-    // mask / dropout: the MFMA mask kernel (fa_fwd_extra.hip) for 16-bit operands it takes, the generic kernel for everything else
-    // fa_fwd serves (fp32, other head dims, unaligned rows) - never the fp32 MFMA kernel, which has no mask path
-    const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     Selection sel;
     const int rc = select_plan(G, L, Dk, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal, mfma16_ok, f32_ok && !extra, Dk != D, &sel);
     if (rc != FA_OK) return rc;
@@ -758,7 +761,7 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
     if (L > (1ll << 30) || G > (1ll << 30)) return fail(FA_ERR_TOO_LARGE, "G and L must be < 2^30");
     const void* const ptrs[8] = {q, k, v, out, dout, dq, dk, dv};
-    // MFMA kernels: head_dim 64/128, 16-byte aligned rows - 16-bit dtypes (fa_bwd_kernels.hip) and fp32
+    // MFMA kernels: head_dim 64/128 (16-bit: 256 too, and every multiple of 8 below, zero-extended), 16-byte aligned rows - 16-bit dtypes (fa_bwd_kernels.hip) and fp32
     // (fa_bwd_f32.hip, v_mfma_f32_32x32x2_f32); everything else -> generic kernels
     const int64_t Dk0 = kernel_head_dim(D, dtype);
     bool mfma = Dk0 != 0 && !(dtype == FA_DTYPE_F32 && options().f32_generic);
@@ -774,6 +777,7 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
     }
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     if (extra && dtype == FA_DTYPE_F32) mfma = false;       // (the fp32 MFMA kernels have no mask path: generic kernels)
+    if (extra && Dk0 == 256) mfma = false;                  // (nor have the head_dim 256 kernels)
     if (!mfma && D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic backward supports D <= 1024 (got %lld)", (long long)D);
     if (!mfma && G * L > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     fa::BwdParams p;

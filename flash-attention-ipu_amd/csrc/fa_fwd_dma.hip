@@ -638,9 +638,21 @@ static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, int split,
     return e;
 }
 
+// head_dim 256 (and 136 .. 248 zero-extended): the one form that fits - 4 waves x 32 rows, 64-key tiles: K0 K1 V0 V1 = 132 KB of LDS, one
+// workgroup per CU, 256 VGPRs + the accumulators' overflow in AGPRs (no scratch)
+template <typename T, bool SKIP>
+static hipError_t launch_dma_256(const FwdParams& p, int waves, int qb, int split, int pair, hipStream_t stream) {
+    if (!(waves == 4 && qb == 1 && split == 1 && !pair)) return hipErrorInvalidValue;
+    return launch1((const void*)(fa_fwd_dma_kernel<T, 256, 4, SKIP, 1, 1>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
+}
+
 // waves = waves per kv split group (the workgroup has waves x split); qb = 32-row query blocks per wave (1, or 2 for head_dim 64
 // with 4 waves); split = kv split groups (1; 2 | 4 with 4 waves and qb 1).  The host sized p.nq_tiles for 32 waves qb rows.
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, int split, int pair, hipStream_t stream) {
+    if (p.D == 256) {
+        if (dtype == 1) return launch_dma_256<__bf16, true>(p, waves, qb, split, pair, stream);
+        return p.skipmax ? launch_dma_256<_Float16, true>(p, waves, qb, split, pair, stream) : launch_dma_256<_Float16, false>(p, waves, qb, split, pair, stream);
+    }
     if (dtype == 1) {   // bf16: always skip-max
         return p.D == 64 ? launch_dma_w<__bf16, 64, true>(p, waves, qb, split, pair, stream) : launch_dma_w<__bf16, 128, true>(p, waves, qb, split, pair, stream);
     }

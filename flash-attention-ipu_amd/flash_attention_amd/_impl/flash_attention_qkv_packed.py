@@ -45,12 +45,12 @@ def flash_attention_qkv_packed(qkv: torch.Tensor, num_chunks_q: int, num_chunks_
         # HIP forward; HIP backward through autograd (an opaque torch.library custom op under torch.compile)
         D = qkv.shape[3]
         sixteen = qkv.dtype in (torch.float16, torch.bfloat16)
-        native = D in (64, 128) or (sixteen and D < 128 and D % 8 == 0)     # (zero-extended inside the MFMA kernels: no copies)
-        if not native and D < 128 and qkv.shape[1] * qkv.shape[2] >= PAD_HEAD_DIM_MIN_ROWS and not torch.compiler.is_compiling():
+        native = D in (64, 128) or (sixteen and D <= 256 and D % 8 == 0)    # (zero-extended inside the MFMA kernels: no copies)
+        if not native and D < (256 if sixteen else 128) and qkv.shape[1] * qkv.shape[2] >= PAD_HEAD_DIM_MIN_ROWS and not torch.compiler.is_compiling():
             # a head dim the MFMA kernels do not take (not a multiple of 8, or fp32 off 64 / 128), on a call too large for the generic
             # (scalar fp32) kernel: zero columns change neither Q K^T nor the first D columns of P V (the op applies no 1 / sqrt(D)
             # scale, FA.cpp:254), so the call runs padded to a head dim they do take and the result is sliced; autograd sees
-            # pad / slice.  (D > 128 stays on the generic kernel.)
+            # pad / slice.  (D > 256 - fp32: D > 128 - stays on the generic kernel.)
             Dp = (D + 7) // 8 * 8 if sixteen else (64 if D < 64 else 128)
             padded = torch.nn.functional.pad(qkv, (0, Dp - D))
             return ops.attention_qkv_packed(padded, int(num_chunks_q), int(num_chunks_kv))[..., :D].contiguous()

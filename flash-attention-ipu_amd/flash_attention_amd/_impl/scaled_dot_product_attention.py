@@ -33,25 +33,27 @@ def chunk_heuristic(L: int, D: int):
 
 # Head dims other than 64 / 128.  The reference's op has no head-dim restriction (FA.cpp:175-195; its own tests run D = 2,
 # t_cpp:245-251).  The C ABI serves
-#   * f16 / bf16 with D a multiple of 8 below 128 through the MFMA kernels themselves, ZERO-EXTENDED at the next MFMA head dim inside the
-#     kernels (round 4, `FwdParams::Dr`: out-of-range LDS-DMA chunks and predicated register loads read the missing columns as zeros,
-#     stores stop at D - no copies, forward and backward, masks and dropout included);
-#   * everything else (D > 128, D not a multiple of 8, fp32 off 64 / 128) through the generic kernel: one workgroup per query row, scalar
+#   * f16 / bf16 with D a multiple of 8 up to 256 through the MFMA kernels themselves: 64, 128 and 256 natively, the others ZERO-EXTENDED
+#     at the next of the three inside the kernels (round 4, `FwdParams::Dr`: out-of-range LDS-DMA chunks and predicated register loads
+#     read the missing columns as zeros, stores stop at D - no copies, forward and backward; masks and dropout up to head_dim 128);
+#   * everything else (D > 256, D not a multiple of 8, fp32 off 64 / 128) through the generic kernel: one workgroup per query row, scalar
 #     fp32 arithmetic, 1-2 TFLOP/s - a correctness path that an `import flash_attention_amd.auto` must not silently put
-#     under a model.  For calls of at least GENERIC_KERNEL_MAX_ROWS query rows the override therefore pads D < 128 to the next head dim the
+#     under a model.  For calls of at least GENERIC_KERNEL_MAX_ROWS query rows the override therefore pads such a D to the next head dim the
 #     MFMA kernels take (zero columns change neither Q K^T nor the first D columns of P V; the scale stays D^-1/2 of the TRUE head dim;
-#     autograd sees pad / slice) and hands D > 128 to stock SDPA (`orig_fn`).
+#     autograd sees pad / slice) and hands what cannot be padded to one (D > 256; fp32 above 128) to stock SDPA (`orig_fn`).
 # Smaller calls (the reference's own tiny test shapes) stay on the generic kernel: exact fp32 arithmetic, no copies.
 GENERIC_KERNEL_MAX_ROWS = 4096
+MFMA_HEAD_DIM_MAX = 256       # 16-bit operands (fa_capi.cpp: kernel_head_dim); fp32: 64 and 128 only
 
 
 def _mfma_head_dim(D: int, dtype):
     """(served natively?, head dim to pad to or None): what the MFMA kernels make of a D-wide call"""
-    if D in (64, 128) or (dtype in (torch.float16, torch.bfloat16) and D < 128 and D % 8 == 0):
+    sixteen = dtype in (torch.float16, torch.bfloat16)
+    if D in (64, 128) or (sixteen and D <= MFMA_HEAD_DIM_MAX and D % 8 == 0):
         return True, D
-    if D > 128:
+    if D > (MFMA_HEAD_DIM_MAX if sixteen else 128):
         return False, None
-    if dtype in (torch.float16, torch.bfloat16):
+    if sixteen:
         return False, (D + 7) // 8 * 8            # the next multiple of 8: the kernels zero-extend from there
     return False, 64 if D < 64 else 128           # fp32: the fp32 MFMA kernels take 64 and 128 only
 

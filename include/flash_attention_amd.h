@@ -78,7 +78,8 @@ enum {
 
 /* hardware tile the request was mapped to (fa_plan) */
 typedef struct fa_plan_t {
-    int32_t kernel;      /* 0 = MFMA kernel, 64-key tiles (bf16/f16, D in {64,128}), 1 = generic kernel,
+    int32_t kernel;      /* 0 = MFMA kernel, 64-key tiles (bf16/f16, D in {64,128,256}; other multiples of 8 up to 256 run zero-extended
+                                at the next of the three, in this and - up to 128 - in kernels 2, 4, 6), 1 = generic kernel,
                             2 = MFMA kernel, software-pipelined 32-key steps,
                             3 = fp32 MFMA kernel (fp32 inputs, D in {64,128}, 16-byte rows),
                             4 = software-pipelined kernel on v_mfma_f32_16x16x32 (bf16/f16, D in {64,128}),
@@ -199,8 +200,9 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
  *   heads, heads_kv : as in fa_fwd.  With heads_kv < heads (grouped-query attention) k, v, dk and dv have
  *                    G / (heads / heads_kv) groups; dk / dv of a key/value head are the sums over the query heads that
  *                    read it, formed inside ONE workgroup per 128 keys (no expanded K/V, no atomics)   [ABI 3]
- * f16/bf16/fp32 with D in {64, 128} and 16-byte aligned rows run the MFMA kernels; every other case
- * (other D <= 1024, unaligned rows) runs generic fp32-arithmetic kernels.
+ * f16/bf16/fp32 with D in {64, 128}, f16/bf16 with D any other multiple of 8 up to 256 (zero-extended at 64 / 128 / 256 inside
+ * the kernels) and 16-byte aligned rows run the MFMA kernels; every other case (other D <= 1024, unaligned rows) runs generic
+ * fp32-arithmetic kernels.
  * Deterministic: no gradient is accumulated across workgroups.
  */
 int fa_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
@@ -232,7 +234,7 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
  *                   with the two words in device memory the caller captures its own update of them (copy the generator's state to
  *                   a per-call snapshot, advance the generator) and every replay sees fresh values.  fa_bwd_ex must be given the
  *                   snapshot its forward read.  8-byte aligned; read on `stream`, never written.
- * f16 / bf16 operands at head_dim 64 or 128 with 16-byte aligned rows run MFMA kernels (csrc/fa_fwd_extra.hip, fa_bwd_extra.hip);
+ * f16 / bf16 operands at head dims up to 128 (multiples of 8: zero-extended at 64 / 128) with 16-byte aligned rows run MFMA kernels (csrc/fa_fwd_extra.hip, fa_bwd_extra.hip);
  * everything else fa_fwd serves (fp32, other head dims <= 1024, unaligned rows) runs the generic fp32-arithmetic kernels with the same
  * mask and the same dropout decisions (a bias then has the operand dtype, fp32 included).  With mask = NULL and dropout_p = 0 they
  * ARE fa_fwd / fa_bwd.

@@ -1,10 +1,10 @@
 """Head dims other than 64 / 128 (round-3 verdict, item 4).  The reference's op has no head-dim restriction
 (flash_attention_ipu/cpp/flash_attention_qkv_packed.cpp:175-195; its own tests run D = 2, tests/cpp/test_flash_attention.cpp:245-251)
-and the C ABI serves every D <= 1024: f16 / bf16 at every multiple of 8 up to 128 through the MFMA kernels (64 and 128 natively, the
+and the C ABI serves every D <= 1024: f16 / bf16 at every multiple of 8 up to 256 through the MFMA kernels (64, 128 and 256 natively, the
 others ZERO-EXTENDED inside the kernels: out-of-range LDS-DMA chunks and predicated loads read the missing columns as zeros, stores stop
-at the true head dim - forward, backward, masks, dropout), everything else through the generic kernel (one workgroup per query row,
-scalar fp32 arithmetic, 1-2 TFLOP/s).  `import flash_attention_amd.auto` must not put that kernel under a model: large calls it would
-get run padded to a head dim the MFMA kernels take (D < 128) or go to stock SDPA (D > 128)."""
+at the true head dim - forward and backward; masks and dropout up to 128), everything else through the generic kernel (one workgroup per
+query row, scalar fp32 arithmetic, 1-2 TFLOP/s).  `import flash_attention_amd.auto` must not put that kernel under a model: large calls it
+would get run padded to a head dim the MFMA kernels take or, where there is none (D > 256), go to stock SDPA."""
 
 import time
 
@@ -31,7 +31,7 @@ def _time(fn, n=20):
     return best
 
 
-@pytest.mark.parametrize("D", [32, 80, 96])
+@pytest.mark.parametrize("D", [32, 80, 96, 160, 256])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_override_at_other_head_dims_matches_the_oracle_and_is_not_slower_than_stock(D, dtype):
     """`F.scaled_dot_product_attention` on [8, 16, 2048, D] through the override: forward against the fp64 oracle, gradients against
@@ -64,7 +64,7 @@ def test_override_at_other_head_dims_matches_the_oracle_and_is_not_slower_than_s
     assert t_ours <= 1.2 * t_stock, f"D={D}: override {t_ours:.3f} ms vs stock {t_stock:.3f} ms"
 
 
-def test_head_dim_256_goes_to_stock_sdpa_and_tiny_calls_stay_on_the_generic_kernel(monkeypatch):
+def test_head_dims_above_256_go_to_stock_sdpa_and_tiny_calls_stay_on_the_generic_kernel(monkeypatch):
     import flash_attention_amd.auto  # noqa: F401
     from flash_attention_amd._impl import _native
     from oracle import dense_attention_lse
@@ -72,10 +72,21 @@ def test_head_dim_256_goes_to_stock_sdpa_and_tiny_calls_stay_on_the_generic_kern
     calls = []
     real = _native.fwd_strided
     monkeypatch.setattr(_native, "fwd_strided", lambda *a, **kw: (calls.append(a[7]), real(*a, **kw))[1])
-    q, k, v = (torch.randn(2, 4, 1024, 256, device="cuda").bfloat16() for _ in range(3))
+    q, k, v = (torch.randn(2, 4, 1024, 320, device="cuda").bfloat16() for _ in range(3))
     out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
     ref = F.scaled_dot_product_attention.__wrapped__(q, k, v, is_causal=True)
-    assert calls == [] and torch.equal(out, ref), "a large D = 256 call must be stock SDPA's"
+    assert calls == [] and torch.equal(out, ref), "a large D = 320 call must be stock SDPA's"
+    # head_dim 256 is the MFMA kernels' (plan: the 64-key-tile kernel, 4 waves) ...
+    q, k, v = (torch.randn(2, 4, 1024, 256, device="cuda").bfloat16() for _ in range(3))
+    out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+    assert calls == [256] and _native.plan(8, 1024, 256, torch.bfloat16, 1, 1).kernel == 0
+    ref = F.scaled_dot_product_attention.__wrapped__(q.float(), k.float(), v.float(), is_causal=True)
+    torch.testing.assert_close(out.float(), ref, atol=1e-2, rtol=1e-2)
+    # ... but its mask / dropout forms stop at 128: a masked D = 256 call is stock SDPA's
+    calls.clear()
+    mask = torch.ones(1024, 1024, device="cuda", dtype=torch.bool).tril()
+    out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    assert calls == [] and torch.equal(out, F.scaled_dot_product_attention.__wrapped__(q, k, v, attn_mask=mask))
     # the reference's own tiny shape family (t_cpp:245-251: L = 6, D = 2): the generic kernel, exact fp32 arithmetic
     q, k, v = (torch.randn(4, 6, 2, device="cuda") for _ in range(3))
     out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
@@ -85,17 +96,17 @@ def test_head_dim_256_goes_to_stock_sdpa_and_tiny_calls_stay_on_the_generic_kern
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("D", [8, 24, 40, 72, 96, 120])
+@pytest.mark.parametrize("D", [8, 24, 40, 72, 96, 120, 136, 200, 256])
 @pytest.mark.parametrize("B,H,Hkv,L,causal", [(2, 3, 3, 200, True), (1, 4, 2, 333, True), (2, 2, 2, 1024, False), (1, 2, 1, 1500, True)])
 def test_zero_extended_head_dims_through_the_mfma_kernels(dtype, D, B, H, Hkv, L, causal):
-    """fa_fwd / fa_bwd on operands whose rows are D elements wide, D a multiple of 8 below 128 other than 64: the 64-key-tile MFMA
-    kernels run them at head_dim 64 / 128 with the missing columns read as zeros (`FwdParams::Dr`) - no padded copies.  Out, logsumexp
+    """fa_fwd / fa_bwd on operands whose rows are D elements wide, D a multiple of 8 up to 256 other than 64 / 128: the MFMA
+    kernels run them at head_dim 64 / 128 / 256 with the missing columns read as zeros (`FwdParams::Dr`) - no padded copies.  Out, logsumexp
     and all three gradients against the fp64 oracle; ragged L, grouped K/V heads, causal and unmasked."""
     from flash_attention_amd._impl import _native, ops
     from oracle import dense_attention_lse, frozen_randn
 
     p = _native.plan(B * H, L, D, dtype, 1, 1, softmax_scale=D ** -0.5, causal=causal)
-    assert p.kernel in (0, 2, 4, 6), "a 16-bit head dim that is a multiple of 8 below 128 must be served by an MFMA kernel"
+    assert p.kernel in (0, 2, 4, 6), "a 16-bit head dim that is a multiple of 8 up to 256 must be served by an MFMA kernel"
     q = (frozen_randn(SEED + L + D, (B, H, L, D)) * 0.8).to(dtype)
     k = (frozen_randn(SEED + L + D + 1, (B, Hkv, L, D)) * 0.8).to(dtype)
     v = (frozen_randn(SEED + L + D + 2, (B, Hkv, L, D)) * 0.8).to(dtype)
@@ -192,7 +203,7 @@ def test_mask_and_dropout_at_head_dim_96():
         assert torch.isfinite(gg).all() and not bool(bad.any()), f"{name}: {int(bad.sum())} out of tolerance"
 
 
-@pytest.mark.parametrize("D,dtype", [(100, torch.bfloat16), (96, torch.float32)])
+@pytest.mark.parametrize("D,dtype", [(100, torch.bfloat16), (196, torch.bfloat16), (96, torch.float32)])
 def test_padded_head_dims(D, dtype):
     """What the kernels do not zero-extend - a head dim that is no multiple of 8, fp32 off 64 / 128 - runs PADDED on a large call
     (override and packed op): forward against the oracle, gradients finite and shaped."""
