@@ -803,7 +803,8 @@ static hipError_t launch_bwd_t(const BwdParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream) {
-    if (p.D == 256) return dtype == 1 ? launch_bwd_t<__bf16, 256>(p, stream) : launch_bwd_t<_Float16, 256>(p, stream);   // (and 136 .. 248 zero-extended)
+    if (p.D == 192) return dtype == 1 ? launch_bwd_t<__bf16, 192>(p, stream) : launch_bwd_t<_Float16, 192>(p, stream);   // (and 136 .. 184 zero-extended)
+    if (p.D == 256) return dtype == 1 ? launch_bwd_t<__bf16, 256>(p, stream) : launch_bwd_t<_Float16, 256>(p, stream);   // (and 200 .. 248 zero-extended)
     if (dtype == 1) return p.D == 64 ? launch_bwd_t<__bf16, 64>(p, stream) : launch_bwd_t<__bf16, 128>(p, stream);
     return p.D == 64 ? launch_bwd_t<_Float16, 64>(p, stream) : launch_bwd_t<_Float16, 128>(p, stream);
 }

@@ -100,18 +100,18 @@ const Options& options() {
 // wave at head_dim 64, 8 waves at head_dim 128).
 int waves_for_chunk(int64_t want) { return want >= 128 ? 4 : want >= 64 ? 2 : 1; }
 
-// Head dims the MFMA kernels serve: 64 and 128 natively (16-bit and fp32), 256 for 16-bit operands (the 64-key-tile kernels alone: one
-// 4-wave workgroup per CU, fa_fwd_dma.hip / fa_bwd_kernels.hip); for 16-bit operands every other multiple of 8 up to 256 runs ZERO-EXTENDED
-// at the next of the three (FwdParams::Dr: out-of-range LDS-DMA chunks and predicated register loads read the missing columns as zeros,
+// Head dims the MFMA kernels serve: 64 and 128 natively (16-bit and fp32), 192 and 256 for 16-bit operands (the 64-key-tile kernels alone: one
+// workgroup per CU, fa_fwd_dma.hip / fa_bwd_kernels.hip); for 16-bit operands every other multiple of 8 up to 256 runs ZERO-EXTENDED
+// at the next of the four (FwdParams::Dr: out-of-range LDS-DMA chunks and predicated register loads read the missing columns as zeros,
 // stores stop at the true head dim) - the reference's op has no head-dim restriction (FA.cpp:175-195).  Returns 0 when there is no such kernel.
 int64_t kernel_head_dim(int64_t D, int32_t dtype) {
     if (D == 64 || D == 128) return D;
-    if ((dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D <= 256 && D % 8 == 0) return D < 64 ? 64 : D < 128 ? 128 : 256;
+    if ((dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D <= 256 && D % 8 == 0) return D <= 64 ? 64 : D <= 128 ? 128 : D <= 192 ? 192 : 256;
     return 0;
 }
 
 bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* const strides[4]) {
-    if (!(D == 64 || D == 128 || D == 256)) return false;
+    if (!(D == 64 || D == 128 || D == 192 || D == 256)) return false;
     for (int i = 0; i < 4; ++i) {
         if (ptrs[i] && (reinterpret_cast<uintptr_t>(ptrs[i]) & 15)) return false;
         if (strides[i]) {
@@ -263,7 +263,15 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
     const int64_t D = r.D;
     char& which = c->which;
     int &waves = c->waves, &qb = c->qb, &split = c->split;
-    if (D == 256) { which = 'd'; waves = 4; qb = 1; split = 1; return; }      // head_dim 256: the 64-key-tile kernel in its 4-wave form (132 KB of LDS, the whole register file)
+    if (D > 128) {
+        // head_dim 192 / 256: the 64-key-tile kernel alone, one workgroup per CU (99 / 132 KB of LDS).  192 fits 8 waves (225 registers, two
+        // waves per SIMD: [3,128,2048,192] 323 -> 269 us, [3,32,8192,192] 970 -> 753 us = 1 096 TFLOP/s); 256 spills 32 registers in that form and
+        // loses 20-35 % (426 -> 531 us), so it keeps 4 waves with the whole register file unless 8 are forced
+        int w = (D == 192 && r.cq >= 256 && r.L >= 1024 && r.g8 * ((r.L + 255) / 256) >= 256) ? 8 : 4;
+        if (opt.waves == 4 || opt.waves == 8) w = opt.waves;
+        which = 'd'; waves = w; qb = 1; split = 1;
+        return;
+    }
     if (!FA_EXPERIMENTAL && (which == 't' || which == 'P')) which = 'd';      // (not in this build: make EXPERIMENTAL=1)
     if (r.d_only && (which == 'P' || which == 't')) { which = 'd'; qb = 1; split = 1; if (waves > 4) waves = 4; }   // (the experimental kernels do not read a narrower head dim)
     if (r.want32 && r.pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
@@ -290,7 +298,7 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
     int pair = 0;
     {
         const int64_t nq128 = (L + 127) / 128;
-        const bool pair_ok = which == 'd' && r.causal && waves == 4 && qb == 1 && split == 1 && nq128 >= 2 && D != 256;
+        const bool pair_ok = which == 'd' && r.causal && waves == 4 && qb == 1 && split == 1 && nq128 >= 2 && D <= 128;
         // measured (profiles/r03_short/sweep_*.txt): pairs LOSE 2..10 % at L = 1024 .. 4096 (4 resident workgroups per CU already hide each
         // other's prologues; the pair's second tile waits for the first tile's stores at its first barrier) - built-in rule: off
         if (c.table_pair && pair_ok && c.source == 1) pair = 1;          // (a measured row may switch them on)
@@ -623,7 +631,7 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     // everything else fa_fwd serves (fp32, other head dims, unaligned rows) - never the fp32 MFMA kernel, which has no mask path
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     int64_t Dk0 = kernel_head_dim(D, dtype);
-    if (extra && Dk0 == 256) Dk0 = 0;              // (the mask / dropout kernels stop at head_dim 128: their dK/dV form does not fit the register file at 256)
+    if (extra && Dk0 > 128) Dk0 = 0;               // (the mask / dropout kernels stop at head_dim 128: their dK/dV form does not fit the register file at 256)
     const bool wide_ok = !wide_rows && Dk0 != 0 && aligned16(Dk0, elt_size(dtype), ptrs, strides) && L * k_strides[2] < (1ll << 31) && L * v_strides[2] < (1ll << 31);
     const int64_t Dk = wide_ok ? Dk0 : D;          // the head dim the launched kernel runs at (D itself on the generic path)
     const bool mfma16_ok = wide_ok && (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16);
@@ -777,7 +785,7 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
     }
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     if (extra && dtype == FA_DTYPE_F32) mfma = false;       // (the fp32 MFMA kernels have no mask path: generic kernels)
-    if (extra && Dk0 == 256) mfma = false;                  // (nor have the head_dim 256 kernels)
+    if (extra && Dk0 > 128) mfma = false;                   // (nor have the head_dim 192 / 256 kernels)
     if (!mfma && D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic backward supports D <= 1024 (got %lld)", (long long)D);
     if (!mfma && G * L > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     fa::BwdParams p;

@@ -28,6 +28,13 @@
 
 namespace fa {
 
+// K tile rows in LDS: chunk position cp of a row holds the row's 16-byte chunk cp ^ k_swizzle(row) - an XOR inside aligned groups of
+// 8 (head_dim 64: rows are 8 chunks; head_dim 192: 24 = three groups of 8) or 16 chunks (128, 256)
+template <int D>
+__device__ __forceinline__ int k_swizzle(int row) {
+    return D == 64 ? ((row >> 1) & 7) : (D % 128 == 0) ? (row & 15) : (row & 7);
+}
+
 // (the body lives in a __device__ function: the buffer/LDS-DMA builtins do not exist for the host pass,
 // and a __global__ template that names them loses its host-side launch stub)
 //
@@ -154,9 +161,10 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     for (int j = 0; j < PPW; ++j) {
         const int pc = wave + j * NWAVES;
         // K: lane-linear piece = 1024/ROWB rows; LDS chunk position cp of row holds global chunk cp ^ swz(row)
-        const int row = pc * (1024 / ROWB) + lane / (ROWB / 16);
-        const int cp = lane % (ROWB / 16);
-        const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+        // (head_dim 192: a row is 24 chunks, a piece 2 2/3 rows - the piece's 64 chunks are numbered through the tile)
+        const int row = (pc * 64 + lane) / (ROWB / 16);
+        const int cp = (pc * 64 + lane) % (ROWB / 16);
+        const int sw = k_swizzle<D>(row);
         // (a chunk past the true head dim: an offset beyond any descriptor's extent - the DMA writes zeros for it, as for rows past L)
         k_vo[j] = (cp ^ sw) < dchunks ? (unsigned)row * k_slb + ((cp ^ sw) << 4) : 0x80000000u;
         k_dst[j] = pc * 1024;
@@ -195,7 +203,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 
     int k_rd[KS];
     {
-        const int sw = (D == 64) ? ((r >> 1) & 7) : (r & 15);
+        const int sw = k_swizzle<D>(r);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * ROWB + (((2 * ks + h) ^ sw) << 4);
     }
@@ -532,7 +540,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                                : smem_all + wave * (WQ * ROWB);
     static_assert(!PAIR || (NWAVES <= 4 && 2 * WQ * ROWB <= KTILE_B && 2 * WQ * ROWB <= VTILE_B), "pair epilogue slabs must fit K1 / V1");
     constexpr int CPR = D / 8;   // 16-byte chunks per row
-    constexpr int RPI = 64 / CPR;   // rows per store instruction (8 at D=64, 4 at D=128)
+    constexpr int ESW = CPR & -CPR;   // the slab's XOR swizzle stays inside aligned groups of this many chunks (the largest power of two in CPR: 8 at head_dim 192)
     if (wave_active) {
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
@@ -546,15 +554,15 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = (T)(o[b][dt][4 * rg + j] * inv);
                 const int ch = 4 * dt + rg;                                   // chunk holding d = 32dt + 8rg + 4h ..+3
-                *(vec4*)(slab + r * ROWB + ((ch ^ (r & (CPR - 1))) << 4) + 8 * h) = w;
+                *(vec4*)(slab + r * ROWB + ((ch ^ (r & (ESW - 1))) << 4) + 8 * h) = w;
             }
         }
         const int row_b = qrow + 32 * b;
         if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * p.scale + __logf(lt);
 #pragma unroll
-        for (int i = 0; i < 32 / RPI; ++i) {
-            const int rr = i * RPI + lane / CPR, ch = lane % CPR;
-            const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (CPR - 1))) << 4));
+        for (int i = 0; i < CPR / 2; ++i) {                      // 64 chunks per store instruction: 8 rows at D=64, 4 at 128, 2 2/3 at 192, 2 at 256
+            const int rr = (i * 64 + lane) / CPR, ch = (i * 64 + lane) % CPR;
+            const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (ESW - 1))) << 4));
             const int orow = q_row0 + 32 * b + rr;
             if (orow < L && ch < dchunks && (FA_DMA_ABL != 6 || val.x == 0x12345u)) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
         }
@@ -638,20 +646,26 @@ static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, int split,
     return e;
 }
 
-// head_dim 256 (and 136 .. 248 zero-extended): the one form that fits - 4 waves x 32 rows, 64-key tiles: K0 K1 V0 V1 = 132 KB of LDS, one
-// workgroup per CU, 256 VGPRs + the accumulators' overflow in AGPRs (no scratch)
+// head_dim 192 / 256 (and 136 .. 184 / 200 .. 248 zero-extended): one form - 4 waves x 32 rows, 64-key tiles: K0 K1 V0 V1 = 99 / 132 KB of LDS,
+// one workgroup per CU; 234 VGPRs at 192, 256 VGPRs + the accumulators' overflow in AGPRs at 256 (no scratch)
+template <typename T, int D, bool SKIP>
+static hipError_t launch_dma_wide(const FwdParams& p, int waves, int qb, int split, int pair, hipStream_t stream) {
+    if (!((waves == 4 || waves == 8) && qb == 1 && split == 1 && !pair)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles));
+    return waves == 8 ? launch1((const void*)(fa_fwd_dma_kernel<T, D, 8, SKIP, 1, 1>), grid, dim3(512), 0, stream, p)
+                      : launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 1>), grid, dim3(256), 0, stream, p);
+}
 template <typename T, bool SKIP>
-static hipError_t launch_dma_256(const FwdParams& p, int waves, int qb, int split, int pair, hipStream_t stream) {
-    if (!(waves == 4 && qb == 1 && split == 1 && !pair)) return hipErrorInvalidValue;
-    return launch1((const void*)(fa_fwd_dma_kernel<T, 256, 4, SKIP, 1, 1>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
+static hipError_t launch_dma_wide_d(const FwdParams& p, int waves, int qb, int split, int pair, hipStream_t stream) {
+    return p.D == 192 ? launch_dma_wide<T, 192, SKIP>(p, waves, qb, split, pair, stream) : launch_dma_wide<T, 256, SKIP>(p, waves, qb, split, pair, stream);
 }
 
 // waves = waves per kv split group (the workgroup has waves x split); qb = 32-row query blocks per wave (1, or 2 for head_dim 64
 // with 4 waves); split = kv split groups (1; 2 | 4 with 4 waves and qb 1).  The host sized p.nq_tiles for 32 waves qb rows.
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, int split, int pair, hipStream_t stream) {
-    if (p.D == 256) {
-        if (dtype == 1) return launch_dma_256<__bf16, true>(p, waves, qb, split, pair, stream);
-        return p.skipmax ? launch_dma_256<_Float16, true>(p, waves, qb, split, pair, stream) : launch_dma_256<_Float16, false>(p, waves, qb, split, pair, stream);
+    if (p.D > 128) {
+        if (dtype == 1) return launch_dma_wide_d<__bf16, true>(p, waves, qb, split, pair, stream);
+        return p.skipmax ? launch_dma_wide_d<_Float16, true>(p, waves, qb, split, pair, stream) : launch_dma_wide_d<_Float16, false>(p, waves, qb, split, pair, stream);
     }
     if (dtype == 1) {   // bf16: always skip-max
         return p.D == 64 ? launch_dma_w<__bf16, 64, true>(p, waves, qb, split, pair, stream) : launch_dma_w<__bf16, 128, true>(p, waves, qb, split, pair, stream);

@@ -33,8 +33,8 @@ def chunk_heuristic(L: int, D: int):
 
 # Head dims other than 64 / 128.  The reference's op has no head-dim restriction (FA.cpp:175-195; its own tests run D = 2,
 # t_cpp:245-251).  The C ABI serves
-#   * f16 / bf16 with D a multiple of 8 up to 256 through the MFMA kernels themselves: 64, 128 and 256 natively, the others ZERO-EXTENDED
-#     at the next of the three inside the kernels (round 4, `FwdParams::Dr`: out-of-range LDS-DMA chunks and predicated register loads
+#   * f16 / bf16 with D a multiple of 8 up to 256 through the MFMA kernels themselves: 64, 128, 192 and 256 natively, the others ZERO-EXTENDED
+#     at the next of the four inside the kernels (round 4, `FwdParams::Dr`: out-of-range LDS-DMA chunks and predicated register loads
 #     read the missing columns as zeros, stores stop at D - no copies, forward and backward; masks and dropout up to head_dim 128);
 #   * everything else (D > 256, D not a multiple of 8, fp32 off 64 / 128) through the generic kernel: one workgroup per query row, scalar
 #     fp32 arithmetic, 1-2 TFLOP/s - a correctness path that an `import flash_attention_amd.auto` must not silently put

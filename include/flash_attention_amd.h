@@ -78,8 +78,8 @@ enum {
 
 /* hardware tile the request was mapped to (fa_plan) */
 typedef struct fa_plan_t {
-    int32_t kernel;      /* 0 = MFMA kernel, 64-key tiles (bf16/f16, D in {64,128,256}; other multiples of 8 up to 256 run zero-extended
-                                at the next of the three, in this and - up to 128 - in kernels 2, 4, 6), 1 = generic kernel,
+    int32_t kernel;      /* 0 = MFMA kernel, 64-key tiles (bf16/f16, D in {64,128,192,256}; other multiples of 8 up to 256 run zero-extended
+                                at the next of the four, in this and - up to 128 - in kernels 2, 4, 6), 1 = generic kernel,
                             2 = MFMA kernel, software-pipelined 32-key steps,
                             3 = fp32 MFMA kernel (fp32 inputs, D in {64,128}, 16-byte rows),
                             4 = software-pipelined kernel on v_mfma_f32_16x16x32 (bf16/f16, D in {64,128}),
@@ -200,7 +200,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
  *   heads, heads_kv : as in fa_fwd.  With heads_kv < heads (grouped-query attention) k, v, dk and dv have
  *                    G / (heads / heads_kv) groups; dk / dv of a key/value head are the sums over the query heads that
  *                    read it, formed inside ONE workgroup per 128 keys (no expanded K/V, no atomics)   [ABI 3]
- * f16/bf16/fp32 with D in {64, 128}, f16/bf16 with D any other multiple of 8 up to 256 (zero-extended at 64 / 128 / 256 inside
+ * f16/bf16/fp32 with D in {64, 128}, f16/bf16 with D any other multiple of 8 up to 256 (zero-extended at 64 / 128 / 192 / 256 inside
  * the kernels) and 16-byte aligned rows run the MFMA kernels; every other case (other D <= 1024, unaligned rows) runs generic
  * fp32-arithmetic kernels.
  * Deterministic: no gradient is accumulated across workgroups.

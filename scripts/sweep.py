@@ -18,6 +18,7 @@ CFG = {"cfg2": (128, 4096, 64, torch.bfloat16, 8, 8), "cfg2h": (128, 4096, 64, t
        "small1": (8, 2048, 64, torch.bfloat16, 1, 1), "small2": (16, 1024, 64, torch.bfloat16, 1, 1),
        "small3": (32, 4096, 64, torch.bfloat16, 1, 1), "small4": (12, 1024, 64, torch.bfloat16, 1, 1),
        "gpt": (96, 1024, 64, torch.bfloat16, 1, 1), "long64": (16, 32768, 64, torch.bfloat16, 16, 16), "g64l8k": (64, 8192, 64, torch.bfloat16, 8, 8), "g32l16k": (32, 16384, 64, torch.bfloat16, 8, 8), "g32l4k": (32, 4096, 64, torch.bfloat16, 8, 8), "g256l2k": (256, 2048, 64, torch.bfloat16, 8, 8), "d128l2k": (128, 2048, 128, torch.bfloat16, 8, 8), "d128l8k": (32, 8192, 128, torch.bfloat16, 8, 8), "d96l8k": (32, 8192, 96, torch.bfloat16, 8, 8), "d96l32k": (16, 32768, 96, torch.bfloat16, 16, 16), "d32l8k": (64, 8192, 32, torch.bfloat16, 8, 8), "d128g16": (16, 4096, 128, torch.bfloat16, 8, 8), "d128h": (64, 4096, 128, torch.float16, 8, 8), "g64l4k": (64, 4096, 64, torch.bfloat16, 8, 8), "small5": (4, 8192, 128, torch.bfloat16, 1, 1),
+       "d192": (128, 2048, 192, torch.bfloat16, 1, 1), "d256": (128, 2048, 256, torch.bfloat16, 1, 1), "d256l8k": (32, 8192, 256, torch.bfloat16, 1, 1), "d192l8k": (32, 8192, 192, torch.bfloat16, 1, 1), "d256h": (128, 2048, 256, torch.float16, 1, 1),
        "g64l1k": (64, 1024, 64, torch.bfloat16, 1, 1), "g48l2k": (48, 2048, 64, torch.bfloat16, 1, 1), "g24l4k": (24, 4096, 64, torch.bfloat16, 1, 1),
        "g96l1kd128": (96, 1024, 128, torch.bfloat16, 1, 1), "g128l1k": (128, 1024, 64, torch.bfloat16, 1, 1), "g192l1k": (192, 1024, 64, torch.bfloat16, 1, 1)}
 args = sys.argv[1:]

@@ -73,7 +73,7 @@ int main() {
             for (const Ov& o : ov) EXPECT(fa_debug_set_option(o.name, o.value) == FA_OK);
             for (int64_t G : {1, 7, 8, 12, 96, 128, 2048})
                 for (int64_t L : {1, 6, 32, 100, 256, 1000, 1024, 2048, 4096, 32768})
-                    for (int64_t D : {2, 64, 96, 128, 200, 256})
+                    for (int64_t D : {2, 64, 96, 128, 160, 200, 256})
                         for (int dt : {FA_DTYPE_F16, FA_DTYPE_BF16, FA_DTYPE_F32})
                             for (int32_t nc : {1, 2, 8, 64})
                                 for (float scale : {1.0f, 0.125f})
@@ -82,14 +82,14 @@ int main() {
                                         fa_plan_t pl;
                                         if (fa_plan(G, L, D, dt, nc, nc == 8 ? 4 : nc, scale, causal, &pl) != FA_OK) { EXPECT(L % (nc == 8 ? 4 : nc) != 0); continue; }
                                         ++checked;
-                                        const bool mfma16 = (D == 64 || D == 128 || D == 96 || D == 200 || D == 256) && dt != FA_DTYPE_F32;    // (96 / 200: zero-extended at 128 / 256)
-                                        const int64_t Dk = D == 96 ? 128 : D == 200 ? 256 : D;
+                                        const bool mfma16 = (D == 64 || D == 128 || D == 96 || D == 160 || D == 200 || D == 256) && dt != FA_DTYPE_F32;    // (96 / 160 / 200: zero-extended at 128 / 192 / 256)
+                                        const int64_t Dk = D == 96 ? 128 : D == 160 ? 192 : D == 200 ? 256 : D;
                                         const int64_t chunk = L / nc;
                                         EXPECT(pl.grid >= 1 && pl.grid <= 0x7fffffffll && pl.waves >= 1 && pl.sched >= 1 && pl.block_q >= 1 && pl.block_kv >= 1);
                                         EXPECT(pl.lds_bytes > 0 && pl.lds_bytes <= 160 * 1024);                  // one workgroup must fit a CU's LDS
                                         EXPECT(pl.chunk_q == chunk);
                                         if (!mfma16) { EXPECT(pl.kernel == 1 || (pl.kernel == 3 && (D == 64 || D == 128))); continue; }
-                                        if (Dk == 256) EXPECT(pl.kernel == 0 && pl.waves == 4 && pl.qb == 1 && pl.block_q == 128 && !pl.pair);   // one form only, whatever was forced
+                                        if (Dk > 128) EXPECT(pl.kernel == 0 && (pl.waves == 4 || pl.waves == 8) && pl.qb == 1 && pl.block_q == 32 * pl.waves && !pl.pair && pl.lds_bytes == (Dk == 192 ? 99072 : 132096));   // the 64-key-tile kernel, unsplit, whatever was forced
                                         EXPECT(pl.kernel == 0 || pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 6);   // nothing experimental in this build
                                         EXPECT(pl.qb == 1 || pl.qb == 2);
                                         EXPECT(pl.waves == 1 || pl.waves == 2 || pl.waves == 4 || pl.waves == 8 || pl.waves == 16);
@@ -105,7 +105,7 @@ int main() {
                                         }
                                         if (pl.qb == 2) EXPECT(Dk == 64 && (pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 0) && pl.block_q == 256);
                                         // an unforced plan honours the q chunk as an upper bound on the workgroup's rows
-                                        if (ov.empty()) EXPECT(pl.block_q <= (chunk > 32 ? chunk : 32) || pl.kernel == 6 || Dk == 256);   // (head_dim 256 has the one 128-row form)
+                                        if (ov.empty()) EXPECT(pl.block_q <= (chunk > 32 ? chunk : 32) || pl.kernel == 6 || Dk > 128);   // (head_dim 192 / 256 have the one 128-row form)
                                         // the grid covers every (group, q tile): 8-aligned groups x tiles (pairs: two tiles per workgroup)
                                         const int64_t g8 = (G + 7) / 8 * 8, tiles = (L + pl.block_q - 1) / pl.block_q;
                                         EXPECT(pl.grid == (pl.pair ? g8 * ((tiles + 1) / 2) : g8 * tiles));

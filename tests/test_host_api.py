@@ -226,6 +226,8 @@ def _check_builtin_rules(native):
     p256 = native.plan(4, 256, 256, torch.bfloat16, 1, 1)    # head_dim 256 (16-bit): the 64-key-tile kernel's 4-wave form, 132 KB of LDS
     assert (p256.kernel, p256.block_q, p256.block_kv, p256.waves, p256.qb, p256.pair) == (0, 128, 64, 4, 1, 0) and p256.lds_bytes == 132096
     assert native.plan(4, 256, 200, torch.float16, 1, 1).kernel == 0       # ... and the multiples of 8 below it, zero-extended
+    p192 = native.plan(4, 256, 160, torch.float16, 1, 1)                   # ... 136 .. 192 at head_dim 192: 99 KB of LDS
+    assert (p192.kernel, p192.block_q, p192.waves, p192.lds_bytes) == (0, 128, 4, 2 * 64 * 192 * 2 + 2 * 6 * (64 * 64 + 64))
     assert native.plan(4, 256, 256, torch.float32, 1, 1).kernel == 1       # fp32: 64 / 128 only
     assert native.plan(4, 256, 264, torch.bfloat16, 1, 1).kernel == 1
 
