@@ -108,6 +108,41 @@ def fuzz(cases, seed, log=print):
                   f"max(d - tol)={excess:.3e} max|dLSE|={dl.max().item():.3e} (base LSE there {base_lse.flatten()[dl.argmax()].item():.3f}) finite={bool(torch.isfinite(out).all())}")
       if case % 20 == 0:
           log(f"case {case}: B={B} H={H} L={L} D={D} {dt} ok so far, bad={bad}")
+  # head dims above 128 (native at 192 / 256, the multiples of 8 between zero-extended): the 64-key-tile kernel with 4 and with 8 waves against each
+  # other and, for short sequences, the fp64 oracle
+  for case in range(max(2, cases // 3)):
+      D = rng.choice([136, 160, 192, 192, 200, 224, 256, 256])
+      L = rng.choice([rng.randint(1, 300), rng.randint(1, 1500), rng.randint(1500, 3000)])
+      B, H = rng.randint(1, 2), rng.randint(1, 4)
+      dt = rng.choice([torch.bfloat16, torch.float16])
+      scale = rng.choice([0.5, D ** -0.5])
+      amp = rng.choice([0.3, 1.0]) * (0.25 if scale == 0.5 else 1.0)
+      causal = rng.random() < 0.7
+      Hkv = rng.choice([h for h in range(1, H + 1) if H % h == 0]) if rng.random() < 0.3 else H
+      torch.manual_seed(20_000 + case)
+      if rng.random() < 0.5 and Hkv == H:
+          x = (torch.randn(B, L, 3, H, D, device="cuda") * amp).to(dt)
+          q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+      else:
+          q = (torch.randn(B, H, L, D, device="cuda") * amp).to(dt)
+          k, v = ((torch.randn(B, Hkv, L, D, device="cuda") * amp).to(dt) for _ in range(2))
+      base, base_lse = run(q, k, v, H, scale, {"waves": 4, "sched": 1}, causal)
+      ref = None
+      if L <= 700:
+          ref, ref_lse = dense_attention_lse(q.cpu(), k.cpu(), v.cpu(), scale=scale, causal=causal)
+      for env in ({}, {"waves": 8, "sched": rng.choice([1, 2, 8])}, {"waves": 4, "sched": rng.choice([2, 8])}):
+          out, lse = run(q, k, v, H, scale, env, causal)
+          ok = bool(torch.isfinite(out).all()) and bool(((out.float() - base.float()).abs() <= 1e-2 * (1 if dt == torch.bfloat16 else 0.1) + 2.0 ** -6 * base.float().abs()).all()) \
+              and bool(((lse - base_lse).abs() <= 6e-3 + 1e-4 * base_lse.abs()).all())
+          if ref is not None:
+              e = (out.cpu().double() - ref).abs()
+              el = (lse.cpu().double() - ref_lse.reshape(B * H, L)).abs()
+              ok = ok and bool((e <= 1e-2 + 1e-2 * ref.abs()).all()) and bool((el <= (6e-3 if dt == torch.bfloat16 else 2e-3) + 1e-4 * ref_lse.reshape(B * H, L).abs()).all())
+          if not ok:
+              bad += 1
+              log(f"MISMATCH wide case {case}: B={B} H={H} Hkv={Hkv} L={L} D={D} {dt} scale={scale:.3g} causal={causal} knobs={env} max|d|={(out.float() - base.float()).abs().max().item():.3e}")
+      if case % 20 == 0:
+          log(f"wide case {case}: B={B} H={H} L={L} D={D} {dt} ok so far, bad={bad}")
   # fp32 inputs: the fp32 MFMA kernel against the generic kernel (FA_AMD_F32=generic) and the oracle
   for case in range(max(1, cases // 5)):
       D = rng.choice([64, 128])
@@ -134,7 +169,7 @@ def fuzz(cases, seed, log=print):
   # autograd through the fp64 oracle (MFMA kernels for 16-bit and fp32 at head_dim 64 / 128, generic kernels otherwise)
   from flash_attention_amd._impl import ops
   for case in range(max(2, cases // 6)):
-      D = rng.choice([64, 64, 128, 128, 24, 80])
+      D = rng.choice([64, 64, 128, 128, 24, 80, 160, 192, 256])
       L = rng.choice([rng.randint(1, 130), rng.randint(1, 420)])
       G = rng.randint(1, 6)
       dt = rng.choice([torch.bfloat16, torch.float16, torch.float32])
