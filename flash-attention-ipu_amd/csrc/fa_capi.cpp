@@ -100,8 +100,8 @@ const Options& options() {
 // wave at head_dim 64, 8 waves at head_dim 128).
 int waves_for_chunk(int64_t want) { return want >= 128 ? 4 : want >= 64 ? 2 : 1; }
 
-// Head dims the MFMA kernels serve: 64 and 128 natively (16-bit and fp32), 192 and 256 for 16-bit operands (the 64-key-tile kernels alone: one
-// workgroup per CU, fa_fwd_dma.hip / fa_bwd_kernels.hip); for 16-bit operands every other multiple of 8 up to 256 runs ZERO-EXTENDED
+// Head dims the MFMA kernels serve: 64 and 128 natively (16-bit and fp32), 192 and 256 for 16-bit operands (one workgroup per CU: the 64-key-tile
+// kernels, fa_fwd_dma.hip / fa_bwd_kernels.hip, and at 256 the pipelined forward's 4-wave form); for 16-bit operands every other multiple of 8 up to 256 runs ZERO-EXTENDED
 // at the next of the four (FwdParams::Dr: out-of-range LDS-DMA chunks and predicated register loads read the missing columns as zeros,
 // stores stop at the true head dim) - the reference's op has no head-dim restriction (FA.cpp:175-195).  Returns 0 when there is no such kernel.
 int64_t kernel_head_dim(int64_t D, int32_t dtype) {
@@ -269,7 +269,12 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
         // loses 20-35 % (426 -> 531 us), so it keeps 4 waves with the whole register file unless 8 are forced
         int w = (D == 192 && r.cq >= 256 && r.L >= 1024 && r.g8 * ((r.L + 255) / 256) >= 256) ? 8 : 4;
         if (opt.waves == 4 || opt.waves == 8) w = opt.waves;
-        which = 'd'; waves = w; qb = 1; split = 1;
+        // 256 with the skip-max arithmetic from L = 1024 on: the software-pipelined kernel's 4-wave form (133 KB of rings; one wave per SIMD needs the
+        // hand-ordered step to keep the matrix pipe fed: [3,128,2048,256] 428 -> 362 us, [3,32,8192,256] 1 478 -> 1 191 us = 923 TFLOP/s)
+        bool pipe256 = D == 256 && r.pipe_ok && r.L >= 1024 && r.cq >= 128;
+        if (opt.kernel == 'd' || opt.waves == 8) pipe256 = false;
+        if (opt.kernel == 'p' && D == 256 && r.pipe_ok) pipe256 = true;
+        which = pipe256 ? 'p' : 'd'; waves = pipe256 ? 4 : w; qb = 1; split = 1;
         return;
     }
     if (!FA_EXPERIMENTAL && (which == 't' || which == 'P')) which = 'd';      // (not in this build: make EXPERIMENTAL=1)

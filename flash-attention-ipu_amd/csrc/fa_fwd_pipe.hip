@@ -948,6 +948,14 @@ static hipError_t launch_pipe_w(const FwdParams& p, int waves, int qb, hipStream
 // callers guarantee: D in {64, 128}, waves in {1, 2, 4} (or 8 at D = 128), skip-max arithmetic wanted (bf16, or f16 with p.skipmax);
 // qb = 32-row query blocks per wave (2 only for D = 64 with 4 waves; the host sized p.nq_tiles for it)
 hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream) {
+    if (p.D == 256) {   // head_dim 256 (and 200 .. 248 zero-extended): 4 waves x 32 rows, one workgroup per CU (133 KB of rings)
+        if (waves != 4 || qb != 1) return hipErrorInvalidValue;
+        const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles));
+        if (dtype == 1) return p.causal ? launch1((const void*)(fa_fwd_pipe_kernel<__bf16, 256, 4, 1, true>), grid, dim3(256), 0, stream, p)
+                                        : launch1((const void*)(fa_fwd_pipe_kernel<__bf16, 256, 4, 1, false>), grid, dim3(256), 0, stream, p);
+        return p.causal ? launch1((const void*)(fa_fwd_pipe_kernel<_Float16, 256, 4, 1, true>), grid, dim3(256), 0, stream, p)
+                        : launch1((const void*)(fa_fwd_pipe_kernel<_Float16, 256, 4, 1, false>), grid, dim3(256), 0, stream, p);
+    }
     if (dtype == 1) return p.D == 64 ? launch_pipe_w<__bf16, 64>(p, waves, qb, stream) : launch_pipe_w<__bf16, 128>(p, waves, qb, stream);
     return p.D == 64 ? launch_pipe_w<_Float16, 64>(p, waves, qb, stream) : launch_pipe_w<_Float16, 128>(p, waves, qb, stream);
 }

@@ -89,7 +89,8 @@ int main() {
                                         EXPECT(pl.lds_bytes > 0 && pl.lds_bytes <= 160 * 1024);                  // one workgroup must fit a CU's LDS
                                         EXPECT(pl.chunk_q == chunk);
                                         if (!mfma16) { EXPECT(pl.kernel == 1 || (pl.kernel == 3 && (D == 64 || D == 128))); continue; }
-                                        if (Dk > 128) EXPECT(pl.kernel == 0 && (pl.waves == 4 || pl.waves == 8) && pl.qb == 1 && pl.block_q == 32 * pl.waves && !pl.pair && pl.lds_bytes == (Dk == 192 ? 99072 : 132096));   // the 64-key-tile kernel, unsplit, whatever was forced
+                                        if (Dk > 128) EXPECT(((pl.kernel == 0 && pl.lds_bytes == (Dk == 192 ? 99072 : 132096)) || (pl.kernel == 2 && Dk == 256 && pl.waves == 4 && pl.skipmax == 1 && pl.lds_bytes == 133136))
+                                                            && (pl.waves == 4 || pl.waves == 8) && pl.qb == 1 && pl.block_q == 32 * pl.waves && !pl.pair);   // the 64-key-tile kernel unsplit, or (256, skip-max) the pipelined kernel's 4-wave form - whatever was forced
                                         EXPECT(pl.kernel == 0 || pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 6);   // nothing experimental in this build
                                         EXPECT(pl.qb == 1 || pl.qb == 2);
                                         EXPECT(pl.waves == 1 || pl.waves == 2 || pl.waves == 4 || pl.waves == 8 || pl.waves == 16);

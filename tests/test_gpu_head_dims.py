@@ -76,10 +76,10 @@ def test_head_dims_above_256_go_to_stock_sdpa_and_tiny_calls_stay_on_the_generic
     out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
     ref = F.scaled_dot_product_attention.__wrapped__(q, k, v, is_causal=True)
     assert calls == [] and torch.equal(out, ref), "a large D = 320 call must be stock SDPA's"
-    # head_dim 256 is the MFMA kernels' (plan: the 64-key-tile kernel, 4 waves) ...
+    # head_dim 256 is the MFMA kernels' (plan: the pipelined kernel, 4 waves) ...
     q, k, v = (torch.randn(2, 4, 1024, 256, device="cuda").bfloat16() for _ in range(3))
     out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
-    assert calls == [256] and _native.plan(8, 1024, 256, torch.bfloat16, 1, 1).kernel == 0
+    assert calls == [256] and _native.plan(8, 1024, 256, torch.bfloat16, 1, 1, softmax_scale=1 / 16).kernel == 2
     ref = F.scaled_dot_product_attention.__wrapped__(q.float(), k.float(), v.float(), is_causal=True)
     torch.testing.assert_close(out.float(), ref, atol=1e-2, rtol=1e-2)
     # ... but its mask / dropout forms stop at 128: a masked D = 256 call is stock SDPA's
@@ -181,8 +181,9 @@ def test_zero_extended_head_dims_through_every_kernel_that_reads_them(knobs, ker
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("waves", [4, 8])
-@pytest.mark.parametrize("D,G,L,causal", [(192, 2, 1000, True), (152, 3, 2304, True), (256, 2, 1000, True), (208, 1, 2304, False), (192, 9, 300, False)])
+@pytest.mark.parametrize("waves", [4, 8, "pipe"])
+@pytest.mark.parametrize("D,G,L,causal", [(192, 2, 1000, True), (152, 3, 2304, True), (256, 2, 1000, True), (208, 1, 2304, False), (192, 9, 300, False), (256, 9, 300, False),
+                                          (232, 2, 1333, True)])
 def test_head_dims_192_and_256_in_both_workgroup_forms(knobs, dtype, waves, D, G, L, causal):
     """head_dim 192 / 256 (and what runs zero-extended at them) through the 64-key-tile kernel with 4 and with 8 waves (192: the rule's
     choice from 256 workgroups on; 256: forced only - it spills there), unscaled f16 with the exact row max included: out and logsumexp
@@ -190,10 +191,17 @@ def test_head_dims_192_and_256_in_both_workgroup_forms(knobs, dtype, waves, D, G
     from flash_attention_amd._impl import _native
     from oracle import dense_attention_lse, frozen_randn
 
-    knobs.set("waves", waves)
-    scale = D ** -0.5 if dtype == torch.bfloat16 else 0.5     # (f16 at scale 0.5 > 1/4: the exact-max arithmetic)
+    pipe = waves == "pipe"      # the software-pipelined kernel's 4-wave form: head_dim 256 (and 200 .. 248 at it), skip-max arithmetic only
+    if pipe and D <= 192:
+        pytest.skip("no pipelined form at head_dim 192")
+    scale = D ** -0.5 if (dtype == torch.bfloat16 or pipe) else 0.5     # (f16 at scale 0.5 > 1/4: the exact-max arithmetic)
+    if pipe:
+        knobs.set("kernel", "pipe")
+    else:
+        knobs.set("kernel", "dma")
+        knobs.set("waves", waves)
     p = _native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale, causal=causal)
-    assert (p.kernel, p.waves, p.block_q, p.qb) == (0, waves, 32 * waves, 1)
+    assert (p.kernel, p.waves, p.block_q, p.qb) == ((2, 4, 128, 1) if pipe else (0, waves, 32 * waves, 1))
     x = (frozen_randn(SEED + 41 * L + D, (3, G, L, D)) * (0.8 if dtype == torch.bfloat16 else 0.3)).to(dtype)
     ref, ref_lse = dense_attention_lse(x[0][None].double(), x[1][None].double(), x[2][None].double(), scale=scale, causal=causal)
     q, k, v = x.cuda()
@@ -205,7 +213,7 @@ def test_head_dims_192_and_256_in_both_workgroup_forms(knobs, dtype, waves, D, G
     torch.cuda.synchronize()
     assert bool((buf[G * L * D:] == 7.0).all()), "stores past the true head dim"
     err = (out.cpu().double() - ref[0]).abs()
-    assert bool((err <= 1e-2 + 1e-2 * ref[0].abs()).all()), f"{waves} waves D={D} {dtype}: max|d|={err.max().item():.3e}"
+    assert bool((err <= 1e-2 + 1e-2 * ref[0].abs()).all()), f"{waves} D={D} {dtype}: max|d|={err.max().item():.3e}"
     torch.testing.assert_close(lse.cpu().double(), ref_lse[0], atol=6e-3, rtol=1e-4)
 
 

@@ -223,7 +223,10 @@ def _check_builtin_rules(native):
     p96 = native.plan(4, 256, 96, torch.bfloat16, 1, 1)      # 16-bit, a multiple of 8 below 128: zero-extended at 128 by the 64-key-tile MFMA kernel
     assert (p96.kernel, p96.block_kv, p96.qb) == (0, 64, 1)
     assert native.plan(4, 256, 100, torch.bfloat16, 1, 1).kernel == 1      # not a multiple of 8: generic
-    p256 = native.plan(4, 256, 256, torch.bfloat16, 1, 1)    # head_dim 256 (16-bit): the 64-key-tile kernel's 4-wave form, 132 KB of LDS
+    p256 = native.plan(4, 256, 256, torch.bfloat16, 1, 1)    # head_dim 256 (16-bit), short: the 64-key-tile kernel's 4-wave form, 132 KB of LDS
+    p256p = native.plan(64, 2048, 256, torch.bfloat16, 1, 1)  # ... from L = 1024 on (skip-max arithmetic): the pipelined kernel's 4-wave form
+    assert (p256p.kernel, p256p.block_q, p256p.block_kv, p256p.waves, p256p.qb, p256p.lds_bytes) == (2, 128, 32, 4, 1, 133136)
+    assert native.plan(64, 2048, 256, torch.float16, 1, 1).kernel == 0     # (unscaled f16 keeps the row max: the 64-key-tile kernel)
     assert (p256.kernel, p256.block_q, p256.block_kv, p256.waves, p256.qb, p256.pair) == (0, 128, 64, 4, 1, 0) and p256.lds_bytes == 132096
     assert native.plan(4, 256, 200, torch.float16, 1, 1).kernel == 0       # ... and the multiples of 8 below it, zero-extended
     p192 = native.plan(4, 256, 160, torch.float16, 1, 1)                   # ... 136 .. 192 at head_dim 192: 99 KB of LDS
