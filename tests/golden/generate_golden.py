@@ -17,6 +17,8 @@ Vectors:
       (nq,nk) the heuristic chose, incl. the heuristic table of 8(c)
   G5  larger shapes from the frozen-stream generator -> sampled rows + fp64 checksums
   G6  error-message strings of the 4 ValueErrors and 5 NotImplementedErrors
+  G7  head dims other than 64 / 128 (the op has no head-dim restriction, FA.cpp:175-195): G=2, L=512, D in {32, 96, 192, 256}, frozen-stream inputs
+      scaled by 0.5, fp32 / bf16 / f16 -> sampled rows + fp64 checksums          (`python tests/golden/generate_golden.py g7` writes this file only)
 """
 
 import importlib.util
@@ -59,10 +61,36 @@ def load_reference():
     return poptorch, mods
 
 
+G7_DIMS = (32, 96, 192, 256)
+G7_SHAPE = (2, 512)      # G, L
+
+
+def generate_g7(fa):
+    g7 = {}
+    G, L = G7_SHAPE
+    rows = sorted({0, 1, 31, 32, 63, 64, 255, 256, L - 1})
+    for D in G7_DIMS:
+        x = frozen_randn(SEED + 7 + D, (3, G, L, D)) * 0.5
+        for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
+            o = fa(x.to(dt), 2, 2).double()
+            g7[f"D{D}_{dt_name}_rows"] = o[:, rows, :].numpy()
+            g7[f"D{D}_{dt_name}_sum"] = np.array(o.sum().item())
+            g7[f"D{D}_{dt_name}_abssum"] = np.array(o.abs().sum().item())
+    g7["rowidx"] = np.array(rows)
+    g7["dims"] = np.array(G7_DIMS)
+    g7["shape"] = np.array(G7_SHAPE)
+    np.savez_compressed(HERE / "g7_head_dims.npz", **g7)
+
+
 def main():
     orig_sdpa = torch.nn.functional.scaled_dot_product_attention
     poptorch, mods = load_reference()
     fa = mods["flash_attention_qkv_packed"].flash_attention_qkv_packed
+    if sys.argv[1:] == ["g7"]:
+        generate_g7(fa)
+        torch.nn.functional.scaled_dot_product_attention = orig_sdpa
+        print("wrote g7_head_dims.npz")
+        return
     patched = torch.nn.functional.scaled_dot_product_attention
     assert patched.__wrapped__ is orig_sdpa
 
@@ -130,6 +158,9 @@ def main():
         g5[f"{tag}_rowidx"] = np.array(rows)
         g5[f"{tag}_shape"] = np.array([G, L, D])
     np.savez_compressed(HERE / "g5_large_sampled.npz", **g5)
+
+    # ---- G7: head dims other than 64 / 128
+    generate_g7(fa)
 
     # ---- G6: error strings
     errs = {"ValueError": [], "NotImplementedError": []}

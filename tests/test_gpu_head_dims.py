@@ -180,6 +180,32 @@ def test_zero_extended_head_dims_through_every_kernel_that_reads_them(knobs, ker
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=6e-3, rtol=1e-4)
 
 
+def test_golden_g7_head_dims_from_the_reference():
+    """tests/golden/g7_head_dims.npz: outputs of the reference's own Python (generate_golden.py) at D = 32, 96 (zero-extended here), 192, 256
+    (native here), G = 2, L = 512, unscaled packed op.  fp32 inputs run the generic kernel (exact arithmetic: 1e-4); the 16-bit calls run the
+    MFMA kernels and sit within the reference 16-bit CPU path's own rounding noise (it rounds the scores to 16 bits) + this repo's tolerance."""
+    import pathlib
+
+    import numpy as np
+
+    import flash_attention_amd as fa
+    from flash_attention_amd._impl import _native
+    from oracle import frozen_randn
+
+    g = np.load(pathlib.Path(__file__).parent / "golden" / "g7_head_dims.npz")
+    G, L = (int(x) for x in g["shape"])
+    rows = g["rowidx"]
+    for D in (int(d) for d in g["dims"]):
+        x = frozen_randn(SEED + 7 + D, (3, G, L, D)) * 0.5
+        o32 = fa.flash_attention_qkv_packed(x.cuda(), 2, 2).cpu().double()
+        assert (o32[:, rows, :] - torch.from_numpy(g[f"D{D}_f32_rows"])).abs().max().item() <= 1e-4
+        assert abs(o32.sum().item() - float(g[f"D{D}_f32_sum"])) <= 1e-1
+        for dn, dt, bound in (("f16", torch.float16, 2e-2), ("bf16", torch.bfloat16, 1e-1)):
+            assert _native.plan(G, L, D, dt, 2, 2).kernel in (0, 2, 4, 6)
+            o = fa.flash_attention_qkv_packed(x.to(dt).cuda(), 2, 2).cpu().double()
+            assert (o[:, rows, :] - torch.from_numpy(g[f"D{D}_{dn}_rows"])).abs().max().item() <= bound, (D, dn)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("waves", [4, 8, "pipe"])
 @pytest.mark.parametrize("D,G,L,causal", [(192, 2, 1000, True), (152, 3, 2304, True), (256, 2, 1000, True), (208, 1, 2304, False), (192, 9, 300, False), (256, 9, 300, False),

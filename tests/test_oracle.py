@@ -102,6 +102,22 @@ def test_dense_matches_golden_g5_sampled_rows(golden_dir):
             assert (o64[:, rows, :] - torch.from_numpy(g[f"{tag}_{dt_name}_rows"])).abs().max().item() < noise
 
 
+def test_dense_matches_golden_g7_head_dims(golden_dir):
+    """G7: the reference's own Python at head dims other than 64 / 128 (32, 96, 192, 256: its op has no head-dim restriction, FA.cpp:175-195) -
+    pins the oracle where the round-4 kernels run zero-extended (32, 96) or at the new native dims (192, 256)."""
+    g = np.load(golden_dir / "g7_head_dims.npz")
+    G, L = (int(x) for x in g["shape"])
+    rows = g["rowidx"]
+    for D in (int(d) for d in g["dims"]):
+        x = frozen_randn(SEED + 7 + D, (3, G, L, D)) * 0.5
+        out = dense_causal_attention(x, compute_dtype=torch.float32)
+        np.testing.assert_allclose(out[:, rows, :].double().numpy(), g[f"D{D}_f32_rows"], atol=1e-5, rtol=1e-5)
+        assert abs(out.double().sum().item() - float(g[f"D{D}_f32_sum"])) < 1e-2
+        for dt_name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+            o16 = dense_causal_attention(x.to(dt))      # same-dtype oracle == the reference's 16-bit CPU path, bit for bit
+            assert torch.equal(o16[:, rows, :].double(), torch.from_numpy(g[f"D{D}_{dt_name}_rows"]))
+
+
 def test_heuristic_table(golden_dir):
     meta = json.loads((golden_dir / "g6_meta.json").read_text())
     for key, (nq, nk) in meta["heuristic"].items():
