@@ -139,6 +139,17 @@ def _scaled_dot_product_attention_amd(
         raise NotImplementedError("flash_attention_ipu does not currently support non-zero dropout_p")
     if not is_causal and not on_device:
         raise NotImplementedError("flash_attention_ipu does not currently support is_causal=False")
+    # Different sequence lengths with the same batch / head layout (a decode step against a key/value cache, cross-attention): the reference
+    # raises for every query.shape != key.shape (sdpa.py:33-37) and so does this override off the GPU; ON the GPU such a call is stock SDPA's
+    # (no kernel here takes L_q != L_kv), so that `import flash_attention_amd.auto` does not break a model's generation loop.
+    if (on_device and key.shape == value.shape and query.ndim == key.ndim and query.shape[:-2] == key.shape[:-2]
+            and query.shape[-1] == key.shape[-1] and query.shape[-2] != key.shape[-2]):
+        kw = {}
+        if scale is not None:
+            kw["scale"] = scale
+        if enable_gqa:
+            kw["enable_gqa"] = enable_gqa
+        return orig_fn(query, key, value, attn_mask, dropout_p, is_causal, **kw)
     gqa = query.shape != key.shape
     # (grouped K/V heads are served only when the caller asks for them, as stock SDPA does: without enable_gqa=True a
     # query.shape != key.shape call raises like the reference instead of silently computing something stock SDPA rejects)

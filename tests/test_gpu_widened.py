@@ -153,6 +153,31 @@ def test_sdpa_override_serves_the_widened_modes():
         patched(q, k.repeat_interleave(2, 1), v.repeat_interleave(2, 1), is_causal=True)
 
 
+def test_different_sequence_lengths_go_to_stock_sdpa_on_the_gpu_and_raise_off_it():
+    """A decode step against a key/value cache (L_q = 1) and cross-attention (L_q != L_kv): the reference rejects every query.shape !=
+    key.shape (scaled_dot_product_attention.py:33-37); off the GPU so does the override, on the GPU the call is stock SDPA's - importing
+    the override must not break a generation loop."""
+    import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl import _native
+
+    patched = F.scaled_dot_product_attention
+    stock = patched.__wrapped__
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    k, v = (torch.randn(2, 4, 300, 64, device="cuda", generator=gen).bfloat16() for _ in range(2))
+    calls = []
+    real = _native.fwd_strided
+    _native.fwd_strided = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    try:
+        for Lq, causal in ((1, False), (7, False), (300 - 8, True)):
+            q = torch.randn(2, 4, Lq, 64, device="cuda", generator=gen).bfloat16()
+            assert torch.equal(patched(q, k, v, is_causal=causal), stock(q, k, v, is_causal=causal))
+    finally:
+        _native.fwd_strided = real
+    assert calls == []
+    with pytest.raises(NotImplementedError, match="Grouped- or Multi-query"):
+        patched(torch.zeros(2, 4, 1, 64), k.cpu(), v.cpu(), is_causal=True)
+
+
 @pytest.mark.parametrize("scale", [0.0, -0.125])
 def test_sdpa_nonpositive_scale_goes_to_stock_sdpa(scale):
     """A softmax scale <= 0 is outside what the kernels compute (fixed reference max, exp2 of scale*log2e*s): the
