@@ -292,13 +292,32 @@ def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
     per_call = sorted(a.elapsed_time(b) for a, b in spans)
     attn_ms = layers * per_call[len(per_call) // 2]          # 12 calls per step x the median call
     stock_ms = run(steps, patched.__wrapped__)
+    # the same step captured once in a HIP graph and replayed (the override's launches are capture-safe: caller's stream, no host sync):
+    # what a serving loop would run; a failed capture only drops the field
+    graph_ms = None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fwd()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fwd()
+        for _ in range(warmup):
+            graph.replay()
+        graph_ms = per_step_ms(graph.replay, steps)[0]
+        del graph
+    except Exception:  # noqa: BLE001
+        graph_ms = None
     flops = layers * 2.0 * batch * H * T * T * hs
     tf = flops / (attn_ms * 1e-3) / 1e12
     from flash_attention_amd._impl import _native
     from flash_attention_amd._impl.scaled_dot_product_attention import chunk_heuristic
 
     plan = _native.plan(batch * H, T, hs, torch.bfloat16, *chunk_heuristic(T, hs), softmax_scale=hs ** -0.5)
-    return {"value": round(step_ms, 3), "unit": "ms/step", "stock_sdpa_ms": round(stock_ms, 3), "tokens_per_s": round(batch * T / (step_ms * 1e-3)),
+    return {"value": round(step_ms, 3), "unit": "ms/step", "stock_sdpa_ms": round(stock_ms, 3), "hip_graph_ms": None if graph_ms is None else round(graph_ms, 3),
+            "tokens_per_s": round(batch * T / (step_ms * 1e-3)),
             "attn_ms": round(attn_ms, 3), "attn_share": round(attn_ms / step_ms, 4), "attn_tflops": round(tf, 1), "attn_frac": round(tf / PEAK_TFLOPS, 4),
             "kernel": kernel_name(plan).replace("fa_", "").replace("_kernel", ""), "calls_per_step": layers,
             "shape": f"GPT-2 small fwd, B={batch} T={T} 12 layers x 12 heads, bf16 autocast, through flash_attention_amd.auto"}
@@ -709,7 +728,7 @@ def main():
             line["secondary"] = sec
             line["roofline"]["other_configs"] = {
                 k: ({"tflops": v["value"], "frac": v["frac"], "kernel": v["kernel"], "ms": v["ms"]} if "frac" in v else
-                    {"step_ms": v.get("value"), "stock_ms": v.get("stock_sdpa_ms"), "attn_frac": v.get("attn_frac")} if "error" not in v else v)
+                    {"step_ms": v.get("value"), "stock_ms": v.get("stock_sdpa_ms"), "graph_ms": v.get("hip_graph_ms"), "attn_frac": v.get("attn_frac")} if "error" not in v else v)
                 for k, v in sec.items()}
         if not args.no_cpu_baseline and not dist_on:
             line["cpu_baseline"] = cpu_baseline(4096, 64) if args.config.startswith("cfg2") else cpu_baseline(min(L, 4096), D)

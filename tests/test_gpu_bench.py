@@ -35,4 +35,6 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_every_baseline_con
         assert name in others and "error" not in others[name], (name, others.get(name))
         assert name in rec["secondary"]
     assert list(rec["secondary"])[-4:-2] == ["cfg5_shard", "cfg3"], "the BASELINE configs come last among the forward records"
+    g4 = others["cfg4_gpt2_fwd"]      # the GPT-2 step also replays from a HIP graph (the override's launches are capture-safe)
+    assert g4["graph_ms"] and g4["graph_ms"] < 1.3 * g4["step_ms"]
     assert others["cfg3"]["kernel"] == "fwd_pipe16" and others["cfg3"]["tflops"] > 0 and others["cfg2_f16"]["frac"] > 0
