@@ -56,9 +56,6 @@ struct Options {
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
     std::atomic<int> mirror{-1};    // -1 auto, 0 off, 1 on: mirrored row blocks in the two-block pipelined kernel (causal, head_dim 64, L % 256 == 0)
     std::atomic<int> fold{-1};      // -1 auto (= off), 0 off, 1 on for scaled bf16 calls: the scale fold of the pipelined kernel (fa_fwd_pipe.hip FOLD)
-    std::atomic<int> wl{-1};        // -1 auto, 0 off, 1 on wherever it can run: the persistent work-list launch (fa_fwd_wl.hip; needs the caller's workspace)
-    std::atomic<int> wl_cap{0};     // 0 auto, else the chain cap: kv tiles per unit above which a q tile's kv loop is cut in parts
-    std::atomic<int> wl_slots{0};   // 0 auto, else persistent workgroups per CU (1..4 at head_dim 64, 1..2 at 128)
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -89,9 +86,6 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
         if (const char* e = getenv("FA_AMD_FOLD")) { if (*e) g_opt.fold = atoi(e); }
         if (const char* e = getenv("FA_AMD_MIRROR")) { if (*e) g_opt.mirror = atoi(e); }
-        if (const char* e = getenv("FA_AMD_WL")) { if (*e) g_opt.wl = atoi(e); }
-        if (const char* e = getenv("FA_AMD_WL_CAP")) g_opt.wl_cap = atoi(e);
-        if (const char* e = getenv("FA_AMD_WL_SLOTS")) g_opt.wl_slots = atoi(e);
     });
     return g_opt;
 }
@@ -150,80 +144,7 @@ struct Selection {
     int pair;        // 'd' only: 1 = a workgroup owns q tiles (nq - 1 - i) and i, one after the other
     int perm_n;      // 'd' | 'h': > 0 = placement-balanced order of the XCD's first perm_n slots
     uint8_t perm[128];
-    bool wl;         // the request can run as a persistent work-list launch (plan.wl): wl_w / wl_grid describe it, the fields above its fallback
-    fa::WlParams wl_w;
-    int wl_grid;
 };
-
-// ---- the persistent work-list launch (fa_fwd_wl.hip) -------------------------------------------------------------------
-// CUs of the current device (cached per device ordinal; the sanitizer build's stub answers 256)
-int device_cus() {
-    static std::atomic<int> cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int n = cache[dev].load();
-    if (n > 0) return n;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-    cache[dev].store(n);
-    return n;
-}
-
-constexpr int64_t kWlHeadBytes = 0;         // (the workspace begins with the arrival tickets)
-int64_t wl_slot_bytes(int64_t D) { return 256 * 16 * ((D / 32 * 16 + 2 + 3) / 4); }     // 256 lanes x (m, l, O) in 16-byte pieces
-
-// The unit pattern of one group: q tiles heaviest first, a q tile of n kv tiles cut into ceil(n / cap) parts.  cap = the chain cap:
-// about two thirds of a slot's fair share of the launch's kv tiles, at least 4 (a part pays ~2 tiles' time for the publish / fold).
-// Returns false when the request cannot run as a work-list launch.
-bool wl_make(int64_t G, int64_t L, int64_t D, int32_t causal, const Options& opt, Selection* sel) {
-    sel->wl = false;
-    sel->wl_grid = 0;
-    if (!(D == 64 || D == 128) || G > (1 << 20)) return false;
-    const int64_t nq = (L + 127) / 128;
-    if (nq > 255) return false;
-    const int per_cu_max = D == 64 ? 4 : 2;
-    int per_cu = opt.wl_slots > 0 ? (int)opt.wl_slots : per_cu_max;
-    if (per_cu > per_cu_max) per_cu = per_cu_max;
-    const int64_t slots = (int64_t)device_cus() * per_cu;
-    const auto tiles_of = [&](int64_t qi) { const int64_t ke = (causal && (qi + 1) * 128 < L) ? (qi + 1) * 128 : L; return (ke + 63) / 64; };
-    int64_t per_group = 0;
-    for (int64_t qi = 0; qi < nq; ++qi) per_group += tiles_of(qi);
-    const double share = (double)(G * per_group) / (double)slots;
-    int64_t cap = opt.wl_cap > 0 ? (int64_t)opt.wl_cap : (int64_t)ceil(share / 1.5);
-    if (cap < 4 && opt.wl_cap <= 0) cap = 4;
-    fa::WlParams& w = sel->wl_w;
-    memset(&w, 0, sizeof(w));
-    int n_pat = 0, n_split = 0;
-    for (int64_t i = nq - 1; i >= 0; --i) {      // (causal: the last q tile is the heaviest; unmasked: all equal)
-        const int64_t n = tiles_of(i);
-        int64_t parts = (n + cap - 1) / cap;
-        if (parts > n) parts = n;
-        if (parts > 255) return false;
-        if (n_pat + parts > fa::kWlMaxPattern) return false;
-        // (parts > 1 entries must form a prefix of the pattern: tiles_of is monotone in the visiting order)
-        if (parts > 1 && n_split != n_pat) return false;
-        for (int64_t pt = 0; pt < parts; ++pt) w.pat[n_pat++] = (uint32_t)i | ((uint32_t)pt << 8) | ((uint32_t)parts << 16);
-        if (parts > 1) n_split = n_pat;
-    }
-    w.n_pat = n_pat;
-    w.n_split = n_split;
-    w.nq = (int32_t)nq;
-    w.slot_bytes = (int32_t)wl_slot_bytes(D);
-    w.ticket_off = kWlHeadBytes;
-    w.slot_off = kWlHeadBytes + ((G * nq * 4 + 255) / 256) * 256;
-    const int64_t bytes = w.slot_off + G * n_split * (int64_t)w.slot_bytes;
-    if (bytes > (1ll << 31)) return false;
-    const int64_t units = G * n_pat;
-    // workgroup b serves list b & 7 (the groups b & 7, + 8, ...): as many workgroups per list as the longest list has units, at most the chip's slots
-    const int64_t longest = n_pat * ((G + 7) / 8);
-    sel->wl_grid = (int)(8 * (longest < slots / 8 ? longest : slots / 8));
-    sel->plan.wl = 1;
-    sel->plan.wl_cap = (int32_t)cap;
-    sel->plan.wl_units = (int32_t)(units > 0x7fffffff ? 0x7fffffff : units);
-    sel->plan.wl_grid = sel->wl_grid;
-    sel->plan.workspace_bytes = bytes;
-    sel->wl = true;
-    return true;
-}
 
 // Placement-balanced block order for a causal 'd' launch whose workgroups are all resident at once (a grid of at most one
 // round of slots: e.g. GPT-2 small's attention call, 96 groups x 8 q tiles = 768 workgroups on 1024 slots).  Nothing is
@@ -475,8 +396,6 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     sel->split = 1;
     sel->pair = 0;
     sel->perm_n = 0;
-    sel->wl = false;
-    sel->wl_grid = 0;
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
     const int64_t g8 = (G + 7) / 8 * 8;
@@ -499,15 +418,6 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         apply_overrides(r, opt, &c);
         apply_constraints(r, opt, &c);
         finish_mfma_plan(r, opt, c, sel);
-        // the persistent work-list launch replaces the plan above where the caller lends a workspace (fa_fwd_ws): plain 128-row
-        // workgroups of the 64-key-tile kernel only - 4 waves allowed by the q chunk, 64-key tiles by the kv chunk
-        {
-            const int64_t wgs128 = g8 * ((L + 127) / 128);
-            const bool can = r.wmax == 4 && !r.want32 && (D == 64 || D == 128) && opt.kernel == 0 && opt.waves == 0 && opt.qb == 0 && opt.split == 0 && opt.pair < 0;
-            // built-in rule (profiles/r05_wl): on for nothing yet - the forced option decides until the measurements are in
-            const bool rule = false && wgs128 > 0;
-            if (can && (opt.wl == 1 || (opt.wl < 0 && rule))) wl_make(G, L, D, causal, opt, sel);
-        }
     } else if (f32_ok) {
         plan->kernel = 3;
         plan->waves = 4;
@@ -550,7 +460,7 @@ const OptionName kOptionNames[] = {
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
     {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"fold", &Options::fold, -1, 1},
-    {"mirror", &Options::mirror, -1, 1}, {"wl", &Options::wl, -1, 1}, {"wl_cap", &Options::wl_cap, 0, 255}, {"wl_slots", &Options::wl_slots, 0, 4},
+    {"mirror", &Options::mirror, -1, 1},
 };
 
 }  // namespace
@@ -702,11 +612,8 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
            int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,
            const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
            int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,
-           float softmax_scale, int32_t causal, void* stream, const fa::ExtraParams* ex,
-           void* workspace = nullptr, int64_t workspace_bytes = 0) {
+           float softmax_scale, int32_t causal, void* stream, const fa::ExtraParams* ex) {
     if (!q || !k || !v || !out) return fail(FA_ERR_NULL_POINTER, "q, k, v and out must be non-null");
-    if (workspace_bytes < 0 || (workspace == nullptr && workspace_bytes != 0)) return fail(FA_ERR_BAD_SHAPE, "workspace_bytes must be >= 0, and 0 without a workspace");
-    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(FA_ERR_MISALIGNED, "the workspace must be 256-byte aligned");
     if (!q_strides || !k_strides || !v_strides || !o_strides) return fail(FA_ERR_NULL_POINTER, "stride arrays must be non-null");
     if (heads < 1 || (G >= 1 && G % heads != 0)) return fail(FA_ERR_BAD_SHAPE, "G=%lld must be a positive multiple of heads=%lld", (long long)G, (long long)heads);
     if (heads_kv < 1 || heads % heads_kv != 0) return fail(FA_ERR_BAD_SHAPE, "heads=%lld must be a positive multiple of heads_kv=%lld", (long long)heads, (long long)heads_kv);
@@ -780,19 +687,6 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     }
     hipStream_t st = (hipStream_t)stream;
     if (extra_mfma) { p.perm_n = 0; p.skipmax = 0; }
-    // the persistent work-list launch: where the selection allows it and the caller lent a workspace that holds its counters and partial slots
-    if (sel.wl && !extra && workspace != nullptr && workspace_bytes >= plan.workspace_bytes) {
-        p.nq_tiles = (int32_t)((L + 127) / 128);
-        p.perm_n = 0;
-        p.stamps = nullptr;
-        if (void* sb = g_stamp_buf.load()) {   // measurement builds: 16 u64 per wave of the persistent grid
-            if ((int64_t)sel.wl_grid * 4 * 16 * 8 <= g_stamp_bytes.load()) p.stamps = static_cast<unsigned long long*>(sb);
-        }
-        sel.wl_w.ws = static_cast<unsigned*>(workspace);
-        const hipError_t ew = fa::launch_fwd_wl(p, sel.wl_w, dtype, sel.wl_grid, st);
-        if (ew != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(ew));
-        return FA_OK;
-    }
     hipError_t e = extra_mfma         ? fa::launch_fwd_extra(p, dtype, st)
                    : sel.which == 'g' ? fa::launch_fwd_generic(p, dtype, st)
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
@@ -824,22 +718,6 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
            float softmax_scale, int32_t causal, void* stream) {
     return fwd_impl(q, k, v, out, lse, G, L, D, heads, heads_kv, q_strides, k_strides, v_strides, o_strides,
                     num_chunks_q, num_chunks_kv, dtype, softmax_scale, causal, stream, nullptr);
-}
-
-int fa_fwd_ws(const void* q, const void* k, const void* v, void* out, float* lse,
-              int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,
-              const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
-              int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,
-              float softmax_scale, int32_t causal, void* workspace, int64_t workspace_bytes, void* stream) {
-    return fwd_impl(q, k, v, out, lse, G, L, D, heads, heads_kv, q_strides, k_strides, v_strides, o_strides,
-                    num_chunks_q, num_chunks_kv, dtype, softmax_scale, causal, stream, nullptr, workspace, workspace_bytes);
-}
-
-int64_t fa_fwd_workspace_bytes(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q, int32_t num_chunks_kv,
-                               float softmax_scale, int32_t causal) {
-    fa_plan_t plan;
-    if (fa_plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale, causal, &plan) != FA_OK) return 0;
-    return plan.wl ? plan.workspace_bytes : 0;
 }
 
 int fa_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
@@ -961,11 +839,6 @@ extern "C" {
 
 int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,
                       int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, void* stream) {
-    return fa_fwd_qkv_packed_ws(qkv, out, lse, G, L, D, num_chunks_q, num_chunks_kv, dtype, nullptr, 0, stream);
-}
-
-int fa_fwd_qkv_packed_ws(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,
-                         int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!qkv || !out) return fail(FA_ERR_NULL_POINTER, "qkv and out must be non-null");
     if (G < 1 || L < 1 || D < 1) return fail(FA_ERR_BAD_SHAPE, "G, L, D must be >= 1");
     if (dtype < 0 || dtype > 2) return fail(FA_ERR_BAD_DTYPE, "dtype must be FA_DTYPE_F16/BF16/F32 (got %d)", dtype);
@@ -976,8 +849,8 @@ int fa_fwd_qkv_packed_ws(const void* qkv, void* out, float* lse, int64_t G, int6
     const int64_t es = elt_size(dtype);
     const int64_t strides[3] = {L * D, 0, D};
     const char* base = static_cast<const char*>(qkv);
-    return fa_fwd_ws(base, base + G * L * D * es, base + 2 * G * L * D * es, out, lse, G, L, D, 1, 1,
-                     strides, strides, strides, strides, num_chunks_q, num_chunks_kv, dtype, 1.0f, 1, workspace, workspace_bytes, stream);
+    return fa_fwd(base, base + G * L * D * es, base + 2 * G * L * D * es, out, lse, G, L, D, 1, 1,
+                  strides, strides, strides, strides, num_chunks_q, num_chunks_kv, dtype, 1.0f, 1, stream);
 }
 
 }  // extern "C"

@@ -155,24 +155,8 @@ __device__ __forceinline__ i32x4 make_raw_rsrc(const void* base, unsigned num_by
 
 // lds_base and rsrc must be wave-uniform (they travel in SGPRs; M0 carries the LDS base and is
 // written and restored inside the same statement, as the compiler reserves it)
-// SETTLE: the descriptor words may have been written by a VALU instruction just before (v_readlane of a spilled SGPR, v_readfirstlane): a
-// VMEM instruction must not read such an SGPR for 5 wait states, and hipcc pads that hazard for its own instructions only - kernels that
-// spill SGPRs (the persistent work-list kernel does) put the wait states into the statement itself.
-template <bool SETTLE = false>
 __device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned lds_base, unsigned voffset) {
     unsigned keep;
-    if constexpr (SETTLE) {
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\t"
-            "s_nop 0\n\t"
-            "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "s"(lds_base), "v"(voffset), "s"(rsrc)
-            : "memory");
-    } else {
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %1\n\t"
@@ -182,7 +166,6 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned lds_base, unsi
         : "=&s"(keep)
         : "s"(lds_base), "v"(voffset), "s"(rsrc)
         : "memory");
-    }
 }
 // the same without saving / restoring M0 around the load (two scalar instructions fewer per piece: the software-pipelined kernels
 // are bound by instruction issue).  M0 is a RESERVED register for hipcc on gfx9 ("inline asm clobber list contains

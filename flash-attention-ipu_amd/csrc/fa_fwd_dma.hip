@@ -35,22 +35,6 @@ __device__ __forceinline__ int k_swizzle(int row) {
     return D == 64 ? ((row >> 1) & 7) : (D % 128 == 0) ? (row & 15) : (row & 7);
 }
 
-// ---- work-list launches (WL below; fa_params.h WlParams) ------------------------------------------------------------------
-// The one word other workgroups touch - a q tile's arrival ticket - is reached through agent-scope atomics only (MI355X: the XCDs'
-// L2s are not coherent with each other).
-__device__ __forceinline__ unsigned wl_fetch_add(unsigned* a, unsigned v) {
-    return __hip_atomic_fetch_add(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Workgroup b works on list x = b & 7 - the units of the groups x, x + 8, ..., heaviest first - as member j = b >> 3 of the list's nw
-// workgroups (b, b + 8, ... share an XCD: observed dispatch order, used for speed only - any placement computes the same result).
-// Its round-r unit is r nw + j in even rounds and r nw + (nw - 1 - j) in odd ones: the serpentine over a descending list hands every
-// member nearly the same sum of kv tiles with no counter to draw from (a returning atomic costs ~1 us under load, per unit and workgroup,
-// and a thousand workgroups leaving through one exit counter queue for 12 us: both measured, profiles/r05_wl/dynamic_first_build.txt).
-__device__ __forceinline__ int wl_unit_of_round(int r, int j, int nw, int len) {
-    const int u = r * nw + ((r & 1) ? nw - 1 - j : j);
-    return u < len ? u : -1;
-}
-
 // (the body lives in a __device__ function: the buffer/LDS-DMA builtins do not exist for the host pass,
 // and a __global__ template that names them loses its host-side launch stub)
 //
@@ -71,16 +55,9 @@ __device__ __forceinline__ int wl_unit_of_round(int r, int j, int nw, int len) {
 // tile from a row, so the fixed reference max of the skip-max mode has nothing to stand on); instantiated in fa_fwd_extra.hip.
 // MPRE (EXTRA only): a mask that differs from row to row has the raw data of the NEXT tile requested one tile ahead (16 more registers,
 // which a key-padding row - cache-resident - or a dropout-only launch would pay for nothing: measured +6 % on those).
-//
-// WL (fa_fwd_wl.hip; QB == 1, SPLIT == 1, no PAIR / EXTRA): the workgroup is PERSISTENT.  It runs its share of its list's (group, q tile,
-// kv part) units (wl_unit_of_round above); the next unit's first K/V tile is requested right after the current unit's loop (as a pair's
-// second tile is) and its Q rows as soon as the epilogue has emptied the accumulators, so both land under the current unit's epilogue.
-// A q tile whose kv loop was cut in parts: every part stores its (m, l, O) write-through into its partial slot and draws the q tile's
-// arrival ticket; the part that draws the last one folds all slots IN PART ORDER (bit-reproducible whoever arrives last) and writes the rows.
-template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT, bool PAIR, bool EXTRA = false, bool MPRE = false, bool WL = false>
-__device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlParams* wlp = nullptr) {
+template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT, bool PAIR, bool EXTRA = false, bool MPRE = false>
+__device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     static_assert(!EXTRA || !SKIP, "mask / dropout launches use the exact-max arithmetic");
-    static_assert(!WL || (QB == 1 && SPLIT == 1 && !PAIR && !EXTRA), "work-list launches: plain 128-row workgroups");
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
@@ -99,15 +76,13 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
 
     constexpr int GROUP_B = 2 * KTILE_B + 2 * VTILE_B;                                      // K0 K1 V0 V1 of one group
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[SPLIT * GROUP_B];
-    __shared__ int flags[NWAVES * SPLIT + (WL ? 1 : 0)];   // WL: + the arrival ticket drawn for the workgroup
-    constexpr int CTRL = NWAVES * SPLIT;
-    (void)CTRL;
+    __shared__ int flags[NWAVES * SPLIT];
 
     static_assert(!PAIR || (SPLIT == 1 && QB == 1), "q-tile pairs: unsplit workgroups with one query block per wave");
     const int nq = p.nq_tiles;
     const int nslot = PAIR ? (nq + 1) >> 1 : nq;      // workgroups per group
-    int g = 0, qd = 0;
-    if constexpr (!WL) {
+    int g, qd;
+    {
         int b = blockIdx.x;
         if (p.perm_n > 0) {                            // placement-balanced order of a grid below one round of slots (fa_capi.cpp)
             const int s_ = b >> 3;
@@ -123,19 +98,15 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
         qd = rem / bc;
         g = (g0 + (rem - qd * bc)) * 8 + xcd;
     }
-    if (!WL && g >= p.G) return;
+    if (g >= p.G) return;
     const int n_pass = (PAIR && qd != nq - 1 - qd) ? 2 : 1;
 #ifdef FA_STAMPS   /* measurement build only (scripts/phase_times.py): phase time stamps, written to p.stamps at the end */
     const unsigned long long st0_ = __builtin_amdgcn_s_memtime();
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
     unsigned long long st1_ = 0, st2_ = 0;
 #define FA_STAMP(V_) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); V_ = __builtin_amdgcn_s_memtime(); }
-    // WL: time of a wave's life by phase, summed over its units (no drain: the phases end at barriers anyway)
-    unsigned long long wa_ = 0, wb_ = 0, wc_ = 0, wd_ = 0, acc_wait_ = 0, acc_loop_ = 0, acc_fold_ = 0, acc_epi_ = 0, acc_units_ = 0, acc_tiles_ = 0, acc_folds_ = 0;
-#define FA_WSTAMP(V_) { if constexpr (WL) V_ = __builtin_amdgcn_s_memtime(); }
 #else
 #define FA_STAMP(V_) {}
-#define FA_WSTAMP(V_) {}
 #endif
 
     const int L = p.L;
@@ -143,43 +114,12 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base -> M0)
     const int ws = SPLIT == 1 ? 0 : wave_all / NWAVES;               // kv split group of this wave
     const int wave = SPLIT == 1 ? wave_all : wave_all - ws * NWAVES; // its row block inside the group
-    constexpr int tstride = SPLIT;                                   // a wave group streams the kv tiles ws, ws + SPLIT, ... (tfirst, below)
+    constexpr int tstride = SPLIT;                                   // a wave group streams the kv tiles ws, ws + SPLIT, ...
+    const int tfirst = ws;
     unsigned char* const smem = smem_all + ws * GROUP_B;
     unsigned char* const smem_v = smem + 2 * KTILE_B;
     const int r = lane & 31, h = lane >> 5;
-    // ---- WL: the unit in hand (cur_*), the one after it (nx_*), this workgroup's place in its list
-    int cur_qi = 0, cur_t0 = 0, cur_t1 = 0, cur_part = 0, cur_parts = 1, cur_k0 = 0;
-    int nx_u = -1, nx_g = 0, nx_qi = 0, nx_t0 = 0, nx_t1 = 0, nx_part = 0, nx_parts = 1, nx_k0 = 0;
-    int wl_round = 0;
-    const int wl_x = (int)(blockIdx.x & 7u), wl_j = (int)(blockIdx.x >> 3);
-    const int wl_nw = (int)((gridDim.x - (unsigned)wl_x + 7u) >> 3);                     // workgroups on this list
-    const int wl_ngx = WL ? (p.G - wl_x + 7) >> 3 : 1;                                    // groups on this list
-    const int wl_len = WL ? wlp->n_pat * wl_ngx : 0;                                      // units on this list
-    (void)cur_part; (void)cur_parts; (void)cur_k0; (void)nx_u; (void)nx_g; (void)nx_qi; (void)nx_t0; (void)nx_t1; (void)nx_part; (void)nx_parts; (void)nx_k0;
-    (void)wl_round; (void)wl_j; (void)wl_nw; (void)wl_len;
-    // unit U_ of the list -> group, q tile, kv tile range [t0, t1), part of parts, pattern index of the q tile's first part
-#define FA_WL_DECODE(U_, G_, QI_, T0_, T1_, PART_, PARTS_, K0_)                                    \
-    {                                                                                              \
-        /* bunch-major: the list's groups in bunches of p.sched whose K/V share the XCD's L2 while the list's workgroups run them */ \
-        const int per_b_ = p.sched * wlp->n_pat;                                                   \
-        const int bn_ = (U_) / per_b_, rem_ = (U_) - bn_ * per_b_;                                 \
-        const int g0_ = bn_ * p.sched;                                                             \
-        const int bc_ = (wl_ngx - g0_) < p.sched ? (wl_ngx - g0_) : p.sched;                       \
-        const int k_ = rem_ / bc_;                                                                 \
-        G_ = (g0_ + (rem_ - k_ * bc_)) * 8 + wl_x;                                                 \
-        const unsigned e_ = wlp->pat[k_];                                                          \
-        QI_ = (int)(e_ & 0xffu); PART_ = (int)((e_ >> 8) & 0xffu); PARTS_ = (int)(e_ >> 16);       \
-        K0_ = k_ - PART_;                                                                          \
-        const int ke_ = (p.causal != 0 && (QI_ + 1) * BQ < L) ? (QI_ + 1) * BQ : L;                \
-        const int n_ = (ke_ + BK - 1) / BK;                                                        \
-        T0_ = PART_ * n_ / PARTS_; T1_ = (PART_ + 1) * n_ / PARTS_;                                \
-    }
-    if constexpr (WL) {
-        const int u0 = wl_unit_of_round(0, wl_j, wl_nw, wl_len);
-        if (u0 < 0) return;           // (more workgroups than units on this list: the host sizes the grid so that this is rare)
-        FA_WL_DECODE(u0, g, cur_qi, cur_t0, cur_t1, cur_part, cur_parts, cur_k0)
-    }
-    int bb = g / p.H, hh = g - bb * p.H;
+    const int bb = g / p.H, hh = g - bb * p.H;
     const T* __restrict__ qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
     const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
     const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
@@ -211,7 +151,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
             qf[b][ks] = ch_ < dchunks ? ld_ : z_;  /* (columns past the true head dim: zeros) */   \
         }                                                                                          \
     }
-    FA_LOAD_Q(WL ? cur_qi : nq - 1 - qd)
+    FA_LOAD_Q(nq - 1 - qd)
 
     // ---- LDS-DMA geometry: piece pc = wave + j*NWAVES of a tile, lane -> source byte offset
     const unsigned k_slb = (unsigned)p.k_sl * 2, v_slb = (unsigned)p.v_sl * 2;   // row strides in bytes
@@ -245,8 +185,8 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
         const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
         if (FA_DMA_ABL != 2) {                                                                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
-            lds_dma_b128<WL>(kr_, smem_lds + (BUF_) * KTILE_B + k_dst[j], k_vo[j]);                \
-            lds_dma_b128<WL>(vr_, smem_lds + 2 * KTILE_B + (BUF_) * VTILE_B + v_dst[j], v_vo[j]);  \
+            lds_dma_b128(kr_, smem_lds + (BUF_) * KTILE_B + k_dst[j], k_vo[j]);                    \
+            lds_dma_b128(vr_, smem_lds + 2 * KTILE_B + (BUF_) * VTILE_B + v_dst[j], v_vo[j]);      \
         }                                                                                          \
         }                                                                                          \
     }
@@ -479,7 +419,6 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
         FA_MASK_PREFETCH(tfirst)                                                                   \
         FA_TILE_BARRIER()                                                                          \
         if (pass == 0) FA_STAMP(st1_)                                                              \
-        if ((MODE_) == 0 || !SKIPMAX) FA_WSTAMP(wb_)                                               \
         for (int rr = 0; rr < n_rounds; rr += 2) {              /* (workgroup-uniform bounds) */   \
             const int t = tfirst + rr * tstride;                /* this group's tile of the round */ \
             if (t + tstride < n_tiles) FA_DMA_TILE(t + tstride, 1)                                 \
@@ -496,24 +435,16 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
     bool tile0_requested = false;     // pairs: the next q tile's first K/V tile is already on its way to buffer 0
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
 #pragma nounroll
-    for (int pass = 0; WL || pass < n_pass; ++pass) {   // (WL: one unit per trip, until the workgroup's share of its list is done)
-    // (WL: the epilogue's and the next-Q loads' per-lane address arithmetic is redone for every unit from a lane index the optimiser cannot
-    //  see through - held across the unit loop instead, those ~16 registers spill at the 128-register budget of 4 workgroups per CU)
-    FA_WSTAMP(wa_)
-    int lane_e = lane;
-    if constexpr (WL) asm volatile("" : "+v"(lane_e));
-    const int r_e = lane_e & 31, h_e = lane_e >> 5;
-    const int qi = WL ? cur_qi : pass == 0 ? nq - 1 - qd : qd;     // heaviest first; pairs: then the light partner
+    for (int pass = 0; pass < n_pass; ++pass) {
+    const int qi = pass == 0 ? nq - 1 - qd : qd;     // heaviest first; pairs: then the light partner
     const int q_row0 = qi * BQ + wave * WQ;
     const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
     const bool wave_active = q_row0 < L;
     // causal: keys up to the workgroup's last row; otherwise every key.  `klim`: the last key a row may see is
     // min(row, L - 1) under the causal mask and L - 1 without it (rows past L are clamped duplicates, never stored)
     const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
-    const int n_tiles = WL ? cur_t1 : (kv_end + BK - 1) / BK;      // (WL: the unit's kv tiles are [cur_t0, cur_t1))
-    const int tfirst = WL ? cur_t0 : ws;                           // the wave group's first tile
-    const int n_rounds = WL ? cur_t1 - cur_t0 : (n_tiles + SPLIT - 1) / SPLIT;   // rounds of the workgroup's lock-step loop (uniform over all its waves)
-    (void)kv_end;
+    const int n_tiles = (kv_end + BK - 1) / BK;
+    const int n_rounds = (n_tiles + SPLIT - 1) / SPLIT;   // rounds of the workgroup's lock-step loop (uniform over all its waves)
     const int wave_last = causal ? q_row0 : L - 1;      // a tile reaching past this key carries a mask for the wave
     const int wave_kv_last = causal ? q_row0 + WQ - 1 : L - 1;   // tiles starting after it hold nothing for the wave
     FA_RESET_STATE()
@@ -544,114 +475,6 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
         FA_PASS(1)
     }
     if (pass + 1 == n_pass) FA_STAMP(st2_)
-    FA_WSTAMP(wc_)
-    if constexpr (WL) {
-        // the next unit: its first K/V tile goes into buffer 0 now (every wave is past the loop's last barrier) and lands under this unit's
-        // publish / fold / epilogue; its Q rows are requested further down, once the accumulators have been emptied (register budget)
-        nx_u = wl_unit_of_round(++wl_round, wl_j, wl_nw, wl_len);
-        if (nx_u >= 0) {
-            FA_WL_DECODE(nx_u, nx_g, nx_qi, nx_t0, nx_t1, nx_part, nx_parts, nx_k0)
-            const int nb_ = nx_g / p.H, nh_ = nx_g - nb_ * p.H;
-            const T* __restrict__ kg = (const T*)p.k + (int64_t)nb_ * p.k_sb + (int64_t)(nh_ / p.kv_div) * p.k_sh;   // (shadow the unit in hand for the macro)
-            const T* __restrict__ vg = (const T*)p.v + (int64_t)nb_ * p.v_sb + (int64_t)(nh_ / p.kv_div) * p.v_sh;
-            FA_DMA_TILE(nx_t0, 0)
-            tile0_requested = true;
-        }
-    }
-    // the next unit's Q rows -> the registers the loop released.  Buffer loads: a chunk past the true head dim and nothing else reads as
-    // zeros through the descriptor's range check (as the K/V DMA does it), so no select consumes - and thereby waits for - a load here.
-#define FA_WL_LOAD_NEXT_Q()                                                                        \
-    if (nx_u >= 0) {                                                                               \
-        const int nb_ = nx_g / p.H, nh_ = nx_g - nb_ * p.H;                                        \
-        const T* qn_ = (const T*)p.q + (int64_t)nb_ * p.q_sb + (int64_t)nh_ * p.q_sh;             \
-        const __amdgpu_buffer_rsrc_t qr_ = __builtin_amdgcn_make_buffer_rsrc((void*)qn_, 0, (int)(((unsigned)(L - 1) * (unsigned)p.q_sl + (unsigned)p.Dr) * 2u), 0x00020000); \
-        const int qrow_ = nx_qi * BQ + wave * WQ + r_e;                                            \
-        const unsigned qro_ = (unsigned)(qrow_ < L ? qrow_ : L - 1) * ((unsigned)p.q_sl * 2u);     \
-        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                        \
-            const int ch_ = 2 * ks + h_e;                                                          \
-            const u32x4 ld_ = __builtin_amdgcn_raw_buffer_load_b128(qr_, (int)(ch_ < dchunks ? qro_ + (unsigned)(ch_ << 4) : 0x80000000u), 0, 0); \
-            qf[0][ks] = __builtin_bit_cast(vec8, ld_);                                             \
-        }                                                                                          \
-    }
-    // ---- WL, a q tile cut in kv parts: publish this part's (m, l, O) write-through (sc1: no release fence needed, the bytes leave the
-    // XCD's L2 at once), drain, draw the arrival ticket; the last arriver reads every part's slot with sc1 loads (they bypass this CU's L1,
-    // no acquire needed: MI355X_MICROARCH.md, inter-workgroup visibility, valid forms) and folds them in part order.
-    bool wl_out = true;      // this workgroup writes the unit's rows
-    (void)wl_out;
-    if constexpr (WL) {
-        if (cur_parts > 1) {
-            constexpr int NV = DT * 16 + 2, NV4 = (NV + 3) / 4;      // floats per lane, in 16-byte pieces
-            constexpr int NT = NWAVES * 64;
-            char* slots = (char*)wlp->ws + wlp->slot_off + ((int64_t)g * wlp->n_split + cur_k0) * wlp->slot_bytes;
-            {   // (provably wave-uniform: the descriptors below travel in SGPRs)
-                const unsigned long long a_ = (unsigned long long)slots;
-                // (readfirstlane returns int: widen each half as UNSIGNED - a sign-extended low half sets the high half to ones, and the
-                //  descriptor then points into nowhere whenever the slot's address has bit 31 set: a memory fault on two of three boxes)
-                const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(a_ >> 32)), lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a_);
-                slots = (char*)(((unsigned long long)hi_ << 32) | (unsigned long long)lo_);
-            }
-            unsigned* const ticket = (unsigned*)((char*)wlp->ws + wlp->ticket_off) + ((int64_t)g * wlp->nq + qi);
-            {
-                float vals[NV4 * 4];
-                vals[0] = m[0];
-                vals[1] = lsum[0][0];
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) vals[2 + dt * 16 + e] = o[0][dt][e];
-#pragma unroll
-                for (int i = NV; i < NV4 * 4; ++i) vals[i] = 0.f;
-                // (compiler builtins, not asm: the descriptor words come out of v_readfirstlane, and hipcc pads the VALU-writes-SGPR ->
-                //  VMEM-reads-it hazard for its own instructions only)
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slots + (int64_t)cur_part * wlp->slot_bytes, 0, wlp->slot_bytes, 0x00020000);
-#pragma unroll
-                for (int j = 0; j < NV4; ++j) {
-                    const u32x4 v4 = {__builtin_bit_cast(unsigned, vals[4 * j]), __builtin_bit_cast(unsigned, vals[4 * j + 1]),
-                                      __builtin_bit_cast(unsigned, vals[4 * j + 2]), __builtin_bit_cast(unsigned, vals[4 * j + 3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (j * NT + tid) * 16, 0, 16 /* sc1: write-through */);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the ticket is drawn for it
-            __syncthreads();
-            if (wave_all == 0 && lane == 0) flags[CTRL] = (int)wl_fetch_add(ticket, 1u);
-            __syncthreads();
-            wl_out = __builtin_amdgcn_readfirstlane(flags[CTRL]) == cur_parts - 1;
-            if (wl_out) {
-                if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody draws it again in this launch)
-                for (int pp = 0; pp < cur_parts; ++pp) {
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slots + (int64_t)pp * wlp->slot_bytes, 0, wlp->slot_bytes, 0x00020000);
-                    u32x4 t4[NV4];
-#pragma unroll
-                    for (int j = 0; j < NV4; ++j) t4[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (j * NT + tid) * 16, 0, 16 /* sc1 */);
-                    float tv[NV4 * 4];
-#pragma unroll
-                    for (int i = 0; i < NV4 * 4; ++i) tv[i] = __builtin_bit_cast(float, (unsigned)t4[i >> 2][i & 3]);
-                    if (pp == 0) {
-                        m[0] = tv[0];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) lsum[0][j] = tv[1];
-#pragma unroll
-                        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) o[0][dt][e] = tv[2 + dt * 16 + e];
-                    } else {
-                        // (a part that saw no key of a row hands over m = -inf, l = 0, O = 0: weight 2^(-inf) = 0)
-                        const float mn = max2(m[0], tv[0]);
-                        const float a0 = fast_exp2((m[0] - mn) * c), a1 = fast_exp2((tv[0] - mn) * c);
-                        m[0] = mn;
-                        const float ln = lsum[0][0] * a0 + tv[1] * a1;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) lsum[0][j] = ln;
-#pragma unroll
-                        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) o[0][dt][e] = o[0][dt][e] * a0 + tv[2 + dt * 16 + e] * a1;
-                    }
-                }
-            }
-        }
-    }
-    FA_WSTAMP(wd_)
     if constexpr (PAIR) {
         if (pass + 1 < n_pass) {
             // the pair's second q tile: its Q rows go into the registers the loop has just released, its first K/V tile into
@@ -713,13 +536,12 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
     // 32-row slab [32][D] with the 16-byte chunk index XORed by the row, so writes and reads are
     // conflict-free and no workgroup barrier is needed.
     // Pairs: the slabs live in the K1 / V1 buffers (two waves each), K0 / V0 are receiving the next q tile's first K/V tile.
-    // (WL: likewise - K0 / V0 are receiving the next unit's first tile)
-    unsigned char* slab = (PAIR || WL) ? smem_all + (wave < 2 ? KTILE_B + wave * (WQ * ROWB) : 2 * KTILE_B + VTILE_B + (wave - 2) * (WQ * ROWB))
+    unsigned char* slab = PAIR ? smem_all + (wave < 2 ? KTILE_B + wave * (WQ * ROWB) : 2 * KTILE_B + VTILE_B + (wave - 2) * (WQ * ROWB))
                                : smem_all + wave * (WQ * ROWB);
-    static_assert(!(PAIR || WL) || (NWAVES <= 4 && 2 * WQ * ROWB <= KTILE_B && 2 * WQ * ROWB <= VTILE_B), "pair epilogue slabs must fit K1 / V1");
+    static_assert(!PAIR || (NWAVES <= 4 && 2 * WQ * ROWB <= KTILE_B && 2 * WQ * ROWB <= VTILE_B), "pair epilogue slabs must fit K1 / V1");
     constexpr int CPR = D / 8;   // 16-byte chunks per row
     constexpr int ESW = CPR & -CPR;   // the slab's XOR swizzle stays inside aligned groups of this many chunks (the largest power of two in CPR: 8 at head_dim 192)
-    if (wave_active && (!WL || wl_out)) {
+    if (wave_active) {
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         const float lt = lsum[b][0];
@@ -732,41 +554,21 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = (T)(o[b][dt][4 * rg + j] * inv);
                 const int ch = 4 * dt + rg;                                   // chunk holding d = 32dt + 8rg + 4h ..+3
-                *(vec4*)(slab + r_e * ROWB + ((ch ^ (r_e & (ESW - 1))) << 4) + 8 * h_e) = w;
+                *(vec4*)(slab + r * ROWB + ((ch ^ (r & (ESW - 1))) << 4) + 8 * h) = w;
             }
         }
-        const int row_b = q_row0 + r_e + 32 * b;
-        if (p.lse != nullptr && h_e == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * p.scale + __logf(lt);
+        const int row_b = qrow + 32 * b;
+        if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * p.scale + __logf(lt);
 #pragma unroll
         for (int i = 0; i < CPR / 2; ++i) {                      // 64 chunks per store instruction: 8 rows at D=64, 4 at 128, 2 2/3 at 192, 2 at 256
-            const int rr = (i * 64 + lane_e) / CPR, ch = (i * 64 + lane_e) % CPR;
+            const int rr = (i * 64 + lane) / CPR, ch = (i * 64 + lane) % CPR;
             const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (ESW - 1))) << 4));
             const int orow = q_row0 + 32 * b + rr;
             if (orow < L && ch < dchunks && (FA_DMA_ABL != 6 || val.x == 0x12345u)) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
         }
     }
     }   // wave_active
-    // (ONE load site behind the epilogue's join: loads on both arms of the branch meet in register copies, and a copy waits for its load)
-    if constexpr (WL) { FA_WL_LOAD_NEXT_Q() }
-#ifdef FA_STAMPS
-    if constexpr (WL) {
-        const unsigned long long we_ = __builtin_amdgcn_s_memtime();
-        acc_wait_ += wb_ - wa_; acc_loop_ += wc_ - wb_; acc_fold_ += wd_ - wc_; acc_epi_ += we_ - wd_;
-        acc_units_ += 1; acc_tiles_ += (unsigned long long)n_rounds; acc_folds_ += (cur_parts > 1 && wl_out) ? 1 : 0;
-    }
-#endif
-    if constexpr (WL) {   // the next unit becomes the unit in hand
-        if (nx_u < 0) break;
-        g = nx_g; cur_qi = nx_qi; cur_t0 = nx_t0; cur_t1 = nx_t1; cur_part = nx_part; cur_parts = nx_parts; cur_k0 = nx_k0;
-        bb = g / p.H; hh = g - bb * p.H;
-        qg = (const T*)p.q + (int64_t)bb * p.q_sb + (int64_t)hh * p.q_sh;
-        kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;
-        vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
-        og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
-    }
     }   // pass
-#undef FA_WL_DECODE
-#undef FA_WL_LOAD_NEXT_Q
 #undef FA_DMA_TILE
 #undef FA_MASK_PREFETCH
 #undef FA_TILE_BARRIER
@@ -783,16 +585,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p, const WlPara
     {   // stamps go to a buffer of their own (fa_debug_set_stamp_buffer), never to an output: 16 u64 per wave
         unsigned long long st3_;
         FA_STAMP(st3_)
-        if (WL && p.stamps != nullptr && lane == 0) {
-            unsigned long long* sp = p.stamps + ((int64_t)blockIdx.x * NWAVES + wave_all) * 16;
-            unsigned hwid, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            sp[0] = st0_; sp[1] = acc_wait_; sp[2] = acc_loop_; sp[3] = st3_; sp[4] = ((unsigned long long)xcc << 32) | hwid;
-            sp[5] = acc_tiles_; sp[6] = acc_units_; sp[7] = acc_fold_; sp[8] = acc_epi_; sp[9] = (unsigned long long)blockIdx.x;
-            sp[10] = rt0_; sp[11] = __builtin_amdgcn_s_memrealtime(); sp[12] = acc_folds_;
-        }
-        if (!WL && p.stamps != nullptr && lane == 0) {
+        if (p.stamps != nullptr && lane == 0) {
             unsigned long long* sp = p.stamps + (((int64_t)g * nslot + qd) * (NWAVES * SPLIT) + wave_all) * 16;
             int tot_tiles = 0;   // kv tiles this workgroup streamed (both q tiles of a pair)
             for (int ps = 0; ps < n_pass; ++ps) {

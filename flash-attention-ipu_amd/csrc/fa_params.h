@@ -53,23 +53,6 @@ struct FwdParams {
     unsigned long long* stamps;   // measurement builds only (-DFA_STAMPS, scripts/phase_times.py): 16 u64 per wave, else null
 };
 
-// Work-list launch (fa_fwd_wl.hip): a grid of (at most) the chip's resident workgroups; workgroup b runs its share of list b & 7's
-// (group, q tile, kv part) UNITS.  Unit u of list x (the groups g = x mod 8, ng(x) of them) is pattern entry u / ng(x) - heaviest first -
-// of group 8 (u mod ng(x)) + x.  The first n_split pattern entries are the kv parts of q tiles whose kv loop is cut in `parts` pieces;
-// each such part publishes its (m, l, O) to a partial slot of the caller's workspace and the part that arrives last folds them.
-// Workspace layout (fa_capi.cpp wl_make; the tickets are zero before the first launch, every launch leaves them zero):
-//   [ticket_off, ...)    one arrival counter per (group, q tile)       [slot_off, ...)  partial slots of slot_bytes each, (group, entry)-major
-constexpr int kWlMaxPattern = 256;
-struct WlParams {
-    unsigned* ws;
-    int64_t ticket_off, slot_off;     // bytes
-    int32_t n_pat;                    // pattern entries = units per group
-    int32_t n_split;                  // leading entries that own a partial slot
-    int32_t slot_bytes;
-    int32_t nq;                       // q tiles per group (ticket index = g * nq + qi)
-    uint32_t pat[kWlMaxPattern];      // qi | part << 8 | parts << 16
-};
-
 // backward (fa_bwd_kernels.hip)
 struct BwdParams {
     const void* q; const void* k; const void* v; const void* o; const void* dout;
@@ -115,7 +98,6 @@ hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hip
 hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream); // fa_fwd_pipe16.hip
 hipError_t launch_fwd_pp(const FwdParams& p, int dtype, hipStream_t stream);                        // fa_fwd_pp.hip (head_dim 64)
 hipError_t launch_fwd_kh(const FwdParams& p, int dtype, int split, hipStream_t stream);             // fa_fwd_kh.hip
-hipError_t launch_fwd_wl(const FwdParams& p, const WlParams& w, int dtype, int grid, hipStream_t stream);   // fa_fwd_wl.hip (persistent work-list launch)
 double probe_mfma_peak(int dtype, int iters, int random_data);
 hipError_t launch_clock_sampler(unsigned long long* out, int spins, hipStream_t stream);   // fa_probe.hip
 

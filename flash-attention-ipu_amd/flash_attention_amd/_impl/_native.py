@@ -17,7 +17,7 @@ _LIB = None
 _LIB_PATH = None
 
 FA_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
-ABI_VERSION = 6
+ABI_VERSION = 5
 
 
 class FaPlan(ctypes.Structure):
@@ -36,11 +36,6 @@ class FaPlan(ctypes.Structure):
         ("source", ctypes.c_int32),
         ("pair", ctypes.c_int32),
         ("balanced", ctypes.c_int32),
-        ("wl", ctypes.c_int32),
-        ("wl_cap", ctypes.c_int32),
-        ("wl_units", ctypes.c_int32),
-        ("wl_grid", ctypes.c_int32),
-        ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -98,11 +93,6 @@ def _declare(lib):
     lib.fa_fwd.restype = ctypes.c_int
     lib.fa_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, p64, p64, p64, p64,
                            i32, i32, i32, ctypes.c_float, i32, vp]
-    lib.fa_fwd_ws.restype = ctypes.c_int
-    lib.fa_fwd_ws.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, p64, p64, p64, p64,
-                              i32, i32, i32, ctypes.c_float, i32, vp, i64, vp]
-    lib.fa_fwd_workspace_bytes.restype = ctypes.c_int64
-    lib.fa_fwd_workspace_bytes.argtypes = [i64, i64, i64, i32, i32, i32, ctypes.c_float, i32]
     lib.fa_bwd.restype = ctypes.c_int
     lib.fa_bwd.argtypes = [vp] * 10 + [i64, i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64 * 3), i32, ctypes.c_float, i32, vp]
     u64 = ctypes.c_uint64
@@ -118,8 +108,6 @@ def _declare(lib):
     lib.fa_probe_mfma_peak.argtypes = [i32, i32, i32]
     lib.fa_fwd_qkv_packed.restype = ctypes.c_int
     lib.fa_fwd_qkv_packed.argtypes = [vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
-    lib.fa_fwd_qkv_packed_ws.restype = ctypes.c_int
-    lib.fa_fwd_qkv_packed_ws.argtypes = [vp, vp, vp, i64, i64, i64, i32, i32, i32, vp, i64, vp]
 
 
 def _raise(rc):
@@ -145,7 +133,7 @@ def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale: float = 1.0
 
 _KERNEL_CODE = {"auto": 0, "": 0, None: 0, "dma": ord("d"), "pipe": ord("p"), "pipe16": ord("x"), "pp": ord("P"), "kh": ord("h"), "tile": ord("t")}
 _OPTION_AUTO = {"kernel": 0, "qb": 0, "waves": 0, "sched": 0, "skipmax": -1, "f32_generic": 0, "table": 1, "split": 0, "pair": -1,
-                "balance": -1, "fold": -1, "mirror": -1, "wl": -1, "wl_cap": 0, "wl_slots": 0}
+                "balance": -1, "fold": -1, "mirror": -1}
 
 
 def experimental_kernels() -> bool:
@@ -161,7 +149,6 @@ def set_debug_option(name: str, value) -> None:
     rc = lib.fa_debug_set_option(name.encode(), int(value))
     if rc != 0:
         _raise(rc)
-    _WS_NEED.clear()      # (an option can change what a request needs)
 
 
 def get_debug_option(name: str) -> int:
@@ -236,44 +223,13 @@ class _on_device_of:
         return False
 
 
-# ---- the workspace fa_fwd_ws borrows for persistent work-list launches (include/flash_attention_amd.h, ABI 6) ----------------------
-# One zero-filled uint8 tensor per (device, stream): launches on one stream are ordered, and every launch leaves the workspace's
-# counters zero, so the tensor is lent again and again without being touched from here.  The library allocates nothing; this is the
-# caller's side of that contract.  A workspace is never freed or shrunk: a captured HIP graph holds its address.
-_WS = {}          # (device index, raw stream) -> tensor
-_WS_KEEP = []     # replaced (outgrown) workspaces
-_WS_NEED = {}     # request -> bytes (fa_fwd_workspace_bytes), dropped whenever a debug option changes
-
-
-def _workspace(lib, idx, stream, key):
-    """(pointer, bytes) of the workspace to lend to this request on this stream; (None, 0) when the request uses none."""
-    need = _WS_NEED.get(key)
-    if need is None:
-        need = _WS_NEED[key] = int(lib.fa_fwd_workspace_bytes(*key))
-    if need == 0:
-        return None, 0
-    t = _WS.get((idx, stream))
-    if t is None or t.numel() < need:
-        if torch.cuda.is_current_stream_capturing():
-            return None, 0            # (no allocation inside a capture: the launch runs its static plan)
-        if t is not None:
-            _WS_KEEP.append(t)
-        size = max(need, 1 << 24)
-        t = _WS[(idx, stream)] = torch.zeros((size + (1 << 20) - 1) >> 20 << 20, dtype=torch.uint8, device=torch.device("cuda", idx))
-    return t.data_ptr(), t.numel()
-
-
 def fwd_packed(qkv: torch.Tensor, out: torch.Tensor, lse, num_chunks_q: int, num_chunks_kv: int):
     """qkv: contiguous CUDA [3,G,L,D]; out: contiguous [G,L,D]; lse: None or fp32 [G,L]."""
     lib = load_native_library()
     _, G, L, D = qkv.shape
-    dt = FA_DTYPE[qkv.dtype]
     with _on_device_of(qkv) as stream:
-        dev = qkv.device.index
-        ws, ws_bytes = _workspace(lib, torch.cuda.current_device() if dev is None else dev, stream,
-                                  (G, L, D, dt, num_chunks_q, num_chunks_kv, 1.0, 1))
-        rc = lib.fa_fwd_qkv_packed_ws(qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
-                                      G, L, D, num_chunks_q, num_chunks_kv, dt, ws, ws_bytes, stream)
+        rc = lib.fa_fwd_qkv_packed(qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+                                   G, L, D, num_chunks_q, num_chunks_kv, FA_DTYPE[qkv.dtype], stream)
     if rc != 0:
         _raise(rc)
 
@@ -282,16 +238,12 @@ def fwd_strided(q, k, v, out, lse, G, L, D, heads, qs, ks, vs, os_, num_chunks_q
                 causal: bool = True, heads_kv=None):
     """Strided three-view forward: see fa_fwd in include/flash_attention_amd.h."""
     lib = load_native_library()
-    dt = FA_DTYPE[q.dtype]
     with _on_device_of(q) as stream:
-        dev = q.device.index
-        ws, ws_bytes = _workspace(lib, torch.cuda.current_device() if dev is None else dev, stream,
-                                  (G, L, D, dt, num_chunks_q, num_chunks_kv, float(scale), int(bool(causal))))
-        rc = lib.fa_fwd_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
-                           lse.data_ptr() if lse is not None else None, G, L, D, heads,
-                           heads if heads_kv is None else heads_kv,
-                           _strides3(qs), _strides3(ks), _strides3(vs), _strides3(os_),
-                           num_chunks_q, num_chunks_kv, dt, float(scale), int(bool(causal)), ws, ws_bytes, stream)
+        rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                        lse.data_ptr() if lse is not None else None, G, L, D, heads,
+                        heads if heads_kv is None else heads_kv,
+                        _strides3(qs), _strides3(ks), _strides3(vs), _strides3(os_),
+                        num_chunks_q, num_chunks_kv, FA_DTYPE[q.dtype], float(scale), int(bool(causal)), stream)
     if rc != 0:
         _raise(rc)
 

@@ -47,10 +47,9 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 6   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
+#define FA_ABI_VERSION 5   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
                               fa_fwd_ex / fa_bwd_ex (attention mask or bias, dropout); 5: fa_fwd_ex / fa_bwd_ex take `dropout_state`
-                              (seed and offset in DEVICE memory: graph-safe dropout), fa_experimental_kernels(); 6: fa_fwd_ws /
-                              fa_fwd_workspace_bytes (persistent work-list launches on a caller-owned workspace), fa_plan_t gains wl* */
+                              (seed and offset in DEVICE memory: graph-safe dropout), fa_experimental_kernels() */
 
 /* element types (reference allows FLOAT16 and FLOAT, FA.cpp:609; bf16 is new here) */
 enum { FA_DTYPE_F16 = 0, FA_DTYPE_BF16 = 1, FA_DTYPE_F32 = 2 };
@@ -103,15 +102,6 @@ typedef struct fa_plan_t {
                             2 = a debug override was in force (fa_debug_set_option / FA_AMD_* at load) */
     int32_t pair;        /* 1 = a workgroup owns two q tiles, (n - 1 - i) then i, one after the other (causal, 64-key tiles) [ABI 4] */
     int32_t balanced;    /* 1 = placement-balanced block order (a causal grid below one round of the chip's workgroup slots) [ABI 4] */
-    /* [ABI 6] the persistent work-list launch (fa_fwd_wl.hip): wl = 1 means fa_fwd_ws, lent a workspace of at least workspace_bytes,
-       runs THIS REQUEST as wl_grid persistent 128-row workgroups of the 64-key-tile kernel pulling wl_units (group, q tile, kv part)
-       units - a q tile of more than wl_cap kv tiles cut into parts that meet in the workspace - instead of the plan above, which is
-       what fa_fwd, and fa_fwd_ws without a workspace, launch */
-    int32_t wl;
-    int32_t wl_cap;
-    int32_t wl_units;
-    int32_t wl_grid;
-    int64_t workspace_bytes;
 } fa_plan_t;
 
 int fa_abi_version(void);
@@ -199,28 +189,6 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
            float softmax_scale, int32_t causal, void* stream);
 
 /*
- * fa_fwd on a caller-owned device workspace [ABI 6].  Launches that under-fill or barely fill the chip - the reference's own use of the
- * op is one: nanoGPT at block 1024 through the override (demo/train.py:58, scaled_dot_product_attention.py:52-53) - run faster as ONE
- * grid of persistent workgroups that pull (group, q tile, kv part) units from lists in device memory; the lists' heads, the arrival
- * tickets of q tiles whose kv loop is cut in parts and those parts' fp32 (m, l, O) live in the workspace.
- *   fa_fwd_workspace_bytes : how large a workspace the request can use; 0 = none (fa_fwd_ws then is fa_fwd).
- *   workspace              : 256-byte aligned device memory of workspace_bytes bytes, or NULL (then exactly fa_fwd).  A workspace smaller
- *                            than fa_fwd_workspace_bytes() is not an error: the call runs the plan fa_fwd runs.
- * Contract: the workspace is ZERO-FILLED before its first use; every launch leaves its counters zero, so it can be lent again without
- * re-initialising (to any request: the layout is per launch).  One launch at a time per workspace: launches on one stream are ordered,
- * launches on different streams need a workspace each.  The library still allocates nothing and never synchronises.
- * (No reference counterpart: the Poplar graph compiler places the reference's tiles statically, FA.cpp:229-328.)
- */
-int64_t fa_fwd_workspace_bytes(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q, int32_t num_chunks_kv,
-                               float softmax_scale, int32_t causal);
-int fa_fwd_ws(const void* q, const void* k, const void* v, void* out, float* lse,
-              int64_t G, int64_t L, int64_t D, int64_t heads, int64_t heads_kv,
-              const int64_t q_strides[3], const int64_t k_strides[3], const int64_t v_strides[3],
-              const int64_t o_strides[3],
-              int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype,
-              float softmax_scale, int32_t causal, void* workspace, int64_t workspace_bytes, void* stream);
-
-/*
  * Backward of fa_fwd (replaces flashAttentionQKVPackedGrad, flash_attention_qkv_packed.cpp:348-512, and
  * FlashAttentionQKVPackedGradOpx::grow, :643-658).  Unlike the reference it does not recompute the
  * forward: it takes the forward's `out` and `lse`.
@@ -288,9 +256,6 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* out, cons
 /* Forward on a contiguous packed qkv [3,G,L,D] -> out [G,L,D] (scale 1, causal). */
 int fa_fwd_qkv_packed(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,
                       int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, void* stream);
-/* the same on a caller-owned workspace (fa_fwd_ws above: NULL / 0 = exactly fa_fwd_qkv_packed)  [ABI 6] */
-int fa_fwd_qkv_packed_ws(const void* qkv, void* out, float* lse, int64_t G, int64_t L, int64_t D,
-                         int32_t num_chunks_q, int32_t num_chunks_kv, int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,6 @@ int g_stub_launches = 0;
 char g_stub_last = '-';
 
 extern "C" const char* hipGetErrorString(hipError_t) { return "stub"; }
-extern "C" hipError_t hipGetDevice(int* dev) { *dev = 0; return hipSuccess; }
-extern "C" hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 
 namespace fa {
 hipError_t launch_bwd(const BwdParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'B'; return hipSuccess; }
@@ -27,7 +25,6 @@ hipError_t launch_fwd_pipe(const FwdParams&, int, int, int, hipStream_t) { ++g_s
 hipError_t launch_fwd_pipe16(const FwdParams&, int, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'x'; return hipSuccess; }
 hipError_t launch_fwd_pp(const FwdParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'P'; return hipSuccess; }
 hipError_t launch_fwd_kh(const FwdParams&, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'h'; return hipSuccess; }
-hipError_t launch_fwd_wl(const FwdParams&, const WlParams&, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'w'; return hipSuccess; }
 double probe_mfma_peak(int, int, int) { return -1.0; }
 hipError_t launch_clock_sampler(unsigned long long*, int, hipStream_t) { return hipSuccess; }
 }  // namespace fa
