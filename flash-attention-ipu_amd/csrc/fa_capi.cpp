@@ -56,6 +56,7 @@ struct Options {
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
     std::atomic<int> mirror{-1};    // -1 auto, 0 off, 1 on: mirrored row blocks in the two-block pipelined kernel (causal, head_dim 64, L % 256 == 0)
     std::atomic<int> fold{-1};      // -1 auto (= off), 0 off, 1 on for scaled bf16 calls: the scale fold of the pipelined kernel (fa_fwd_pipe.hip FOLD)
+    std::atomic<int> subsets{-1};   // -1 auto, 0 off: q-tile subsets for group counts that leave XCDs idle (FwdParams::xs)
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -86,6 +87,7 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
         if (const char* e = getenv("FA_AMD_FOLD")) { if (*e) g_opt.fold = atoi(e); }
         if (const char* e = getenv("FA_AMD_MIRROR")) { if (*e) g_opt.mirror = atoi(e); }
+        if (const char* e = getenv("FA_AMD_SUBSETS")) { if (*e) g_opt.subsets = atoi(e); }
     });
     return g_opt;
 }
@@ -144,7 +146,29 @@ struct Selection {
     int pair;        // 'd' only: 1 = a workgroup owns q tiles (nq - 1 - i) and i, one after the other
     int perm_n;      // 'd' | 'h': > 0 = placement-balanced order of the XCD's first perm_n slots
     uint8_t perm[128];
+    int xs;          // q-tile subsets per group (FwdParams::xs); 1 = groups map to XCDs whole
 };
+
+// Groups go to XCDs by index mod 8 (a group's K/V then live in ONE XCD's L2).  A group count that is not a multiple of 8 leaves XCDs idle
+// (G = 2: six of eight; measured [2,32768,64]: 0.11 of peak) or unevenly loaded (G = 12: 2 + 1): where that wastes an eighth of the chip or more
+// the launch is laid out over G xs (group, q-tile subset) pairs instead, xs = 8 / gcd(G, 8) - a multiple of 8 pairs, every XCD the same
+// number; a group's K/V are then fetched into xs L2s, which is what the idle XCDs' bandwidth is there for.
+// xs = the smallest of 2, 4, 8 whose G xs pairs waste less than 9 % - unless the pairs an XCD then holds no longer share its L2: a group's K/V
+// (kv_bytes) are fetched by every XCD that holds one of its subsets, and an XCD with more than ~8 MB of K/V in flight re-fetches them per q tile
+// (measured, profiles/r05_subsets: [25,2048,64] with 8 subsets 26.6 -> 31.4 us, [7,4096,128] 60.3 -> 64.0 us); a group whose K/V exceed the
+// 4 MB L2 by themselves streams either way.
+int subsets_for(int64_t G, int64_t L, int64_t kv_bytes) {
+    const int64_t g8 = (G + 7) / 8 * 8;
+    if ((g8 - G) * 8 < g8) return 1;          // (less than an eighth of the XCD slots idle: whole groups - [36,1024,64], 10 %, lost 4 % to subsets)
+    for (int xs = 2; xs <= 8; xs *= 2) {
+        const int64_t gv = G * xs, gv8 = (gv + 7) / 8 * 8;
+        if ((gv8 - gv) * 100 >= 9 * gv8) continue;
+        if ((L + 255) / 256 < xs) return 1;                    // (every subset gets a tile of the widest workgroup)
+        const int64_t per_xcd = gv8 / 8;
+        return (kv_bytes >= (4ll << 20) || per_xcd * kv_bytes <= (8ll << 20)) ? xs : 1;
+    }
+    return 1;
+}
 
 // Placement-balanced block order for a causal 'd' launch whose workgroups are all resident at once (a grid of at most one
 // round of slots: e.g. GPT-2 small's attention call, 96 groups x 8 q tiles = 768 workgroups on 1024 slots).  Nothing is
@@ -308,12 +332,13 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
         // other's prologues; the pair's second tile waits for the first tile's stores at its first barrier) - built-in rule: off
         if (c.table_pair && pair_ok && c.source == 1) pair = 1;          // (a measured row may switch them on)
         if (opt.pair >= 0) { pair = (opt.pair != 0 && pair_ok) ? 1 : 0; c.source = 2; }
+        if (sel->xs > 1) pair = 0;                                       // (q-tile subsets: plain block map only)
     }
     sel->pair = pair;
     sel->perm_n = 0;
     // (the key-halves kernel takes the order too, but measured no gain from it - G = 8 L = 4096 31.7 vs 31.5 us, profiles/r03_kh/balance_*.txt:
     //  its launches are bound per SIMD, not per CU sum - so there it is applied on request only)
-    if (((which == 'd' && !pair && split == 1 && opt.balance != 0) || (which == 'h' && opt.balance == 1)) && r.causal && qb == 1 && waves == 4) {
+    if (((which == 'd' && !pair && split == 1 && opt.balance != 0) || (which == 'h' && opt.balance == 1)) && r.causal && qb == 1 && waves == 4 && sel->xs == 1) {
         const int rows = which == 'h' ? 64 : 32 * waves;                                    // q rows per workgroup
         const int64_t nqt = (L + rows - 1) / rows, ng = g8 / 8;
         const int64_t nitem = nqt;                                                          // workgroups per group
@@ -346,15 +371,18 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
     plan->block_kv = (which == 'p' || which == 'x' || which == 'P') ? 32 : 64;
     plan->skipmax = r.skip;
     plan->source = c.source;
-    plan->grid = g8 * ((L + plan->block_q - 1) / plan->block_q);
+    // workgroups launched for q tiles of `rows` rows: 8-aligned groups x tiles, or - q-tile subsets - 8-aligned (group, subset) pairs x tiles per pair
+    const int64_t xs = sel->xs, g8v = (r.G * xs + 7) / 8 * 8;
+    const auto grid_of = [&](int64_t rows) { const int64_t t = (L + rows - 1) / rows; return xs > 1 ? g8v * ((t + xs - 1) / xs) : g8 * t; };
+    plan->grid = grid_of(plan->block_q);
     if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
     if (which == 'x' && D == 64 && waves == 8) {   // 8 waves x 16 rows (experimental)
         plan->block_q = 128;
-        plan->grid = g8 * ((L + 127) / 128);
+        plan->grid = grid_of(128);
     }
     if (which == 'h') {   // 4 waves = 2 row blocks x 2 key halves per kv split group: 64-row workgroups
         plan->block_q = 64;
-        plan->grid = g8 * ((L + 63) / 64);
+        plan->grid = grid_of(64);
     }
     if (which == 'P') {   // one workgroup = 8 waves = two 256-row halves: the same q tile of two groups of one XCD class
         plan->waves = 8;
@@ -371,12 +399,13 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
         const int64_t kv_bytes = 2 * L * D * es;
         int64_t bunch = sched > 0 ? sched : (8ll << 20) / kv_bytes;
         if (opt.sched > 0) bunch = opt.sched;
-        int64_t ng = g8 / 8;
+        int64_t ng = (xs > 1 ? g8v : g8) / 8;
         if (which == 'P') { bunch = (bunch + 1) / 2; ng = (ng + 1) / 2; }   // (counted in PAIRS of groups)
         if (bunch < 1) bunch = 1;
         if (bunch > ng) bunch = ng;
         plan->sched = (int32_t)bunch;
     }
+    plan->xs = sel->xs;
     sel->which = which;
     sel->split = split;
 }
@@ -396,10 +425,15 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     sel->split = 1;
     sel->pair = 0;
     sel->perm_n = 0;
+    sel->xs = 1;
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
-    const int64_t g8 = (G + 7) / 8 * 8;
+    int64_t g8 = (G + 7) / 8 * 8;
     const int es = elt_size(dtype);
+    sel->xs = (mfma16_ok || f32_ok) ? subsets_for(G, L, 2 * L * D * es) : 1;
+    if (options().kernel == 't' || options().kernel == 'P' || options().subsets == 0) sel->xs = 1;      // (the experimental kernels map groups whole)
+    plan->xs = sel->xs;
+    if (sel->xs > 1) g8 = ((G * sel->xs + 7) / 8 * 8 + sel->xs - 1) / sel->xs;   // the groups the launch really spreads over the XCDs (~G), for the fill rules
     if (mfma16_ok) {
         Request r;
         r.G = G; r.L = L; r.D = D; r.g8 = g8; r.dtype = dtype; r.causal = causal; r.scale = scale; r.es = es;
@@ -424,12 +458,13 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
         plan->qb = 1;
         plan->block_q = 128;
         plan->block_kv = 32;
-        plan->grid = g8 * ((L + 127) / 128);
+        const int64_t g8v = (G * sel->xs + 7) / 8 * 8;
+        plan->grid = sel->xs > 1 ? g8v * (((L + 127) / 128 + sel->xs - 1) / sel->xs) : g8 * ((L + 127) / 128);
         plan->lds_bytes = 2 * 32 * (D + 1) * 4 + 2 * 32 * D * 4;
         {
             int64_t bunch = (8ll << 20) / (2 * L * D * es);
             if (opt.sched > 0) bunch = opt.sched;
-            const int64_t ng = g8 / 8;
+            const int64_t ng = (sel->xs > 1 ? g8v : g8) / 8;
             if (bunch < 1) bunch = 1;
             if (bunch > ng) bunch = ng;
             plan->sched = (int32_t)bunch;
@@ -460,7 +495,7 @@ const OptionName kOptionNames[] = {
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
     {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"fold", &Options::fold, -1, 1},
-    {"mirror", &Options::mirror, -1, 1},
+    {"mirror", &Options::mirror, -1, 1}, {"subsets", &Options::subsets, -1, 0},
 };
 
 }  // namespace
@@ -665,6 +700,14 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     p.causal = causal;
     p.nq_tiles = plan.kernel != 1 ? (int32_t)((L + plan.block_q - 1) / plan.block_q) : 0;
     if (extra_mfma) p.nq_tiles = (int32_t)((L + 127) / 128);     // fa_fwd_extra_kernel: 4 waves x 32 rows, exact-max arithmetic
+    p.xs = 1;
+    p.nq_real = p.nq_tiles;
+    if (sel.xs > 1 && plan.kernel != 1) {     // q-tile subsets: the block map runs over (group, subset) pairs (FwdParams::xs)
+        p.xs = sel.xs;
+        p.G = (int32_t)(G * sel.xs);
+        p.G8 = (int32_t)((G * sel.xs + 7) / 8 * 8);
+        p.nq_tiles = (p.nq_real + sel.xs - 1) / sel.xs;
+    }
     p.sched = plan.sched;
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;

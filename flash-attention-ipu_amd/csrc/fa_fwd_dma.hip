@@ -99,7 +99,14 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         g = (g0 + (rem - qd * bc)) * 8 + xcd;
     }
     if (g >= p.G) return;
-    const int n_pass = (PAIR && qd != nq - 1 - qd) ? 2 : 1;
+    if (p.xs > 1) {   // q-tile subsets (fa_params.h FwdParams::xs): g counts (group, subset) pairs; depth d of subset s is the group's depth d xs + s
+        const int s_ = g % p.xs;
+        g /= p.xs;
+        qd = qd * p.xs + s_;
+        if (qd >= p.nq_real) return;
+    }
+    const int nq_r = p.xs > 1 ? p.nq_real : nq;      // q tiles per (real) group
+    const int n_pass = (PAIR && qd != nq_r - 1 - qd) ? 2 : 1;
 #ifdef FA_STAMPS   /* measurement build only (scripts/phase_times.py): phase time stamps, written to p.stamps at the end */
     const unsigned long long st0_ = __builtin_amdgcn_s_memtime();
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
@@ -151,7 +158,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             qf[b][ks] = ch_ < dchunks ? ld_ : z_;  /* (columns past the true head dim: zeros) */   \
         }                                                                                          \
     }
-    FA_LOAD_Q(nq - 1 - qd)
+    FA_LOAD_Q(nq_r - 1 - qd)
 
     // ---- LDS-DMA geometry: piece pc = wave + j*NWAVES of a tile, lane -> source byte offset
     const unsigned k_slb = (unsigned)p.k_sl * 2, v_slb = (unsigned)p.v_sl * 2;   // row strides in bytes
@@ -436,7 +443,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     T* __restrict__ og = (T*)p.o + (int64_t)bb * p.o_sb + (int64_t)hh * p.o_sh;
 #pragma nounroll
     for (int pass = 0; pass < n_pass; ++pass) {
-    const int qi = pass == 0 ? nq - 1 - qd : qd;     // heaviest first; pairs: then the light partner
+    const int qi = pass == 0 ? nq_r - 1 - qd : qd;     // heaviest first; pairs: then the light partner
     const int q_row0 = qi * BQ + wave * WQ;
     const int qrow = q_row0 + r;                 // block b owns row qrow + 32 b
     const bool wave_active = q_row0 < L;
@@ -589,7 +596,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             unsigned long long* sp = p.stamps + (((int64_t)g * nslot + qd) * (NWAVES * SPLIT) + wave_all) * 16;
             int tot_tiles = 0;   // kv tiles this workgroup streamed (both q tiles of a pair)
             for (int ps = 0; ps < n_pass; ++ps) {
-                const int qi_ = ps == 0 ? nq - 1 - qd : qd;
+                const int qi_ = ps == 0 ? nq_r - 1 - qd : qd;
                 const int ke_ = (causal && (qi_ + 1) * BQ < L) ? (qi_ + 1) * BQ : L;
                 tot_tiles += (ke_ + BK - 1) / BK;
             }

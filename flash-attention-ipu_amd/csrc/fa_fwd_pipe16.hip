@@ -95,6 +95,12 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
         g = (g0 + (rem - qd * bc)) * 8 + xcd;
     }
     if (g >= p.G) return;
+    if (p.xs > 1) {   // q-tile subsets (fa_params.h FwdParams::xs): g counts (group, subset) pairs; depth d of subset s is the group's depth d xs + s
+        const int s_ = g % p.xs, qd_ = (nq - 1 - qi) * p.xs + s_;
+        g /= p.xs;
+        qi = p.nq_real - 1 - qd_;
+        if (qi < 0) return;
+    }
 
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;

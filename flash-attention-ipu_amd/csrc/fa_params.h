@@ -40,7 +40,12 @@ struct FwdParams {
     int32_t D;             // head dim the kernel runs at (64 | 128 for the MFMA kernels)
     int32_t Dr;            // the operands' true head dim (<= D, a multiple of 8): fa_fwd_dma_kernel reads the columns Dr .. D - 1 as zeros
                            // (out-of-range LDS-DMA chunks, predicated Q loads) and stores Dr columns - rows are Dr elements wide in memory
-    int32_t nq_tiles;      // q tiles per group
+    int32_t nq_tiles;      // q tiles per group of the block map (with xs > 1: per (group, subset) pair = ceil(nq_real / xs))
+    int32_t xs;            // q-tile subsets per group (>= 1).  Groups go to XCDs by index mod 8; a group count that leaves XCDs idle or
+                           // unevenly loaded (G = 2: six of eight idle; G = 12: four XCDs with two groups, four with one) is served as
+                           // G xs (group, subset) pairs, xs = 8 / gcd(G, 8): G, G8 and nq_tiles then describe the PAIRS, subset s of a
+                           // group holds its q tiles of depth s, s + xs, ... (depth 0 = the last, heaviest tile) and nq_real its tile count
+    int32_t nq_real;
     int32_t sched;         // groups per XCD bunch (>= 1): heavy-first order inside a bunch
     int32_t skipmax;       // f16 only: 1 = reference max from the first tile + overflow-triggered redo
     int32_t mirror;        // fa_fwd_pipe_kernel, head_dim 64, two blocks per wave, causal, L % 256 == 0: 1 = wave w owns row blocks w and 7 - w (fa_fwd_pipe.hip MIRROR)

@@ -17,7 +17,7 @@ _LIB = None
 _LIB_PATH = None
 
 FA_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class FaPlan(ctypes.Structure):
@@ -36,6 +36,7 @@ class FaPlan(ctypes.Structure):
         ("source", ctypes.c_int32),
         ("pair", ctypes.c_int32),
         ("balanced", ctypes.c_int32),
+        ("xs", ctypes.c_int32),
     ]
 
 
@@ -133,7 +134,7 @@ def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale: float = 1.0
 
 _KERNEL_CODE = {"auto": 0, "": 0, None: 0, "dma": ord("d"), "pipe": ord("p"), "pipe16": ord("x"), "pp": ord("P"), "kh": ord("h"), "tile": ord("t")}
 _OPTION_AUTO = {"kernel": 0, "qb": 0, "waves": 0, "sched": 0, "skipmax": -1, "f32_generic": 0, "table": 1, "split": 0, "pair": -1,
-                "balance": -1, "fold": -1, "mirror": -1}
+                "balance": -1, "fold": -1, "mirror": -1, "subsets": -1}
 
 
 def experimental_kernels() -> bool:

@@ -47,9 +47,9 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 5   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
+#define FA_ABI_VERSION 6   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
                               fa_fwd_ex / fa_bwd_ex (attention mask or bias, dropout); 5: fa_fwd_ex / fa_bwd_ex take `dropout_state`
-                              (seed and offset in DEVICE memory: graph-safe dropout), fa_experimental_kernels() */
+                              (seed and offset in DEVICE memory: graph-safe dropout), fa_experimental_kernels(); 6: fa_plan_t gains xs */
 
 /* element types (reference allows FLOAT16 and FLOAT, FA.cpp:609; bf16 is new here) */
 enum { FA_DTYPE_F16 = 0, FA_DTYPE_BF16 = 1, FA_DTYPE_F32 = 2 };
@@ -102,6 +102,9 @@ typedef struct fa_plan_t {
                             2 = a debug override was in force (fa_debug_set_option / FA_AMD_* at load) */
     int32_t pair;        /* 1 = a workgroup owns two q tiles, (n - 1 - i) then i, one after the other (causal, 64-key tiles) [ABI 4] */
     int32_t balanced;    /* 1 = placement-balanced block order (a causal grid below one round of the chip's workgroup slots) [ABI 4] */
+    int32_t xs;          /* q-tile subsets per group [ABI 6]: groups go to the 8 XCDs by index mod 8; where G leaves XCDs idle or unevenly loaded
+                            (G < 8, G = 12, ...) the launch is laid out over G * xs (group, subset) pairs, xs = 8 / gcd(G, 8), subset s of a
+                            group = its q tiles s, s + xs, ... counted from the last; 1 = groups map whole */
 } fa_plan_t;
 
 int fa_abi_version(void);
@@ -156,6 +159,7 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  *   "balance" -1 auto | 0 | 1       placement-balanced block order of a causal grid below one round of workgroup slots
  *   "fold"    -1 auto (off) | 0 | 1   1 = fold scale log2(e) into Q (pipelined kernel, bf16, head_dim 64, softmax_scale <= 1/4): +5 %, but an
  *                                   error of 2^-9 of the logit's magnitude - for callers who know their logits are small
+ *   "subsets" -1 auto | 0 off       q-tile subsets for group counts that leave XCDs idle (fa_plan_t.xs)
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
 int fa_debug_set_option(const char* name, int32_t value);
 int fa_debug_get_option(const char* name, int32_t* value);

@@ -1,0 +1,131 @@
+"""Group counts that are not a multiple of 8 (GPU, -m gpu): the forward kernels map groups to the 8 XCDs by index mod 8, and where that
+leaves XCDs idle or unevenly loaded the launch is laid out over (group, q-tile subset) pairs (fa_plan_t.xs, csrc/fa_capi.cpp subsets_for).
+Every forward kernel that takes the map is checked against the fp64 oracle and - bit for bit where the kernel is the same - against the
+whole-group map (`subsets` = 0).  The reference has no counterpart: Poplar places its tiles itself (FA.cpp:229-328); the contract checked is
+the op's, fa.py:48-53.
+"""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SEED = 1123581321
+
+
+def _mods():
+    from flash_attention_amd._impl import _native
+
+    assert _native.library_path() is not None
+    return _native
+
+
+def _run(native, qkv, causal, scale=1.0):
+    _, G, L, D = qkv.shape
+    out = torch.empty(G, L, D, device="cuda", dtype=qkv.dtype)
+    lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
+    st = (L * D, 0, D)
+    native.fwd_strided(qkv[0], qkv[1], qkv[2], out, lse, G, L, D, 1, st, st, st, st, 1, 1, scale, causal)
+    torch.cuda.synchronize()
+    return out, lse
+
+
+def _oracle_rows(qkv, rows, causal, scale=1.0):
+    """fp64 attention of the chosen rows of every group (the oracle's arithmetic, oracle/dense_attention.py, on a row subset)"""
+    q, k, v = (t.double() for t in qkv)
+    L = q.shape[1]
+    s = torch.einsum("grd,gkd->grk", q[:, rows], k) * scale
+    if causal:
+        s = s.masked_fill((torch.arange(L, device=q.device)[None, :] > torch.tensor(rows, device=q.device)[:, None])[None], float("-inf"))
+    return torch.softmax(s, -1) @ v, torch.logsumexp(s, -1)
+
+
+CASES = [
+    # G, L, D, kernel, expected xs
+    (2, 8192, 64, None, 4),        # six XCDs idle without subsets
+    (1, 4096, 64, None, 8),
+    (12, 1024, 64, None, 2),       # GPT-2 small at batch 1
+    (12, 2048, 64, "pipe", 2),
+    (3, 4096, 128, "pipe16", 8),
+    (5, 2048, 128, "kh", 8),
+    (6, 2048, 64, "dma", 4),
+    (25, 2048, 64, None, 4),       # GPT-2 XL at batch 1: the smallest subset count that evens the XCDs out
+    (2, 500, 64, "dma", 1),        # fewer 256-row q tiles than subsets: whole groups
+    (7, 4096, 128, None, 1),       # 8 subsets would put 14 MB of K/V on every XCD: whole groups
+    (100, 256, 64, None, 1),       # 4 % waste: whole groups
+]
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("G,L,D,kernel,xs", CASES)
+def test_subsets_vs_oracle_and_whole_group_map(G, L, D, kernel, xs, causal):
+    native = _mods()
+    from oracle import frozen_randn
+
+    dtype = torch.bfloat16
+    qkv = (frozen_randn(SEED + G + L, (3, G, L, D)) * D ** -0.25).to(dtype).cuda()
+    with native.debug_options(kernel=kernel):
+        plan = native.plan(G, L, D, dtype, 1, 1, causal=causal)
+        assert plan.xs == xs, (plan.xs, xs)
+        out, lse = _run(native, qkv, causal)
+        kern = plan.kernel
+    with native.debug_options(kernel=kernel, subsets=0):
+        whole = native.plan(G, L, D, dtype, 1, 1, causal=causal)
+        assert whole.xs == 1
+        out0, lse0 = _run(native, qkv, causal)
+    if (whole.kernel, whole.waves, whole.block_q) == (kern, plan.waves, plan.block_q):
+        assert torch.equal(out, out0) and torch.equal(lse, lse0)      # the same program on every row, in another order
+    rows = sorted({0, 1, 63, 64, L // 2, L - 129 if L > 129 else 0, L - 2, L - 1} | set(range(127, L, max(128, L // 8 // 128 * 128))))
+    ref, ref_lse = _oracle_rows(qkv, rows, causal)
+    for o, l in ((out, lse), (out0, lse0)):
+        err = (o[:, rows].double() - ref).abs()
+        assert torch.isfinite(o.float()).all()
+        assert not bool((err > 1e-2 + 1e-2 * ref.abs()).any()), err.max().item()
+        torch.testing.assert_close(l[:, rows].double(), ref_lse, atol=6e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_subsets_other_dtypes(dtype):
+    native = _mods()
+    from oracle import frozen_randn
+
+    G, L, D = 3, 2048, 64
+    qkv = (frozen_randn(SEED, (3, G, L, D)) * D ** -0.25).to(dtype).cuda()
+    plan = native.plan(G, L, D, dtype, 1, 1)
+    assert plan.xs == 8
+    out, lse = _run(native, qkv, True)
+    rows = [0, 1, 127, 128, 1000, L - 1]
+    ref, ref_lse = _oracle_rows(qkv, rows, True)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert (out[:, rows].double() - ref).abs().max().item() <= tol
+    torch.testing.assert_close(lse[:, rows].double(), ref_lse, atol=6e-3 if dtype != torch.float32 else 1e-4, rtol=1e-4)
+
+
+def test_subsets_through_the_public_op_with_a_mask_and_the_backward():
+    """G = 12 (batch 1 x 12 heads): the override's forward runs on subsets, the mask kernel takes the same map, and the backward (whole
+    groups) consumes the forward's logsumexp - gradients against autograd through the dense fp64 expression."""
+    native = _mods()
+    import flash_attention_amd.auto  # noqa: F401  (patches F.scaled_dot_product_attention)
+    import torch.nn.functional as F
+
+    torch.manual_seed(3)
+    B, H, L, D = 1, 12, 1024, 64
+    q, k, v = (torch.randn(B, H, L, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
+    assert native.plan(B * H, L, D, torch.bfloat16, 4, 4, softmax_scale=D ** -0.5).xs == 2
+    out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+    g = torch.randn_like(out)
+    out.backward(g)
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    s = (qd @ kd.transpose(-1, -2)) * D ** -0.5
+    s = s.masked_fill(torch.triu(torch.ones(L, L, device="cuda", dtype=torch.bool), 1), float("-inf"))
+    ref = torch.softmax(s, -1) @ vd
+    ref.backward(g.double())
+    assert (out.double() - ref).abs().max().item() <= 3e-2
+    for a, b in ((q.grad, qd.grad), (k.grad, kd.grad), (v.grad, vd.grad)):
+        assert (a.double() - b).abs().max().item() <= 6e-2 * max(1.0, b.abs().max().item())
+    # key-padding mask through the same map
+    keep = torch.ones(B, 1, 1, L, device="cuda", dtype=torch.bool)
+    keep[..., L - 100:] = False
+    om = F.scaled_dot_product_attention(q.detach(), k.detach(), v.detach(), attn_mask=keep)
+    sm = ((qd.detach() @ kd.detach().transpose(-1, -2)) * D ** -0.5).masked_fill(~keep, float("-inf"))
+    assert (om.double() - torch.softmax(sm, -1) @ vd.detach()).abs().max().item() <= 3e-2

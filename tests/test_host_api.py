@@ -3,6 +3,7 @@
 
 import ctypes
 import json
+import math
 import pathlib
 import re
 import subprocess
@@ -43,13 +44,13 @@ def test_library_exports_every_declared_symbol(native):
     lib = native.load_native_library()
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/flash_attention_amd.h but not exported"
-    assert lib.fa_abi_version() == 5
+    assert lib.fa_abi_version() == 6
     assert native.library_path().name == "libflash_attention.so"
 
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 5;}\n')
+    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 6;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
 
 
@@ -348,3 +349,54 @@ def test_gpu_tensor_without_gpu_fails_loudly(fa):
         pytest.skip("needs a CPU-only box")
     with pytest.raises((RuntimeError, AssertionError)):
         fa.flash_attention_qkv_packed(torch.zeros(3, 1, 8, 64).cuda(), 1, 1)
+
+
+@pytest.mark.parametrize("G,L,D", [(1, 4096, 64), (2, 32768, 64), (3, 2048, 64), (4, 16384, 128), (5, 1024, 64), (6, 8192, 64), (7, 4096, 128),
+                                   (9, 2048, 64), (10, 1024, 128), (12, 1024, 64), (20, 2048, 64), (25, 4096, 64), (12, 128, 64), (100, 1024, 64), (96, 1024, 64)])
+def test_q_tile_subsets_cover_every_tile_once(native, G, L, D):
+    """Groups go to the 8 XCDs by index mod 8; a group count that wastes >= 9 % of them is laid out as G * xs (group, q-tile subset) pairs
+    (fa_plan_t.xs).  The kernels' block map (csrc/fa_fwd_*.hip: XCD-major slots, bunches of `sched` groups, heaviest tile first, then
+    FwdParams::xs) is restated here from the plan's fields: every (group, q tile) must be reached by exactly one workgroup."""
+    p = native.plan(G, L, D, torch.bfloat16, 1, 1)
+    g8 = (G + 7) // 8 * 8
+    want_xs = 1      # the smallest of 2, 4, 8 that wastes < 9 % of the XCDs, where the pairs of an XCD still share its L2 (fa_capi.cpp subsets_for)
+    if (g8 - G) * 8 >= g8:
+        kv = 2 * L * D * 2
+        for xs_ in (2, 4, 8):
+            gv8 = (G * xs_ + 7) // 8 * 8
+            if (gv8 - G * xs_) * 100 < 9 * gv8:
+                want_xs = xs_ if (L + 255) // 256 >= xs_ and (kv >= 4 << 20 or gv8 // 8 * kv <= 8 << 20) else 1
+                break
+    assert p.xs == want_xs
+    nq_real = (L + p.block_q - 1) // p.block_q
+    xs = p.xs
+    Gv = G * xs if xs > 1 else G
+    G8 = (Gv + 7) // 8 * 8
+    nq = (nq_real + xs - 1) // xs if xs > 1 else nq_real
+    if p.pair:
+        pytest.skip("pairs have a map of their own")
+    assert p.grid == G8 * nq
+    seen = {}
+    for b in range(p.grid):
+        xcd, slot = b & 7, b >> 3
+        ng = G8 >> 3
+        per_bunch = p.sched * nq
+        bunch, rem = divmod(slot, per_bunch)
+        g0 = bunch * p.sched
+        bc = min(ng - g0, p.sched)
+        qd = rem // bc
+        g = (g0 + (rem - qd * bc)) * 8 + xcd
+        if g >= Gv:
+            continue
+        if xs > 1:
+            s, g = g % xs, g // xs
+            qd = qd * xs + s
+            if qd >= nq_real:
+                continue
+        key = (g, nq_real - 1 - qd)
+        assert key not in seen, key
+        seen[key] = b
+    assert len(seen) == G * nq_real and all(0 <= g < G and 0 <= q < nq_real for g, q in seen)
+    if xs > 1:      # every XCD gets the same number of (group, subset) pairs when G * xs is a multiple of 8
+        per_xcd = [sum(1 for (g, q), b in seen.items() if b & 7 == x) for x in range(8)]
+        assert max(per_xcd) - min(per_xcd) <= (nq_real + xs - 1) // xs, per_xcd
