@@ -110,7 +110,7 @@ int main() {
                                         if (ov.empty()) EXPECT(pl.block_q <= (chunk > 32 ? chunk : 32) || pl.kernel == 6 || Dk > 128);   // (head_dim 192 / 256 have the one 128-row form)
                                         // the grid covers every (group, q tile): 8-aligned groups x tiles (pairs: two tiles per workgroup)
                                         const int64_t g8 = (G + 7) / 8 * 8, tiles = (L + pl.block_q - 1) / pl.block_q;
-                                        // (q-tile subsets where G wastes 9 % of the XCDs or more: 8-aligned (group, subset) pairs x tiles per pair)
+                                        // (q-tile subsets where G wastes an eighth of the XCDs or more: 8-aligned (group, subset) pairs x tiles per pair)
                                         EXPECT(pl.xs == 1 || pl.xs == 2 || pl.xs == 4 || pl.xs == 8);
                                         if ((g8 - G) * 8 < g8) EXPECT(pl.xs == 1);
                                         if (pl.xs > 1) { const int64_t gv = G * pl.xs, gv8 = (gv + 7) / 8 * 8; EXPECT((gv8 - gv) * 100 < 9 * gv8 && (L + 255) / 256 >= pl.xs); }

@@ -354,7 +354,7 @@ def test_gpu_tensor_without_gpu_fails_loudly(fa):
 @pytest.mark.parametrize("G,L,D", [(1, 4096, 64), (2, 32768, 64), (3, 2048, 64), (4, 16384, 128), (5, 1024, 64), (6, 8192, 64), (7, 4096, 128),
                                    (9, 2048, 64), (10, 1024, 128), (12, 1024, 64), (20, 2048, 64), (25, 4096, 64), (12, 128, 64), (100, 1024, 64), (96, 1024, 64)])
 def test_q_tile_subsets_cover_every_tile_once(native, G, L, D):
-    """Groups go to the 8 XCDs by index mod 8; a group count that wastes >= 9 % of them is laid out as G * xs (group, q-tile subset) pairs
+    """Groups go to the 8 XCDs by index mod 8; a group count that wastes an eighth of them or more is laid out as G * xs (group, q-tile subset) pairs
     (fa_plan_t.xs).  The kernels' block map (csrc/fa_fwd_*.hip: XCD-major slots, bunches of `sched` groups, heaviest tile first, then
     FwdParams::xs) is restated here from the plan's fields: every (group, q tile) must be reached by exactly one workgroup."""
     p = native.plan(G, L, D, torch.bfloat16, 1, 1)
