@@ -32,6 +32,7 @@ import hashlib
 import json
 import os
 import pathlib
+import re
 import socket
 import subprocess
 import sys
@@ -102,12 +103,26 @@ def cpu_baseline(L, D, budget_s=9.0):
     import torch
     from oracle import dense_causal_attention
 
+    # every core the box GRANTS this process: its affinity mask, cut to the cgroup's CPU quota where one is set (threads beyond a
+    # quota are throttled, not run: oversubscription only slows the sample down)
     cores = os.cpu_count() or 1
+    granted_by = "os.cpu_count"
     try:
         cores = len(os.sched_getaffinity(0))
+        granted_by = "sched_getaffinity"
     except AttributeError:
         pass
-    cores = min(cores, 16)   # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = pathlib.Path(path).read_text().split()
+            quota = int(txt[0]) if txt[0] != "max" else -1
+            period = int(txt[1]) if len(txt) > 1 else int(pathlib.Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if quota > 0 and period > 0 and -(-quota // period) < cores:
+                cores = max(1, -(-quota // period))
+                granted_by = f"cgroup quota ({path})"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
     torch.set_num_threads(cores)
     slab = 8
     gen = torch.Generator().manual_seed(0)
@@ -126,13 +141,30 @@ def cpu_baseline(L, D, budget_s=9.0):
         med = times[len(times) // 2]
         legs[name] = {"value": round(flops / med / 1e12, 5), "reps": len(times), "median_ms_per_slab": round(med * 1e3, 1)}
     return {
-        "value": legs["fp32"]["value"], "unit": "TFLOP/s", "cores": cores, "kind": "port",
+        "value": legs["fp32"]["value"], "unit": "TFLOP/s", "cores": cores, "cores_granted_by": granted_by, "kind": "port",
         "sample": f"{legs['fp32']['reps']} reps of a {slab}-group slab (of 128) at L={L}, D={D}, fp32 dense torch "
                   f"restatement of fa.py:48-53, median {legs['fp32']['median_ms_per_slab']} ms/slab, scaled linearly in G",
         "bf16": {"value": legs["bf16"]["value"], "unit": "TFLOP/s",
                  "sample": f"{legs['bf16']['reps']} reps of the same slab in bf16 (the reference CPU path run on bf16 "
                            f"tensors), median {legs['bf16']['median_ms_per_slab']} ms/slab"},
     }
+
+
+def device_clock_mhz(torch, dev):
+    """Engine clock of the device in MHz: torch's device properties where they carry it, else the highest sclk level rocm-smi lists, else None."""
+    props = torch.cuda.get_device_properties(dev)
+    for attr in ("clock_rate", "clockRate"):
+        v = getattr(props, attr, 0) or 0
+        if v:
+            return int(v) // 1000
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        vals = [int(m) for m in re.findall(r"\((\d+)Mhz\)", out)]
+        if vals:
+            return max(vals)
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 def make_op(name, dev, seed=1, backward=False):
@@ -364,8 +396,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the cfg3 / cfg4 / cfg5-shard records")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gather of O (kernel only)")
-    ap.add_argument("--gather", default="allgather", choices=("allgather", "direct", "root"),
-                    help="N>1: RCCL all-gather (default), direct point-to-point gather, or gather to rank 0")
+    ap.add_argument("--gather", default="auto", choices=("auto", "allgather", "direct", "root"),
+                    help="N>1: how O is moved - auto (default): RCCL all-gather, direct point-to-point gather and gather to rank 0 are timed on "
+                         "the real shard before the ramp, every rank takes the all-reduced maximum and the fastest runs the headline; or force one")
     ap.add_argument("--slabs", type=int, default=8, help="cfg5: slabs per rank (gather of slab s under the kernel of slab s+1)")
     ap.add_argument("--backward", action="store_true", help="N=1: time fa_bwd (dQ + dK/dV kernels) of the config instead of the forward")
     ap.add_argument("--no-probes", action="store_true",
@@ -477,6 +510,38 @@ def main():
     do_gather = dist_on and not args.no_gather
     use_gloo = rehearse and not rehearse_cpu      # (one-GPU rehearsal: no exchange at all; the CPU rehearsal exchanges CPU tensors over gloo)
     launches_per_step = args.slabs if strong else 1
+
+    # ---- N > 1: which way to move O?  Measured HERE, before the ramp, on the real shard with the real kernel under it - the driver gets one
+    # 8-GPU run, and its headline must already run on the exchange this node is fastest with ("prefer direct / grouped
+    # point-to-point and measure").  Every rank runs the same sequence and takes the all-reduced maximum, so all agree on the minimum.
+    exchange_table, exchange_selection = None, "forced (--gather)"
+    if args.gather == "auto":
+        exchange_selection = "auto"
+        if do_gather and not use_gloo:
+            from flash_attention_amd.distributed import select_gather_mode
+
+            def give_up():      # a rank stuck in a collective leaves no headline to print: say so, and fail visibly
+                if rank == 0:
+                    emit_once({"metric": "fwd_attention_tflops_causal_L4096_D64", "value": None, "n_gpus": world,
+                               "error": "the exchange selection did not finish within 180 s (a rank left a collective?)"})
+                sys.stdout.flush()
+                os._exit(3)
+
+            watchdog = threading.Timer(180.0, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                q_sel = qkv[:, :g_launch].contiguous() if strong else qkv
+                step_sel = (lambda: fa.flash_attention_qkv_packed(q_sel, nq, nk)) if op_fn is None else op_fn
+                args.gather, exchange_table = select_gather_mode(step_sel(), step=step_sel, reps=max(2, min(args.steps, 5)))
+                exchange_selection = "auto: fastest kernel + exchange step of the three, timed before the ramp (maximum over ranks)"
+            except Exception as e:  # noqa: BLE001  (the selection must never cost the headline)
+                args.gather = "allgather"
+                exchange_selection = f"auto FAILED ({type(e).__name__}: {e})"[:200] + " -> all-gather"
+            finally:
+                watchdog.cancel()
+        else:
+            args.gather = "allgather"
     kernel_events = []                             # (start, end) per launch inside the timed region (N > 1)
     record = [False]
 
@@ -681,11 +746,13 @@ def main():
                        "tile": f"{plan.block_q} query rows x {plan.block_kv} keys per workgroup step ({plan.waves} waves, {plan.qb} query blocks per wave)",
                        "plan_source": {0: "built-in rules", 1: "measured tuning table", 2: "debug override"}.get(plan.source),
                        "exchange": exchange,
+                       "exchange_selected": args.gather if do_gather else None,
+                       "exchange_selection": exchange_selection if do_gather else None,
                        "flops_per_step_per_gpu": flops_step,
                        "device": {"name": "cpu (FA_BENCH_REHEARSE=cpu: numbers are meaningless)"} if rehearse_cpu else
                                  {"name": torch.cuda.get_device_name(dev),
                                   "compute_units": torch.cuda.get_device_properties(dev).multi_processor_count,
-                                  "clock_mhz": getattr(torch.cuda.get_device_properties(dev), "clock_rate", 0) // 1000 or None}},
+                                  "clock_mhz": device_clock_mhz(torch, dev)}},
             "exchange_bytes_per_rank": {"sent": shard_bytes if do_gather else 0,
                                         "received": ((world - 1) * shard_bytes if args.gather != "root" or rank == 0 else 0) if do_gather else 0} if dist_on else None,
             # what the exchange alone needs when every GPU pair has its own xGMI link and each link carries ONE shard per direction
@@ -703,6 +770,9 @@ def main():
                          "measured_mfma_peak": measured_peak,
                          "measured_mfma_peak_random_operands": measured_peak_random,
                          "frac_of_measured_peak_random_operands": round(achieved / measured_peak_random, 4) if measured_peak_random else None,
+                         # the same two from the per-step MEDIAN (a pass of its own, one event pair per step): the figure to quote when the two differ
+                         "achieved_median": round(flops_launch / (median_ms * 1e-3) / 1e12, 2) if median_ms else None,
+                         "frac_median": round(flops_launch / (median_ms * 1e-3) / 1e12 / PEAK_TFLOPS, 4) if median_ms else None,
                          "kernel": kname, "avg_launch_ms": round(kernel_ms, 4), "avg_launch_note": kernel_note,
                          "flops_per_launch": flops_launch,
                          "algorithmic_bytes": 4 * g_launch * L * D * 2},
@@ -742,80 +812,26 @@ def main():
                         v.pop(k2, None)
         if len(json.dumps(line)) > 7600:
             line.pop("ramp", None)
-    # (rank 0's line is complete except for the exchange comparison below)
-    # ---- N > 1: the three ways to move O, measured in THIS launch after the headline (one driver run tells the whole story):
-    # per mode the exchange alone (a fixed shard, no kernel: what the links deliver) and kernel + exchange per step, overlapped the
-    # way the headline overlaps them.  Every rank runs the same sequence; times are the maximum over ranks.
+    # N > 1: the exchange table of the selection above (per mode: the exchange alone - what the links deliver - and kernel + exchange per
+    # step, overlapped the way the headline overlaps them; maxima over ranks)
     gather_modes = None
-    compare_failed = False
-    if do_gather and not use_gloo and not strong:
-        from flash_attention_amd.distributed import GATHER_MODES
-
+    if exchange_table is not None:
         gather_modes = {}
-
-        def give_up():      # a rank that failed leaves the others inside a collective: after 120 s the headline goes out without the comparison
-            if rank == 0:
-                line["secondary"] = {"gather_modes": dict(gather_modes, error="comparison did not finish within 120 s (a rank left it?)")}
-                emit_once(line)
-            sys.stdout.flush()
-            os._exit(0)
-
-        watchdog = threading.Timer(120.0, give_up)
-        watchdog.daemon = True
-        watchdog.start()
-        try:     # (the comparison must never cost the headline: any failure is recorded and the line is still printed)
-            n_x = max(2, min(args.steps, 10))
-            shard = fa.flash_attention_qkv_packed(qkv, nq, nk)
-            bufs = [torch.empty(world * G, L, D, dtype=dtype, device=dev) for _ in range(2)]
-            for mode in GATHER_MODES:
-                gather_output(shard, out=bufs[0], mode=mode)               # warm-up (connections, first-use setup)
-                sync()
-                dist.barrier()
-                t_x = time.perf_counter()
-                for _ in range(n_x):
-                    gather_output(shard, out=bufs[0], mode=mode)
-                sync()
-                x_ms = (time.perf_counter() - t_x) / n_x * 1e3
-                dist.barrier()
-                pend = [None, None]
-                t_s = time.perf_counter()
-                for i in range(n_x):                                        # kernel of step i + 1 over the exchange of step i
-                    b = i & 1
-                    if pend[b] is not None:
-                        pend[b][1].wait()
-                    o_ = fa.flash_attention_qkv_packed(qkv, nq, nk)
-                    pend[b] = (o_, gather_output(o_, out=bufs[b], async_op=True, mode=mode)[1])
-                for pb in pend:
-                    if pb is not None:
-                        pb[1].wait()
-                sync()
-                s_ms = (time.perf_counter() - t_s) / n_x * 1e3
-                tm = torch.tensor([x_ms, s_ms], dtype=torch.float64, device=dev)
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                x_ms, s_ms = tm[0].item(), tm[1].item()
-                recv = (world - 1) * shard_bytes if mode != "root" else (world - 1) * shard_bytes       # the busiest rank's receive volume
-                gather_modes[mode] = {
-                    "exchange_only_ms": round(x_ms, 4), "ms_per_step": round(s_ms, 4),
-                    "value_tflops": round(world * flops_step / (s_ms * 1e-3) / 1e12, 2),
-                    "received_bytes_busiest_rank": recv,
-                    "achieved_GBps_per_link": round(shard_bytes / (x_ms * 1e-3) / 1e9, 2),
-                }
-
-        except Exception as e:  # noqa: BLE001
-            gather_modes["error"] = f"{type(e).__name__}: {e}"[:300]
-            compare_failed = True
-        finally:
-            watchdog.cancel()
-
-
+        for mode, rec_ in exchange_table.items():
+            x_ms, s_ms = rec_["exchange_only_ms"], rec_["ms_per_step"]
+            gather_modes[mode] = {
+                "exchange_only_ms": round(x_ms, 4), "ms_per_step": round(s_ms, 4),
+                "value_tflops": round(world * 2.0 * g_launch * L * L * D / (max(s_ms, 1e-9) * 1e-3) / 1e12, 2),
+                "received_bytes_busiest_rank": (world - 1) * (shard_bytes // launches_per_step),
+                # one shard per link and direction: what one xGMI link carried (0 at world size 1: nothing crosses a link)
+                "achieved_GBps_per_link": round((shard_bytes // launches_per_step) / (max(x_ms, 1e-9) * 1e-3) / 1e9, 2) if world > 1 else 0.0,
+                "selected": mode == args.gather,
+            }
     if rank == 0:
         if gather_modes is not None:
             line["secondary"] = {"gather_modes": gather_modes}
         emit_once(line)
     if dist_on:
-        if compare_failed:          # (no further collective after a failed exchange: the line is out, leave)
-            sys.stdout.flush()
-            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
     return rc

@@ -672,7 +672,10 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     int64_t Dk0 = kernel_head_dim(D, dtype);
     if (extra && Dk0 > 128) Dk0 = 0;               // (the mask / dropout kernels stop at head_dim 128: their dK/dV form does not fit the register file at 256)
-    const bool wide_ok = !wide_rows && Dk0 != 0 && aligned16(Dk0, elt_size(dtype), ptrs, strides) && L * k_strides[2] < (1ll << 31) && L * v_strides[2] < (1ll << 31);
+    // (a zero-extended call marks the chunks past the true head dim with the LDS-DMA offset 0x80000000 and relies on the descriptor's range
+    //  check to return zeros for it: the K / V extent of a group must then stay below 2^31 BYTES, or that offset is a real address)
+    const int64_t kv_extent_limit = (Dk0 != 0 && Dk0 != D) ? (1ll << 31) / elt_size(dtype) : (1ll << 31);
+    const bool wide_ok = !wide_rows && Dk0 != 0 && aligned16(Dk0, elt_size(dtype), ptrs, strides) && L * k_strides[2] < kv_extent_limit && L * v_strides[2] < kv_extent_limit;
     const int64_t Dk = wide_ok ? Dk0 : D;          // the head dim the launched kernel runs at (D itself on the generic path)
     const bool mfma16_ok = wide_ok && (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16);
     const bool f32_ok = wide_ok && dtype == FA_DTYPE_F32 && !options().f32_generic;
@@ -829,7 +832,8 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
             if (strides[i][j] < 0 || strides[i][j] > (1ll << 40)) return fail(FA_ERR_BAD_STRIDE, "strides must be in [0, 2^40] elements");
             if (strides[i][j] % row_align) mfma = false;
         }
-        if (strides[i][2] > (1ll << 32) || L * strides[i][2] >= (1ll << 31)) mfma = false;
+        // (zero-extended head dims: extents below 2^31 BYTES - the out-of-range LDS-DMA offset 0x80000000 must stay out of range, see fwd_impl)
+        if (strides[i][2] > (1ll << 32) || L * strides[i][2] >= ((Dk0 != 0 && Dk0 != D) ? (1ll << 31) / elt_size(dtype) : (1ll << 31))) mfma = false;
     }
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     if (extra && dtype == FA_DTYPE_F32) mfma = false;       // (the fp32 MFMA kernels have no mask path: generic kernels)

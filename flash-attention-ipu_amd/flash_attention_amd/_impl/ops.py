@@ -479,21 +479,35 @@ def _device_index(device) -> int:
     return device.index if device.index is not None else torch.cuda.current_device()
 
 
+# The device-resident stream is a stream of its own: its seed is torch's seed XOR this constant, so the warm-up run that precedes a capture
+# (eager: seed and offset from the host generator) and the first replay (device state) never draw the same decisions, and eager calls
+# interleaved with replays cannot land on a replay's (seed, offset) either.
+_GRAPH_STREAM_SALT = 0x5DEECE66D2B79F35
+
+
 def init_graph_dropout_state(device=None, seed: Optional[int] = None) -> torch.Tensor:
-    """Create (or re-seed) the device-resident dropout state of `device`: seed from torch's CUDA generator unless given."""
+    """Create - or RE-SEED IN PLACE - the device-resident dropout state of `device`: seed from torch's CUDA generator unless given.
+
+    A HIP graph captured earlier holds the ADDRESS of this tensor (its captured clone reads it, its captured add advances it), so an existing
+    state is overwritten, never replaced: re-seeding after a capture reaches the captured launches, and the memory they write stays owned.
+    torch.manual_seed() alone does not reach the device-resident state - call this afterwards to re-seed captured dropout."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     idx = _device_index(device)
     if torch.cuda.is_current_stream_capturing():
         raise RuntimeError("flash_attention_amd: the graph-safe dropout state must be created outside graph capture - run one eager "
                            "dropout call (the usual warm-up) or flash_attention_amd.init_graph_dropout_state() before torch.cuda.graph")
     gen = torch.cuda.default_generators[idx]
-    s = gen.initial_seed() if seed is None else int(seed)
+    s = (gen.initial_seed() if seed is None else int(seed)) ^ _GRAPH_STREAM_SALT
     try:
         off = gen.get_offset()
     except RuntimeError:
         off = 0
-    st = torch.tensor([s & (2 ** 63 - 1), off & (2 ** 63 - 1)], dtype=torch.int64, device=torch.device("cuda", idx))
-    _GRAPH_DROPOUT_STATE[idx] = st
+    fresh = torch.tensor([s & (2 ** 63 - 1), off & (2 ** 63 - 1)], dtype=torch.int64)
+    st = _GRAPH_DROPOUT_STATE.get(idx)
+    if st is None:
+        st = _GRAPH_DROPOUT_STATE[idx] = fresh.to(torch.device("cuda", idx))
+    else:
+        st.copy_(fresh)          # in place: captured graphs keep reading and advancing THIS memory
     return st
 
 

@@ -16,6 +16,7 @@ Same mechanism, guards, messages and chunk heuristic as the reference override
     like the reference.
 """
 
+import logging
 from math import ceil, floor, log2
 from typing import Callable, Optional
 
@@ -23,6 +24,18 @@ import torch
 
 from . import _native, ops
 from .utils import patch_function
+
+
+logger = logging.getLogger(__name__)
+_HANDOFF_REASONS = set()
+
+
+def _handoff(reason: str) -> None:
+    """A GPU call leaves for stock SDPA (`orig_fn`): say why, ONCE per distinct reason (the reference logs its patch, utils.py:35, and raises
+    where this override hands over - "why is my model slow" must be answerable from the log).  Silent while tracing: a log call breaks the graph."""
+    if reason not in _HANDOFF_REASONS and not torch.compiler.is_compiling():
+        _HANDOFF_REASONS.add(reason)
+        logger.info("flash_attention_amd: scaled_dot_product_attention call handed to stock SDPA: %s", reason)
 
 
 def chunk_heuristic(L: int, D: int):
@@ -149,6 +162,7 @@ def _scaled_dot_product_attention_amd(
             kw["scale"] = scale
         if enable_gqa:
             kw["enable_gqa"] = enable_gqa
+        _handoff("query and key sequence lengths differ (decode step / cross-attention): no kernel here takes L_q != L_kv")
         return orig_fn(query, key, value, attn_mask, dropout_p, is_causal, **kw)
     gqa = query.shape != key.shape
     # (grouped K/V heads are served only when the caller asks for them, as stock SDPA does: without enable_gqa=True a
@@ -170,11 +184,13 @@ def _scaled_dot_product_attention_amd(
     # else is stock SDPA's business
     if on_device and scale is not None and not (scale > 0.0 and scale < float("inf")):
         on_device = False
+        _handoff("scale is not a positive finite number")
     D_true = query.shape[-1]
     native_ok, Dp = _mfma_head_dim(D_true, query.dtype) if on_device else (True, None)
     if on_device and not native_ok and query.numel() > 0 and query.numel() // D_true >= GENERIC_KERNEL_MAX_ROWS:
         if Dp is None or torch.compiler.is_compiling():
             on_device = False       # (no MFMA kernel for this head dim: stock SDPA, not the scalar generic kernel)
+            _handoff(f"head dim {D_true} ({query.dtype}) is beyond the MFMA kernels (16-bit: multiples of 8 up to {MFMA_HEAD_DIM_MAX}; fp32: 64, 128)")
         else:
             if scale is None:
                 scale = D_true ** -0.5
@@ -184,6 +200,8 @@ def _scaled_dot_product_attention_amd(
         if out is not None:
             return _unpad(out, D_true)
         on_device = False       # (a combination the mask / dropout kernels do not take: stock SDPA serves it)
+        _handoff("attn_mask / dropout_p in a combination the mask kernels do not take (head dim above 128, fp32, attn_mask with is_causal, a mask "
+                 "that wants a gradient or does not broadcast to [B, H, L, L], dropout while tracing)")
         if query.shape[-1] != D_true:
             query, key, value = (t[..., :D_true] for t in (query, key, value))
     if on_device:

@@ -85,6 +85,61 @@ def gather_output(out_local: torch.Tensor, group=None, out: Optional[torch.Tenso
     return out
 
 
+def select_gather_mode(out_local: torch.Tensor, step=None, group=None, reps: int = 3, clock=None, modes=GATHER_MODES):
+    """Measure the ways to move O on THIS machine and agree on the fastest: (mode, table).
+
+    xGMI gives every GPU pair a link of its own, so the direct point-to-point gather should beat a ring all-gather -
+    but RCCL's all-gather is not necessarily a ring, and which one wins is a property of the node, so it is timed, not assumed.
+    Per mode: the exchange alone (`reps` gathers of `out_local`, no kernel) and - when `step` is given, a callable that runs the
+    forward and returns a fresh [G/W, L, D] - kernel + exchange per step with the gather of step s under the kernel of step s + 1
+    (double-buffered, as bench.py and SlabGather overlap them).  Every rank runs the same sequence (each gather is a collective);
+    the times are all-reduced to their MAXIMUM over ranks, so every rank sees the same table and takes the same minimum: ms_per_step
+    when `step` is given, else exchange_only_ms; ties go to the earlier entry of `modes`.
+    table[mode] = {"exchange_only_ms", "ms_per_step" (None without `step`)}.  `clock` (default time.perf_counter) is a test hook."""
+    import time
+
+    clock = clock or time.perf_counter
+    world = dist.get_world_size(group)
+    cuda = out_local.is_cuda
+    sync = torch.cuda.synchronize if cuda else (lambda: None)
+    bufs = [torch.empty((world * out_local.shape[0], *out_local.shape[1:]), dtype=out_local.dtype, device=out_local.device) for _ in range(2)]
+    reps = max(1, int(reps))
+    times = []
+    for mode in modes:
+        gather_output(out_local, group=group, out=bufs[0], mode=mode)            # warm-up (connections, first-use setup)
+        sync()
+        dist.barrier(group)
+        t0 = clock()
+        for _ in range(reps):
+            gather_output(out_local, group=group, out=bufs[0], mode=mode)
+        sync()
+        x_ms = (clock() - t0) / reps * 1e3
+        s_ms = 0.0
+        if step is not None:
+            dist.barrier(group)
+            pend = [None, None]
+            t0 = clock()
+            for i in range(reps):
+                b = i & 1
+                if pend[b] is not None:
+                    pend[b][1].wait()
+                o_ = step()
+                pend[b] = (o_, gather_output(o_, group=group, out=bufs[b], async_op=True, mode=mode)[1])   # (o_ stays alive until its gather completes)
+            for pb in pend:
+                if pb is not None:
+                    pb[1].wait()
+            sync()
+            s_ms = (clock() - t0) / reps * 1e3
+        times += [x_ms, s_ms]
+    tm = torch.tensor(times, dtype=torch.float64, device=out_local.device)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX, group=group)
+    tm = tm.tolist()
+    table = {m: {"exchange_only_ms": tm[2 * i], "ms_per_step": tm[2 * i + 1] if step is not None else None} for i, m in enumerate(modes)}
+    key = "ms_per_step" if step is not None else "exchange_only_ms"
+    best = min(modes, key=lambda m: (table[m][key], modes.index(m)))
+    return best, table
+
+
 def flash_attention_qkv_packed_sharded(qkv_local: torch.Tensor, num_chunks_q: int, num_chunks_kv: int,
                                        group=None, gather: bool = True, mode: str = "allgather") -> torch.Tensor:
     """Each rank passes ITS shard `qkv_local` [3, G/W, L, D]; returns the full [G, L, D] on every rank

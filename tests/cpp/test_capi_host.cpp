@@ -169,6 +169,14 @@ int main() {
     EXPECT(fa_debug_set_stamp_buffer(nullptr, 8) == FA_ERR_BAD_OPTION && fa_debug_set_stamp_buffer(buf + 1, 64) == FA_ERR_MISALIGNED);
     EXPECT(fa_debug_set_stamp_buffer(buf, 64) == FA_OK && fa_debug_set_stamp_buffer(nullptr, 0) == FA_OK);
     EXPECT(g_stub_launches == launches0 + 5);
+    {   // a zero-extended head dim (96 runs at 128) marks the chunks past it with the LDS-DMA offset 0x80000000: the MFMA kernels take the call
+        // only while a group's K / V extent is below 2^31 BYTES; a head-inner layout with a longer extent goes to the generic kernel (round-4 advisor)
+        const int64_t inner96[3] = {262144ll * 6144, 96, 6144}, short96[3] = {4096ll * 6144, 96, 6144};
+        EXPECT(fa_fwd(p, p, p, p, nullptr, 64, 4096, 96, 64, 64, short96, short96, short96, short96, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last != 'g');
+        EXPECT(fa_fwd(p, p, p, p, nullptr, 64, 262144, 96, 64, 64, inner96, inner96, inner96, inner96, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last == 'g');
+        const int64_t inner128[3] = {131072ll * 8192, 128, 8192};     // (a native head dim keeps the 2^31-ELEMENT bound)
+        EXPECT(fa_fwd(p, p, p, p, nullptr, 64, 131072, 128, 64, 64, inner128, inner128, inner128, inner128, 1, 1, FA_DTYPE_BF16, 1.0f, 1, nullptr) == FA_OK && g_stub_last != 'g');
+    }
     int64_t st8[8][3];
     for (auto& r : st8) { r[0] = 128 * 64; r[1] = 0; r[2] = 64; }
     float fbuf[4];

@@ -84,6 +84,58 @@ def test_sharded_forward_gloo(world):
     assert sorted(results) == [(r, True) for r in range(world)]
 
 
+def _select_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flash_attention_amd.distributed import select_gather_mode
+
+        # a fake clock: rank 0 alone would pick "allgather" (1 / 5 / 9 ms per step), rank 1 alone "direct" (9 / 2 / 3) - the all-reduced
+        # maxima are 9 / 5 / 9, so BOTH must come out with "direct" and with the same table
+        per_step_ms = [[1.0, 5.0, 9.0], [9.0, 2.0, 3.0]][rank]
+        ticks = []
+        for ms in per_step_ms:
+            ticks += [0.0, 0.5e-3 * 2, 0.0, ms * 1e-3 * 2]     # exchange-only interval, then the overlapped-step interval (reps = 2)
+        now, it = [0.0], iter(ticks)
+
+        def clock():
+            now[0] += next(it)
+            return now[0]
+
+        local = torch.full((2, 4, 8), float(rank))
+        calls = [0]
+
+        def step():
+            calls[0] += 1
+            return local.clone()
+
+        mode, table = select_gather_mode(local, step=step, reps=2, clock=clock)
+        q.put((rank, mode, {k: (round(v["exchange_only_ms"], 6), round(v["ms_per_step"], 6)) for k, v in table.items()}, calls[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_selection_agrees_across_ranks_on_the_all_reduced_maximum():
+    """bench.py --gather auto / distributed.select_gather_mode at world size 2 on gloo: ranks whose own clocks prefer DIFFERENT exchanges
+    must leave the selection with the same mode and the same table (every time is the maximum over ranks)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_select_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, m0, t0, c0), (_, m1, t1, c1) = res
+    assert m0 == m1 == "direct" and t0 == t1
+    assert t0["allgather"][1] == 9.0 and t0["direct"][1] == 5.0 and t0["root"][1] == 9.0
+    assert c0 == c1 == 6           # two overlapped steps per mode, every rank the same sequence of collectives
+
+
 def test_shard_range():
     from flash_attention_amd.distributed import shard_range
 
@@ -139,8 +191,14 @@ def test_bench_n2_control_flow_and_json_schema_on_cpu(config, extra):
     assert line["kernel_only_value"] >= 0 and line["roofline"]["avg_launch_ms"] > 0
     assert line["exchange_bytes_per_rank"]["sent"] > 0 and line["exchange_bytes_per_rank"]["received"] > 0
     assert "workload" in line["config"] and "exchange" in line["config"]
-    if config != "cfg5":
+    if not extra or config == "cfg5":     # --gather auto (the default): the three exchanges were timed before the ramp and the fastest ran the headline
         modes = line["secondary"]["gather_modes"]
         assert set(modes) == {"allgather", "direct", "root"}
         for m in modes.values():
             assert m["exchange_only_ms"] > 0 and m["ms_per_step"] > 0 and m["achieved_GBps_per_link"] >= 0 and m["value_tflops"] >= 0
+        chosen = [k for k, m in modes.items() if m["selected"]]
+        assert chosen == [line["config"]["exchange_selected"]] and line["config"]["exchange_selection"].startswith("auto: fastest")
+        assert modes[chosen[0]]["ms_per_step"] == min(m["ms_per_step"] for m in modes.values())
+    else:
+        assert line["config"]["exchange_selected"] == "direct" and line["config"]["exchange_selection"].startswith("forced")
+        assert "secondary" not in line or "gather_modes" not in line["secondary"]

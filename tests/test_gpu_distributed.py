@@ -87,8 +87,12 @@ def test_bench_multi_gpu_control_flow_on_rccl_at_world_size_1(extra):
     assert rec["kernel_only_value"] >= rec["value"] * 0.5
     assert rec["exchange_bytes_per_rank"]["sent"] > 0 and rec["expected_link_bound_ms"] > 0
     assert "rccl" in rec["config"]["exchange"] or "point-to-point" in rec["config"]["exchange"]
-    if not strong and not extra:
+    if "--gather" not in extra:       # auto: the three exchanges timed before the ramp, all ranks agreed on the fastest
         modes = rec["secondary"]["gather_modes"]
         assert set(modes) == {"allgather", "direct", "root"}, modes
         for m in modes.values():
             assert m["ms_per_step"] > 0 and m["exchange_only_ms"] >= 0
+        assert [k for k, m in modes.items() if m["selected"]] == [rec["config"]["exchange_selected"]]
+        assert rec["config"]["exchange_selection"].startswith("auto: fastest")
+    else:
+        assert rec["config"]["exchange_selected"] == "direct"

@@ -362,6 +362,27 @@ def test_dropout_under_graph_capture_draws_a_fresh_mask_on_every_replay():
     eager = F.scaled_dot_product_attention(q.detach(), k.detach(), v.detach(), dropout_p=p, is_causal=True)
     assert torch.isfinite(eager).all()
     assert ops._GRAPH_DROPOUT_STATE[0] is state
+    # re-seeding AFTER the capture (round-4 advisor): the state is overwritten in place - the same tensor, the same address the graph holds -
+    # so the next replay reads the new seed, and a re-seed to a known value reproduces that replay's mask
+    ptr = state.data_ptr()
+    again = flash_attention_amd.init_graph_dropout_state(dev, seed=777)
+    assert again is state and state.data_ptr() == ptr
+    seed_a, off_a = (int(x) for x in state.tolist())
+    assert seed_a == (777 ^ ops._GRAPH_STREAM_SALT) & (2 ** 63 - 1) and seed_a != results[0][0]
+    graph.replay()
+    torch.cuda.synchronize()
+    first = out.clone()
+    qr, kr, vr = (t.detach().cpu().double() for t in (q, k, v))
+    ref, _ = dense_attention_extra(qr, kr, vr, D ** -0.5, True, None, p, seed_a, off_a)
+    _fwd_close(first, ref, "replay after an in-place re-seed")
+    flash_attention_amd.init_graph_dropout_state(dev, seed=777)
+    state[1] = off_a                                    # (same seed, same offset: the same decisions)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, first)
+    # the device-resident stream is not the eager stream: same torch seed, different decisions
+    torch.manual_seed(1234)
+    assert int(flash_attention_amd.init_graph_dropout_state(dev)[0]) != 1234
 
 
 def test_attn_mask_stays_on_the_hip_path_under_torch_compile():

@@ -153,12 +153,18 @@ def test_sdpa_override_serves_the_widened_modes():
         patched(q, k.repeat_interleave(2, 1), v.repeat_interleave(2, 1), is_causal=True)
 
 
-def test_different_sequence_lengths_go_to_stock_sdpa_on_the_gpu_and_raise_off_it():
+def test_different_sequence_lengths_go_to_stock_sdpa_on_the_gpu_and_raise_off_it(caplog):
     """A decode step against a key/value cache (L_q = 1) and cross-attention (L_q != L_kv): the reference rejects every query.shape !=
     key.shape (scaled_dot_product_attention.py:33-37); off the GPU so does the override, on the GPU the call is stock SDPA's - importing
-    the override must not break a generation loop."""
+    the override must not break a generation loop.  The hand-off is logged, once per distinct reason (the reference logs its patch, utils.py:35)."""
+    import logging
+
     import flash_attention_amd.auto  # noqa: F401
     from flash_attention_amd._impl import _native
+    from flash_attention_amd._impl import scaled_dot_product_attention as ov
+
+    ov._HANDOFF_REASONS.clear()
+    caplog.set_level(logging.INFO, logger=ov.logger.name)
 
     patched = F.scaled_dot_product_attention
     stock = patched.__wrapped__
@@ -174,6 +180,8 @@ def test_different_sequence_lengths_go_to_stock_sdpa_on_the_gpu_and_raise_off_it
     finally:
         _native.fwd_strided = real
     assert calls == []
+    said = [r.getMessage() for r in caplog.records if "handed to stock SDPA" in r.getMessage()]
+    assert len(said) == 1 and "L_q != L_kv" in said[0], said          # three calls, one reason, one line
     with pytest.raises(NotImplementedError, match="Grouped- or Multi-query"):
         patched(torch.zeros(2, 4, 1, 64), k.cpu(), v.cpu(), is_causal=True)
 
