@@ -31,7 +31,7 @@ namespace {
 constexpr float LOG2E_F = 1.4426950408889634f;
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bool f32_block_map(int G8, int G, int sched, int nblk, bool heavy_is_last, int& g, int& blk) {
+__device__ __forceinline__ bool f32_block_map(int G8, int G, int sched, int nblk, bool heavy_is_last, int xs, int nblk_real, int& g, int& blk) {
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int ng = G8 >> 3;
@@ -40,10 +40,19 @@ __device__ __forceinline__ bool f32_block_map(int G8, int G, int sched, int nblk
     const int rem = slot - bunch * per_bunch;
     const int g0 = bunch * sched;
     const int bc = (ng - g0) < sched ? (ng - g0) : sched;
-    const int qd = rem / bc;
-    blk = heavy_is_last ? nblk - 1 - qd : qd;
+    int qd = rem / bc;
     g = (g0 + (rem - qd * bc)) * 8 + xcd;
-    return g < G;
+    if (g >= G) return false;
+    if (xs > 1) {   // block subsets (BwdParams::xs_q / xs_kv): g counts (group, subset) pairs; depth d of subset s is the group's depth d xs + s
+        const int s_ = g % xs;
+        g /= xs;
+        qd = qd * xs + s_;
+        if (qd >= nblk_real) return false;
+        blk = heavy_is_last ? nblk_real - 1 - qd : qd;
+        return true;
+    }
+    blk = heavy_is_last ? nblk - 1 - qd : qd;
+    return true;
 }
 
 // two [32][D] fp32 tiles (rows row0 .. row0+31 of a and b, zero past L) global -> registers -> LDS [32][D + 1]
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void fa_bwd_f32_dq_kernel(const Bwd
     __shared__ float vs[2][BK * KP];
 
     int g, qi;
-    if (!f32_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, g, qi)) return;
+    if (!f32_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, p.xs_q, p.nq_real, g, qi)) return;
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void fa_bwd_f32_dkdv_kernel(const B
     int g, kb;
     // (grouped-query attention: one K/V head per workgroup, its kv_div query heads swept one after the other as one stream
     // of (head, query tile) items - see fa_bwd_dkdv_kernel)
-    if (!f32_block_map(p.G8kv, p.Gkv, p.sched_kv, p.nk_tiles, false, g, kb)) return;   // key block 0 is the heaviest
+    if (!f32_block_map(p.G8kv, p.Gkv, p.sched_kv, p.nk_tiles, false, p.xs_kv, p.nk_real, g, kb)) return;   // key block 0 is the heaviest
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;

@@ -59,7 +59,7 @@ struct BwdGeom {
 
 // which (group, block-of-128) does this workgroup own: same XCD-aware bunched order as the forward;
 // `heavy_first_desc` picks whether block index 0 or nblk-1 is the heaviest.
-__device__ __forceinline__ bool bwd_block_map(int G8, int G, int sched, int nblk, bool heavy_is_last, int& g, int& blk) {
+__device__ __forceinline__ bool bwd_block_map(int G8, int G, int sched, int nblk, bool heavy_is_last, int xs, int nblk_real, int& g, int& blk) {
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int ng = G8 >> 3;
@@ -68,10 +68,19 @@ __device__ __forceinline__ bool bwd_block_map(int G8, int G, int sched, int nblk
     const int rem = slot - bunch * per_bunch;
     const int g0 = bunch * sched;
     const int bc = (ng - g0) < sched ? (ng - g0) : sched;
-    const int qd = rem / bc;
-    blk = heavy_is_last ? nblk - 1 - qd : qd;
+    int qd = rem / bc;
     g = (g0 + (rem - qd * bc)) * 8 + xcd;
-    return g < G;
+    if (g >= G) return false;
+    if (xs > 1) {   // block subsets (BwdParams::xs_q / xs_kv): g counts (group, subset) pairs; depth d of subset s is the group's depth d xs + s
+        const int s_ = g % xs;
+        g /= xs;
+        qd = qd * xs + s_;
+        if (qd >= nblk_real) return false;
+        blk = heavy_is_last ? nblk_real - 1 - qd : qd;
+        return true;
+    }
+    blk = heavy_is_last ? nblk - 1 - qd : qd;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -94,7 +103,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     unsigned char* const smem_v = smem + NB * IMG_B;
 
     int g, qi;
-    if (!bwd_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, g, qi)) return;
+    if (!bwd_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, p.xs_q, p.nq_real, g, qi)) return;
 
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -422,7 +431,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     // heads that read it, one head after the other, as one stream of (head, query tile) items: dK and dV of the shared
     // head are summed in registers - no expanded K/V, no atomics, no second pass.
     int g, kb;
-    if (!bwd_block_map(p.G8kv, p.Gkv, p.sched_kv, p.nk_tiles, false, g, kb)) return;   // key block 0 is the heaviest
+    if (!bwd_block_map(p.G8kv, p.Gkv, p.sched_kv, p.nk_tiles, false, p.xs_kv, p.nk_real, g, kb)) return;   // key block 0 is the heaviest
 
     const int L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;

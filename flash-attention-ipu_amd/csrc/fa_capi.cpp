@@ -869,6 +869,32 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
         p.sched = (int32_t)(bunch > ng ? ng : bunch);
         p.sched_kv = (int32_t)(bunch > ngkv ? ngkv : bunch);
     }
+    // block subsets for group counts that leave XCDs idle (as the forward, subsets_for): MFMA kernels only
+    p.xs_q = p.xs_kv = 1;
+    p.nq_real = p.nq_tiles;
+    p.nk_real = p.nk_tiles;
+    if (mfma && options().subsets != 0) {
+        const int64_t kv_bytes = 2 * L * p.D * elt_size(dtype);
+        // (measured, profiles/r05_subsets/bwd_ab.txt: the backward gains where XCDs are IDLE - [2,16384,64] x1.54, [4,8192,128] x1.14 - and loses
+        //  where they are merely uneven - [12,4096,64] x0.89, [25,2048,64] x0.82: its grids are bound by the heaviest block's chain, and a group's
+        //  Q / dO / K / V streamed into more L2s cost more than the evener spread returns - so: below 8 groups only)
+        const int xq = G < 8 ? subsets_for(G, L, kv_bytes) : 1, xk = p.Gkv < 8 ? subsets_for(p.Gkv, L, kv_bytes) : 1;
+        const auto cap_sched = [](int32_t sched, int32_t g8) { return sched > g8 / 8 ? g8 / 8 : sched; };
+        if (xq > 1) {
+            p.xs_q = xq;
+            p.G = (int32_t)(G * xq);
+            p.G8 = (p.G + 7) / 8 * 8;
+            p.nq_tiles = (p.nq_real + xq - 1) / xq;
+            p.sched = cap_sched(p.sched, p.G8);
+        }
+        if (xk > 1) {
+            p.xs_kv = xk;
+            p.Gkv = p.Gkv * xk;
+            p.G8kv = (p.Gkv + 7) / 8 * 8;
+            p.nk_tiles = (p.nk_real + xk - 1) / xk;
+            p.sched_kv = cap_sched(p.sched_kv, p.G8kv);
+        }
+    }
     if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;

@@ -75,6 +75,9 @@ struct BwdParams {
     int32_t nk_tiles;      // 128-key blocks per group
     int32_t sched;         // query groups per XCD bunch (dQ grid)
     int32_t sched_kv;      // K/V groups per XCD bunch (dK/dV grid)
+    // block subsets, as FwdParams::xs: with xs_q > 1 the dQ grid runs over G xs_q (group, q-tile subset) pairs - G, G8 and nq_tiles describe the
+    // pairs, nq_real is the group's tile count; xs_kv / nk_real the same for the dK/dV grid over Gkv, G8kv, nk_tiles
+    int32_t xs_q, nq_real, xs_kv, nk_real;
     float scale, scale_log2;
     ExtraParams ex;
 };

@@ -103,7 +103,7 @@ def test_subsets_other_dtypes(dtype):
 
 def test_subsets_through_the_public_op_with_a_mask_and_the_backward():
     """G = 12 (batch 1 x 12 heads): the override's forward runs on subsets, the mask kernel takes the same map, and the backward (whole
-    groups) consumes the forward's logsumexp - gradients against autograd through the dense fp64 expression."""
+    groups at 8 groups and more: fa_capi.cpp bwd_impl) consumes the forward's logsumexp - gradients against autograd through the dense fp64 expression."""
     native = _mods()
     import flash_attention_amd.auto  # noqa: F401  (patches F.scaled_dot_product_attention)
     import torch.nn.functional as F
@@ -129,3 +129,33 @@ def test_subsets_through_the_public_op_with_a_mask_and_the_backward():
     om = F.scaled_dot_product_attention(q.detach(), k.detach(), v.detach(), attn_mask=keep)
     sm = ((qd.detach() @ kd.detach().transpose(-1, -2)) * D ** -0.5).masked_fill(~keep, float("-inf"))
     assert (om.double() - torch.softmax(sm, -1) @ vd.detach()).abs().max().item() <= 3e-2
+
+
+@pytest.mark.parametrize("B,H,Hkv,L,D", [(1, 2, 2, 2048, 64), (1, 6, 2, 1024, 128), (1, 3, 3, 2048, 64)])
+def test_backward_block_subsets_vs_autograd_fp64_and_whole_group_map(B, H, Hkv, L, D):
+    """The dQ grid (q-tile subsets) and the dK/dV grid (key-block subsets, over the K/V groups: grouped-query heads included) of a group count
+    that leaves XCDs idle: gradients against autograd through the dense fp64 expression, and bit for bit against the whole-group map."""
+    native = _mods()
+    import flash_attention_amd.auto  # noqa: F401
+    import torch.nn.functional as F
+
+    torch.manual_seed(11)
+    q = torch.randn(B, H, L, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    k, v = (torch.randn(B, Hkv, L, D, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(2))
+    g = torch.randn(B, H, L, D, device="cuda", dtype=torch.bfloat16)
+    grads = {}
+    for sub in (-1, 0):
+        with native.debug_options(subsets=sub):
+            out = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=H != Hkv)
+            grads[sub] = (out.detach().clone(),) + torch.autograd.grad(out, (q, k, v), g)
+    for a, b in zip(grads[-1][1:], grads[0][1:]):
+        assert torch.equal(a, b)                   # the same program on every block, in another order
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    ke, ve = (t.repeat_interleave(H // Hkv, dim=1) for t in (kd, vd))
+    s = (qd @ ke.transpose(-1, -2)) * D ** -0.5
+    s = s.masked_fill(torch.triu(torch.ones(L, L, device="cuda", dtype=torch.bool), 1), float("-inf"))
+    ref = torch.softmax(s, -1) @ ve
+    ref.backward(g.double())
+    assert (grads[-1][0].double() - ref).abs().max().item() <= 3e-2
+    for a, b in zip(grads[-1][1:], (qd.grad, kd.grad, vd.grad)):
+        assert (a.double() - b).abs().max().item() <= 6e-2 * max(1.0, b.abs().max().item())
