@@ -197,8 +197,7 @@ def make_op(name, dev, seed=1, backward=False):
                 return F.scaled_dot_product_attention(q, k, v, is_causal=True)
         plan = _native.plan(G, L, D, dtype, nq, nk, softmax_scale=D ** -0.5)
         return fn, 2.0 * G * L * L * D, kernel_name(plan), \
-            f"{name}: F.scaled_dot_product_attention(is_causal=True) through the override on [{B},{H},{L},{D}] {dname}, scale 1/sqrt(D)" \
-            + (" (opt-in scale fold ON: FA_AMD_FOLD=1, DESIGN.md 3.0i)" if _native.get_debug_option("fold") == 1 else ""), plan
+            f"{name}: F.scaled_dot_product_attention(is_causal=True) through the override on [{B},{H},{L},{D}] {dname}, scale 1/sqrt(D)", plan
     if name == "cfg4_attn":
         import torch.nn.functional as F
         import flash_attention_amd.auto  # noqa: F401
@@ -357,7 +356,7 @@ def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
 
 def kernel_name(plan):
     return {0: "fa_fwd_dma_kernel", 1: "fa_fwd_generic_kernel", 2: "fa_fwd_pipe_kernel", 3: "fa_fwd_f32_kernel",
-            4: "fa_fwd_pipe16_kernel", 5: "fa_fwd_pp_kernel", 6: "fa_fwd_kh_kernel"}[plan.kernel]
+            4: "fa_fwd_pipe16_kernel", 6: "fa_fwd_kh_kernel"}[plan.kernel]
 
 
 def profiled_traffic(config, plan, kname=None):

@@ -16,13 +16,6 @@
 #include "fa_params.h"
 #include "fa_tuning_table.h"
 
-// 1 = this build carries the kernels that no rule or table row selects (make EXPERIMENTAL=1): the register-staged baseline 't'
-// (fa_fwd_tile_kernel), the complementary-phase workgroups 'P' (fa_fwd_pp.hip) and the one-wave-per-SIMD AGPR variant
-// of the pipelined kernel at head_dim 128 ('p' with two query blocks per wave) - A/B material, not product code
-#ifndef FA_EXPERIMENTAL
-#define FA_EXPERIMENTAL 0
-#endif
-
 namespace {
 
 thread_local char g_err[512] = "";
@@ -44,7 +37,7 @@ int elt_size(int dtype) { return dtype == FA_DTYPE_F32 ? 4 : 2; }
 // either the old or the new value of one knob and never a torn one; fa_plan() and fa_fwd() go through the same
 // make_plan(), so a reported plan is the launched plan.
 struct Options {
-    std::atomic<int> kernel{0};     // 0 auto, 'd' | 'p' | 'x' | 't' | 'P' | 'h'
+    std::atomic<int> kernel{0};     // 0 auto, 'd' | 'p' | 'x' | 'h'
     std::atomic<int> qb{0};         // 0 auto, 1 | 2 query blocks per wave
     std::atomic<int> waves{0};      // 0 auto, 1 | 2 | 4 | 8
     std::atomic<int> sched{0};      // 0 auto, else groups per L2 bunch
@@ -54,8 +47,6 @@ struct Options {
     std::atomic<int> split{0};      // 0 auto, 1 | 2 | 4 kv split groups per workgroup (fa_fwd_dma.hip)
     std::atomic<int> pair{-1};      // -1 auto, 0 | 1 q-tile pairs per workgroup (fa_fwd_dma.hip, causal)
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
-    std::atomic<int> mirror{-1};    // -1 auto, 0 off, 1 on: mirrored row blocks in the two-block pipelined kernel (causal, head_dim 64, L % 256 == 0)
-    std::atomic<int> fold{-1};      // -1 auto (= off), 0 off, 1 on for scaled bf16 calls: the scale fold of the pipelined kernel (fa_fwd_pipe.hip FOLD)
     std::atomic<int> subsets{-1};   // -1 auto, 0 off: q-tile subsets for group counts that leave XCDs idle (FwdParams::xs)
 };
 Options g_opt;
@@ -64,13 +55,11 @@ std::once_flag g_opt_once;
 std::atomic<void*> g_stamp_buf{nullptr};
 std::atomic<int64_t> g_stamp_bytes{0};
 
-int parse_kernel(const char* v) {   // dma | pipe | pipe16 | pp | tile
+int parse_kernel(const char* v) {   // dma | pipe | pipe16 | kh
     if (!v) return 0;
-    if (!FA_EXPERIMENTAL && (strcmp(v, "pp") == 0 || v[0] == 'P' || v[0] == 't')) return 0;   // (not in this build)
-    if (strcmp(v, "pp") == 0 || v[0] == 'P') return 'P';
     if (strcmp(v, "kh") == 0 || v[0] == 'h') return 'h';
     if (strcmp(v, "pipe16") == 0 || v[0] == 'x') return 'x';
-    return (v[0] == 't' || v[0] == 'd' || v[0] == 'p') ? v[0] : 0;
+    return (v[0] == 'd' || v[0] == 'p') ? v[0] : 0;
 }
 
 const Options& options() {
@@ -85,8 +74,6 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_TABLE")) { if (*e) g_opt.table = atoi(e); }
         if (const char* e = getenv("FA_AMD_PAIR")) { if (*e) g_opt.pair = atoi(e); }
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
-        if (const char* e = getenv("FA_AMD_FOLD")) { if (*e) g_opt.fold = atoi(e); }
-        if (const char* e = getenv("FA_AMD_MIRROR")) { if (*e) g_opt.mirror = atoi(e); }
         if (const char* e = getenv("FA_AMD_SUBSETS")) { if (*e) g_opt.subsets = atoi(e); }
     });
     return g_opt;
@@ -129,11 +116,8 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 //   'p' fa_fwd_pipe_kernel  software-pipelined 32-key steps (fa_fwd_pipe.hip); skip-max arithmetic only
 //   'x' fa_fwd_pipe16_kernel the pipelined kernel on v_mfma_f32_16x16x32 (fa_fwd_pipe16.hip): head_dim 128 with 4 | 8 waves and qb 1,
 //       head_dim 64 with 4 waves and qb 1 | 2
-//   'P' fa_fwd_pp_kernel    the 32-key-step kernel with the two waves of a SIMD in complementary phases (fa_fwd_pp.hip): head_dim 64,
-//       512-thread workgroups = two 256-row halves (the same q tile of two groups), skip-max arithmetic only
 //   'h' fa_fwd_kh_kernel    64-row workgroups, every wave = (row block, key half) of the streamed 64-key tiles (fa_fwd_kh.hip): half the
 //       dependency chain per tile - for causal launches bound by their heaviest workgroup's kv loop (grids of about one round of slots)
-//   't' fa_fwd_tile_kernel  register-staged A/B baseline (debug override only)
 // qb = 32-row query blocks per wave (2 = 64 rows per wave, head_dim 64 only).
 // split = kv split groups of a 'd' workgroup (4 waves x 32 rows each, all on the same 128 query rows; fa_fwd_dma.hip): for
 // grids with fewer workgroups than the chip has slots, where the kv loop of the longest q tile is the launch's critical path.
@@ -141,7 +125,7 @@ bool aligned16(int64_t D, int elt, const void* const ptrs[4], const int64_t* con
 // kernels' own constraints are enforced on whatever was picked.
 struct Selection {
     fa_plan_t plan;
-    char which;      // 'd' | 'p' | 'x' | 'P' | 'h' | 't' | 'g' generic | 'f' fp32 MFMA
+    char which;      // 'd' | 'p' | 'x' | 'h' | 'g' generic | 'f' fp32 MFMA
     int split;       // kv split groups per workgroup ('d' only; plan.waves counts all of the workgroup's waves)
     int pair;        // 'd' only: 1 = a workgroup owns q tiles (nq - 1 - i) and i, one after the other
     int perm_n;      // 'd' | 'h': > 0 = placement-balanced order of the XCD's first perm_n slots
@@ -212,11 +196,10 @@ struct Request {
     float scale;
     int es, skip, wmax;            // element size; 1 = skip-max arithmetic; waves the q chunk allows
     bool pipe_ok, want32;          // the pipelined kernels implement skip-max only; a kv chunk below 64 keys wants 32-key steps
-    bool d_only;                   // the operands' true head dim is below the kernel's (zero-extended call): the kernels that read FwdParams::Dr only
-                                   // (every product forward kernel does; the experimental 'P' / 't' kernels do not)
+    bool d_only;                   // the operands' true head dim is below the kernel's (zero-extended call: FwdParams::Dr)
 };
 struct Choice {
-    char which;                    // 'd' | 'p' | 'x' | 'P' | 'h' | 't'
+    char which;                    // 'd' | 'p' | 'x' | 'h'
     int waves, qb, sched, source, split, table_pair;
 };
 
@@ -265,17 +248,13 @@ void apply_overrides(const Request& r, const Options& opt, Choice* c) {
     if (fk || fw || fq) { split = 1; c->table_pair = 0; } // (a forced tile drops the table's split / pairs unless forced too)
     if ((fw || fq || fs > 1) && !fk && which == 'h') which = 'd';   // (the key-halves kernel has one tile shape: a forced tile leaves it)
     if (fw == 1 || fw == 2 || fw == 4 || fw == 8) { waves = fw; if (!fq) qb = 1; if (!fk && which == 'p' && waves > 4 && D != 128) which = 'd'; }
-    if (fk == 't') { which = 't'; qb = 1; }
-    else if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
-    else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && (D == 128 || FA_EXPERIMENTAL)) ? 8 : 4; if (!fq) qb = 1; }
-    else if (fk == 'P' && pipe_ok && D == 64) { which = 'P'; waves = 4; qb = 2; }
+    if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
+    else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && D == 128) ? 8 : 4; if (!fq) qb = 1; }
     else if (fk == 'h') { which = 'h'; waves = 4; qb = 1; }
-    else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128 || (FA_EXPERIMENTAL && D == 64 && waves == 8 && fq == 2))) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
+    else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
     if (fq == 1) qb = 1;
-    if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256 && which != 't') qb = 2;
+    if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256) qb = 2;
     if (fq == 2 && fk == 'x' && D == 64) qb = 2;
-    if (fq == 2 && fk == 'p' && fw == 8 && D == 64 && pipe_ok && r.causal && L >= 512 && FA_EXPERIMENTAL) qb = 2;   // 512-row workgroups, one shared ring (fa_fwd_pipe_w8_kernel)
-    if (fq == 2 && fk == 'p' && D == 128 && pipe_ok && L >= 256 && FA_EXPERIMENTAL) { qb = 2; waves = 4; }   // the one-wave-per-SIMD AGPR variant (fa_fwd_pipe_ag_kernel)
     if (fs == 1) split = 1;
     if (fs > 1 && (fk == 0 || fk == 'd')) { which = 'd'; waves = 4; qb = 1; split = fs; }
     if (fs > 1 && fk == 'h') split = fs;
@@ -301,19 +280,12 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
         which = pipe256 ? 'p' : 'd'; waves = pipe256 ? 4 : w; qb = 1; split = 1;
         return;
     }
-    if (!FA_EXPERIMENTAL && (which == 't' || which == 'P')) which = 'd';      // (not in this build: make EXPERIMENTAL=1)
-    if (r.d_only && (which == 'P' || which == 't')) { which = 'd'; qb = 1; split = 1; if (waves > 4) waves = 4; }   // (the experimental kernels do not read a narrower head dim)
     if (r.want32 && r.pipe_ok && which == 'd' && fk == 0 && fs <= 1) {   /* (a forced variant ignores the chunk bound) */ which = 'p'; if (waves > 4 && D != 128) waves = 4; }
-    const bool w8_ = FA_EXPERIMENTAL && which == 'p' && D == 64 && waves == 8 && qb == 2 && r.causal && r.pipe_ok;   // (512-row workgroups: forced only)
-    if (which == 'p' && ((waves > 4 && D != 128 && !w8_) || !r.pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
+    if (which == 'p' && ((waves > 4 && D != 128) || !r.pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
     if (which == 'x' && !r.pipe_ok) which = 'd';
-    if (which == 'P' && !(r.pipe_ok && D == 64)) which = 'd';
-    if (which == 'P') { waves = 4; qb = 2; split = 1; }
     if (which == 'h') { waves = 4; qb = 1; if (!(split == 1 || split == 2 || (split == 4 && D == 64))) split = 1; }
-    // (head_dim 64 with 8 waves = the experimental 16-row-wave form: 128-row workgroups, plan.qb 1, block_q set in finish_mfma_plan)
-    if (which == 'x') { waves = (waves == 8 && (D == 128 || (FA_EXPERIMENTAL && opt.kernel == 'x' && opt.waves == 8))) ? 8 : 4; if (D == 128 || waves == 8) qb = 1; }
-    if (qb == 2 && !w8_ && !((D == 64 || (D == 128 && which == 'p' && FA_EXPERIMENTAL)) && waves == 4)) qb = 1;
-    if (which == 't' && waves > 4) waves = 4;
+    if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
+    if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
     if (split > 1 && !((which == 'd' || which == 'h') && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
 }
 
@@ -362,13 +334,13 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
             sel->perm_n = balanced_order((int)(ng * nitem), weight, sel->perm);
         }
     }
-    plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : which == 'P' ? 5 : which == 'h' ? 6 : 0;
+    plan->kernel = which == 'p' ? 2 : which == 'x' ? 4 : which == 'h' ? 6 : 0;
     plan->pair = pair;
     plan->balanced = sel->perm_n > 0;
     plan->waves = waves * split;
     plan->qb = qb;
     plan->block_q = 32 * waves * qb;
-    plan->block_kv = (which == 'p' || which == 'x' || which == 'P') ? 32 : 64;
+    plan->block_kv = (which == 'p' || which == 'x') ? 32 : 64;
     plan->skipmax = r.skip;
     plan->source = c.source;
     // workgroups launched for q tiles of `rows` rows: 8-aligned groups x tiles, or - q-tile subsets - 8-aligned (group, subset) pairs x tiles per pair
@@ -376,20 +348,11 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
     const auto grid_of = [&](int64_t rows) { const int64_t t = (L + rows - 1) / rows; return xs > 1 ? g8v * ((t + xs - 1) / xs) : g8 * t; };
     plan->grid = grid_of(plan->block_q);
     if (pair) plan->grid = g8 * (((L + plan->block_q - 1) / plan->block_q + 1) / 2);
-    if (which == 'x' && D == 64 && waves == 8) {   // 8 waves x 16 rows (experimental)
-        plan->block_q = 128;
-        plan->grid = grid_of(128);
-    }
     if (which == 'h') {   // 4 waves = 2 row blocks x 2 key halves per kv split group: 64-row workgroups
         plan->block_q = 64;
         plan->grid = grid_of(64);
     }
-    if (which == 'P') {   // one workgroup = 8 waves = two 256-row halves: the same q tile of two groups of one XCD class
-        plan->waves = 8;
-        plan->grid = 8 * ((g8 / 8 + 1) / 2) * ((L + 255) / 256);
-    }
-    plan->lds_bytes = which == 'P' ? 2 * (4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64)) + 32
-                      : which == 'x' ? 8 * 32 * D * 2 + 16
+    plan->lds_bytes = which == 'x' ? 8 * 32 * D * 2 + 16
                       : which == 'p' ? 4 * 32 * D * 2 + 4 * (D / 32) * (32 * 64 + 64) + 4 * waves
                                    : which == 'h' ? split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64)) + 16 * split
                                      : split * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64));
@@ -400,7 +363,6 @@ void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection
         int64_t bunch = sched > 0 ? sched : (8ll << 20) / kv_bytes;
         if (opt.sched > 0) bunch = opt.sched;
         int64_t ng = (xs > 1 ? g8v : g8) / 8;
-        if (which == 'P') { bunch = (bunch + 1) / 2; ng = (ng + 1) / 2; }   // (counted in PAIRS of groups)
         if (bunch < 1) bunch = 1;
         if (bunch > ng) bunch = ng;
         plan->sched = (int32_t)bunch;
@@ -431,7 +393,7 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     int64_t g8 = (G + 7) / 8 * 8;
     const int es = elt_size(dtype);
     sel->xs = (mfma16_ok || f32_ok) ? subsets_for(G, L, 2 * L * D * es) : 1;
-    if (options().kernel == 't' || options().kernel == 'P' || options().subsets == 0) sel->xs = 1;      // (the experimental kernels map groups whole)
+    if (options().subsets == 0 || options().pair == 1 || options().balance == 1) sel->xs = 1;   // (a forced pair / balanced order keeps the whole-group map)
     plan->xs = sel->xs;
     if (sel->xs > 1) g8 = ((G * sel->xs + 7) / 8 * 8 + sel->xs - 1) / sel->xs;   // the groups the launch really spreads over the XCDs (~G), for the fill rules
     if (mfma16_ok) {
@@ -486,16 +448,12 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     return FA_OK;
 }
 
-// mirrored row blocks: -1 (auto) = this default
-inline bool kMirrorDefault(int opt) { return opt < 0 ? false : opt != 0; }
-
 struct OptionName { const char* name; std::atomic<int> Options::*field; int lo, hi; };
 const OptionName kOptionNames[] = {
     {"kernel", &Options::kernel, 0, 127}, {"qb", &Options::qb, 0, 2}, {"waves", &Options::waves, 0, 8},
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
-    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"fold", &Options::fold, -1, 1},
-    {"mirror", &Options::mirror, -1, 1}, {"subsets", &Options::subsets, -1, 0},
+    {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"subsets", &Options::subsets, -1, 0},
 };
 
 }  // namespace
@@ -504,7 +462,7 @@ extern "C" {
 
 int fa_abi_version(void) { return FA_ABI_VERSION; }
 
-int fa_experimental_kernels(void) { return FA_EXPERIMENTAL; }
+int fa_experimental_kernels(void) { return 0; }
 
 const char* fa_last_error(void) { return g_err; }
 
@@ -536,10 +494,8 @@ int fa_debug_set_option(const char* name, int32_t value) {
     for (const OptionName& o : kOptionNames) {
         if (strcmp(o.name, name) != 0) continue;
         if (value < o.lo || value > o.hi) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: %s=%d out of range [%d, %d]", name, value, o.lo, o.hi);
-        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 't' || value == 'P' || value == 'h'))
-            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x', 'P', 'h' or 't'");
-        if (o.field == &Options::kernel && !FA_EXPERIMENTAL && (value == 't' || value == 'P'))
-            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel '%c' is not in this build (make EXPERIMENTAL=1)", (char)value);
+        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 'h'))
+            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x' or 'h'");
         if (o.field == &Options::waves && !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: waves must be 0, 1, 2, 4 or 8");
         if (o.field == &Options::split && value == 3) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: split must be 0, 1, 2 or 4");
@@ -715,16 +671,6 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     p.scale = softmax_scale;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.skipmax = plan.skipmax;
-    // the scale fold of the pipelined kernel (fa_fwd_pipe.hip FOLD): scaled calls only - softmax_scale <= 1/4, the SDPA override's 1 / sqrt(D) -
-    // and bf16 only: with the reference max at 0 an f16 P overflows from a scaled logit of 11 on (2^16), which sharp attention heads reach,
-    // and every such workgroup would pay the exact pass; bf16 P has the fp32 exponent range (overflow needs a scaled logit of 88)
-    // ... and ON REQUEST only (fa_debug_set_option("fold", 1) / FA_AMD_FOLD=1): re-rounding Q c costs 2^-9 of the LOGIT's magnitude - invisible at
-    // unit-variance logits (every parity case passes) but 3x the logsumexp error at a logit spread of 2-3 and percents of P on sharp heads with
-    // logits of 20-30 (tests/tools/fuzz_kernels.py with FUZZ_AMP=5, profiles/r03_fold): +5 % is not worth a result that depends on the input's scale
-    p.fold = (sel.which == 'p' && D == 64 && plan.qb == 2 && plan.waves == 4 && dtype == FA_DTYPE_BF16 && softmax_scale <= 0.25f && options().fold == 1) ? 1 : 0;
-    // mirrored row blocks (fa_fwd_pipe.hip MIRROR): the two-block pipelined kernel at head_dim 64, causal, whole 256-row tiles only
-    p.mirror = (FA_EXPERIMENTAL && sel.which == 'p' && D == 64 && plan.qb == 2 && (plan.waves == 4 || plan.waves == 8) && causal == 1 && L % plan.block_q == 0 && !p.fold
-                && kMirrorDefault(options().mirror)) ? 1 : 0;
     p.perm_n = sel.perm_n;
     if (sel.perm_n > 0) memcpy(p.perm, sel.perm, sizeof(p.perm));
     p.stamps = nullptr;
@@ -738,10 +684,6 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
                    : sel.which == 'p' ? fa::launch_fwd_pipe(p, dtype, plan.waves, plan.qb, st)
                    : sel.which == 'x' ? fa::launch_fwd_pipe16(p, dtype, plan.waves, plan.qb, st)
-#if FA_EXPERIMENTAL
-                   : sel.which == 'P' ? fa::launch_fwd_pp(p, dtype, st)
-                   : sel.which == 't' ? fa::launch_fwd_tile(p, dtype, plan.waves, st)
-#endif
                    : sel.which == 'h' ? fa::launch_fwd_kh(p, dtype, sel.split, st)
                                       : fa::launch_fwd_dma(p, dtype, plan.waves / sel.split, plan.qb, sel.split, sel.pair, st);
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));

@@ -43,63 +43,6 @@ template <> struct Elt<_Float16> {
     static constexpr unsigned short one_bits = 0x3C00;   // 1.0
 };
 
-// ---- MFMAs with operands pinned in the accumulator half of the register file ---------------------------------
-// A wave that owns the WHOLE 512-entry file of its SIMD (one wave per SIMD) can keep what only the matrix pipe ever
-// touches - the O^T accumulators and the Q^T fragments - in AGPRs and leave the 256 architectural VGPRs to the softmax.
-// hipcc picks ONE register form for all of a kernel's MFMA builtins (-amdgpu-mfma-vgpr-form here: VGPR C/D, which the
-// softmax needs for the score tiles), so the two mixed forms are written as asm with "a" constraints; the register
-// allocator then places those values in AGPRs by itself.  hipcc pads no hazard for an asm statement (cdna_hip_programming.md
-// 5.6 "What hipcc does not do"), so these are used ONLY where producer and consumer are far apart in the stream:
-//   O^T: written by PV MFMAs only (accumulate chain: 0 states), read by the epilogue after FA_MFMA_SETTLE();
-//   S^T (VGPR result of mfma_bq): read by the vector code a whole step later in the hand-ordered steps; the
-//   compiler-scheduled steps call FA_MFMA_SETTLE() between the product and its first reader;
-//   P / K / V^T operands: LDS waits are the compiler's own (its s_waitcnt bookkeeping tracks registers, asm operands included);
-//   a VALU-written operand (hipcc is free to put a register copy right in front of the statement: it does, in the ragged steps)
-//   needs two wait states before an MFMA reads it, so every statement opens with `s_nop 1` - except (PAD = false) in the four steady
-//   steps of the loop, whose streams carry no copy and no VALU write to an operand of the MFMA behind it (8 issue cycles a gap
-//   matter to a wave that is alone on its SIMD): the audit below is what licenses that.
-// scripts/audit_asm_mfma.py checks the generated ISA for both directions after every build of such a kernel.
-#define FA_MFMA_SETTLE() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")   /* 8-pass XDL result -> any reader: 12+ states */
-template <typename T> struct MfmaAsm;
-template <> struct MfmaAsm<__bf16> {
-    typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
-    // acc (AGPR) += a (VGPR) x b (VGPR)
-    template <bool PAD = true>
-    static __device__ __forceinline__ void acc_a(float __attribute__((ext_vector_type(16)))& acc, vec8 a, vec8 b) {
-        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    }
-    // d (VGPR) = a (VGPR) x b (AGPR) + c (VGPR)
-    template <bool PAD = true>
-    static __device__ __forceinline__ void bq(float __attribute__((ext_vector_type(16)))& d, vec8 a, vec8 b_acc) {
-        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
-    }
-    template <bool PAD = true>
-    static __device__ __forceinline__ void bq0(float __attribute__((ext_vector_type(16)))& d, vec8 a, vec8 b_acc) {
-        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
-    }
-};
-template <> struct MfmaAsm<_Float16> {
-    typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
-    template <bool PAD = true>
-    static __device__ __forceinline__ void acc_a(float __attribute__((ext_vector_type(16)))& acc, vec8 a, vec8 b) {
-        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    }
-    template <bool PAD = true>
-    static __device__ __forceinline__ void bq(float __attribute__((ext_vector_type(16)))& d, vec8 a, vec8 b_acc) {
-        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
-    }
-    template <bool PAD = true>
-    static __device__ __forceinline__ void bq0(float __attribute__((ext_vector_type(16)))& d, vec8 a, vec8 b_acc) {
-        if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
-    }
-};
-
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // The build uses -fno-honor-nans: without it fmaxf() on MFMA results costs a canonicalising
@@ -164,20 +107,6 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned lds_base, unsi
         "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "s"(lds_base), "v"(voffset), "s"(rsrc)
-        : "memory");
-}
-// the same without saving / restoring M0 around the load (two scalar instructions fewer per piece: the software-pipelined kernels
-// are bound by instruction issue).  M0 is a RESERVED register for hipcc on gfx9 ("inline asm clobber list contains
-// reserved registers: m0" if named as a clobber): the register allocator never holds a value in it, and the compiler's own users of
-// M0 (movrel, sendmsg, its LDS-DMA builtin - none of them in these kernels) load it immediately in front of the instruction that
-// reads it, so nothing can depend on M0 surviving this statement; gfx9 LDS instructions do not read M0.
-__device__ __forceinline__ void lds_dma_b128_m0(i32x4 rsrc, unsigned lds_base, unsigned voffset) {
-    asm volatile(
-        "s_mov_b32 m0, %0\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %2, 0 offen lds"
-        :
         : "s"(lds_base), "v"(voffset), "s"(rsrc)
         : "memory");
 }

@@ -34,9 +34,6 @@
 
 #include "fa_device.h"
 
-#ifndef FA_EXPERIMENTAL
-#define FA_EXPERIMENTAL 0
-#endif
 // ring slots per K / V ring (power of two)
 #ifndef FA_PIPE_SLOTS
 #define FA_PIPE_SLOTS(D_, QB_, W_) 4
@@ -45,14 +42,7 @@
 #ifndef FA_PIPE_PF
 #define FA_PIPE_PF 6
 #endif
-// timing-only ablations (wrong results): -DFA_PIPE_ABL=1 no per-step barrier, 2 no per-step DMA
-#ifndef FA_PIPE_ABL
-#define FA_PIPE_ABL 0
-#endif
 // 1: the row sums of P in the hand-scheduled steps run on the matrix pipe (fa_device.h, rowsum_selector)
-#ifndef FA_PIPE_AG_VSUM
-#define FA_PIPE_AG_VSUM 0   /* measured: 1 246 vs 1 286 TFLOP/s at cfg3 - the matrix-pipe sums stay */
-#endif
 #ifndef FA_PIPE_MFMASUM
 #define FA_PIPE_MFMASUM 1
 #endif
@@ -63,56 +53,16 @@
 #ifndef FA_PIPE_PVFIRST
 #define FA_PIPE_PVFIRST 1
 #endif
-// The step barrier.  __syncthreads() is fence + s_barrier + fence: hipcc puts `s_waitcnt lgkmcnt(0)` in front of the s_barrier, which
-// drains the NEXT step's V^T fragment reads that the hand-ordered step requests near its end so that they fly across the barrier.
-// A bare s_barrier would be enough here (the DMA'd slots' visibility rests on the issuing wave's own vmcnt wait; the slots a DMA
-// issued after this barrier overwrites were last read a full step earlier, reads still in flight are of slots overwritten two
-// barriers later) and -DFA_PIPE_BARE_BARRIER=1 builds it; measured in-process (profiles/r03_step_anatomy): +-0.5 % at every
-// shape - with two waves per SIMD the partner issues while this wave drains - so the fenced form stays.
-#ifndef FA_PIPE_BARE_BARRIER
-#define FA_PIPE_BARE_BARRIER 0
-#endif
-#if FA_PIPE_ABL == 1
-#define FA_PIPE_BARRIER() asm volatile("" ::: "memory")
-#elif FA_PIPE_BARE_BARRIER
-#define FA_PIPE_BARRIER() asm volatile("s_barrier" ::: "memory")
-#else
-// (AG - one wave per SIMD - takes the bare barrier: nobody else issues while this wave drains the next step's V^T fragment reads)
-#define FA_PIPE_BARRIER() { if constexpr (AG) asm volatile("s_barrier" ::: "memory"); else __syncthreads(); }
-#endif
+// The step barrier: __syncthreads() (fence + s_barrier + fence; a bare s_barrier measured +-0.5 %, docs/HISTORY.md)
+#define FA_PIPE_BARRIER() __syncthreads()
 
 namespace fa {
 
-// FOLD (scaled calls only: softmax_scale <= 1/4, i.e. the SDPA override's 1 / sqrt(D)): the factor c = scale log2(e) is folded into the Q
-// fragments when they are loaded (re-rounded to 16 bits: an error of 2^-9 of a unit-variance logit, a quarter of P's own bf16 rounding -
-// NOT legal for the packed op's unscaled logits, where it breaks parity) and the optimistic pass runs with the reference
-// max fixed at 0 instead of the first step's row max: P = 2^(s') with no `v_fma` per score at all - 32 of the step's 80 vector
-// instructions go (456 -> 328 issue cycles against 576 matrix cycles: the step turns matrix-bound).  Any reference value cancels in
-// O / l; what 0 must guarantee is that P neither overflows (caught as before: the row sum turns inf / NaN) nor underflows to nothing
-// (caught by a row sum below 2^-80) - either sends the workgroup through the exact pass, which works on the folded scores with c = 1.
-// AG (one wave per SIMD, the whole 512-entry register file: head_dim 128 with two query blocks per wave): the O^T accumulators and
-// the Q^T fragments live in AGPRs (fa_device.h MfmaAsm), the architectural VGPRs hold the two score tiles, P and the operand fragments.
-// MIRROR (causal, two blocks per wave, L a multiple of the workgroup's rows): wave w owns the 32-row blocks w and 2 NWAVES - 1 - w of
-// the tile instead of 2 w and 2 w + 1, so every wave carries the same number of block-steps through the tile's diagonal region: once
-// block 0 has passed its diagonal the wave runs ONE-block steps (its dead block's MFMAs are not issued) instead of idling through the
-// last waves' steps - the "~3 step-times" a workgroup loses to waves that finish early.
-constexpr bool pipe_mfma_live(int n, int qb, int npv, bool pv0, bool qk0) {   // MFMA n of a PV-first step: operand n / qb, block n % qb
-    return (n % qb) != 0 || ((n / qb) < npv ? pv0 : qk0);
-}
-constexpr int pipe_live_before(int n, int qb, int npv, bool pv0, bool qk0) {
-    int c = 0;
-    for (int i = 0; i < n; ++i) c += pipe_mfma_live(i, qb, npv, pv0, qk0) ? 1 : 0;
-    return c;
-}
-
-template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false, bool AG = false, bool MIRROR = false>
+template <typename T, int D, int NWAVES, int QB, bool CAUSAL>
 __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
-    static_assert(!MIRROR || (QB == 2 && CAUSAL && FA_PIPE_PVFIRST), "mirrored row blocks: causal, two blocks per wave, PV-first steps");
     using E = Elt<T>;
-    using MA = MfmaAsm<T>;
-    // row sums of the hand-ordered steps on the matrix pipe (fa_device.h rowsum_selector) - except AG (FA_PIPE_AG_VSUM): a lone wave's stream is
-    // bound by the matrix pipe, its vector issue has slack, so there the 32 v_add per step are cheaper than 4 row-sum MFMAs (64 matrix cycles)
-    constexpr bool MSUM = FA_PIPE_MFMASUM && !(AG && FA_PIPE_AG_VSUM);
+    // row sums of the hand-ordered steps on the matrix pipe (fa_device.h rowsum_selector)
+    constexpr bool MSUM = FA_PIPE_MFMASUM;
     using vec8 = typename E::vec8;
     typedef T vec4 __attribute__((ext_vector_type(4)));
     constexpr int WQ = 32 * QB;                 // query rows per wave
@@ -123,14 +73,11 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     constexpr int VBLK_B = HK * 64 + 64;        // one 32-column d-block of a V slot (+64 B stagger)
     constexpr int VH_B = (D / 32) * VBLK_B;     // V slot
     constexpr int PIECES = KH_B / 1024;         // 1 KiB DMA pieces per K (or V) slot
-    // HALF (8 waves at head_dim 64: 4 K pieces + 4 V pieces per step): every wave issues ONE piece per step, waves 0 .. PIECES - 1 a
-    // K piece, the others a V piece - a 512-row workgroup streams K/V through ONE ring
-    constexpr bool HALF = PIECES * 2 == NWAVES;
-    constexpr int PPW = HALF ? 1 : PIECES / NWAVES;
-    constexpr int DPS = HALF ? 1 : 2 * PPW;     // LDS-DMA instructions a wave issues per step
+    constexpr int PPW = PIECES / NWAVES;
+    constexpr int DPS = 2 * PPW;                // LDS-DMA instructions a wave issues per step
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
-    static_assert(HALF || (PIECES % NWAVES == 0 && PPW >= 1), "pieces must split evenly over the waves");
+    static_assert(PIECES % NWAVES == 0 && PPW >= 1, "pieces must split evenly over the waves");
 
     // ring depth: 4 slots = the DMA of a step has two steps to land (8 slots = six steps were measured 1-2 %
     // slower: the groups of NS steps leave more ragged steps over)
@@ -191,10 +138,10 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     const T* __restrict__ vg = (const T*)p.v + (int64_t)bb * p.v_sb + (int64_t)(hh / p.kv_div) * p.v_sh;
 
     const int q_row0 = qi * BQ + wave * WQ;
-    int rowb[QB];                                // first row of block b (MIRROR: blocks wave and 2 NWAVES - 1 - wave of the tile)
+    int rowb[QB];                                // first row of block b
 #pragma unroll
-    for (int b = 0; b < QB; ++b) rowb[b] = MIRROR ? qi * BQ + 32 * (b == 0 ? wave : 2 * NWAVES - 1 - wave) : q_row0 + 32 * b;
-    const bool wave_active = MIRROR ? true : q_row0 < L;
+    for (int b = 0; b < QB; ++b) rowb[b] = q_row0 + 32 * b;
+    const bool wave_active = q_row0 < L;
 
     const int dchunks = p.Dr >> 3;               // the operands' true head dim in 16-byte chunks (= D / 8 unless the call runs zero-extended)
     vec8 qf[QB][KS];
@@ -212,14 +159,6 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             qf[b][ks] = ch_ < dchunks ? ld_ : z_;
         }
     }
-    if constexpr (FOLD) {
-#pragma unroll
-        for (int b = 0; b < QB; ++b)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) qf[b][ks][j] = (T)((float)qf[b][ks][j] * p.scale_log2);
-    }
 
     // ---- LDS-DMA geometry (as fa_fwd_dma_kernel, for 32-key slots)
     const unsigned k_slb = (unsigned)p.k_sl * 2, v_slb = (unsigned)p.v_sl * 2;
@@ -227,7 +166,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     int k_dst[PPW], v_dst[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int pc = HALF ? wave % PIECES : wave + j * NWAVES;
+        const int pc = wave + j * NWAVES;
         const int row = pc * (1024 / ROWB) + lane / (ROWB / 16);
         const int cp = lane % (ROWB / 16);
         const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
@@ -242,52 +181,21 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     const unsigned k_bytes = ((unsigned)(L - 1) * (unsigned)p.k_sl + (unsigned)p.Dr) * 2;
     const unsigned v_bytes = ((unsigned)(L - 1) * (unsigned)p.v_sl + (unsigned)p.Dr) * 2;
     const unsigned smem_lds = lds_offset(smem);
-    // one descriptor per operand for the whole workgroup (AG: the steady steps issue their LDS-DMA pieces inside MFMA gaps, a step's
-    // rows reached through the lane offset - no per-step descriptor arithmetic in a stream that has its SIMD to itself)
-    const i32x4 krw_ = make_raw_rsrc((const char*)kg, k_bytes);
-    const i32x4 vrw_ = make_raw_rsrc((const char*)vg, v_bytes);
-    (void)krw_; (void)vrw_;
 
-#ifndef FA_PIPE_LEAN
-#define FA_PIPE_LEAN 0   /* 1: ~35 fewer scalar instructions per step - one buffer descriptor per operand for the whole workgroup (a step's
-                            rows are reached through the lane offset; reads past the operand's extent still return zeros), M0 not saved /
-                            restored, and the hand-ordered steps issue their two DMAs and their counted vmcnt wait unconditionally (a ring
-                            slot beyond the workgroup's last step receives rows nobody reads).  Measured in-process against 0
-                            (profiles/r03_step_anatomy/lean_ab.txt): L = 4096 .. 32768 at head_dim 64 -0.5 .. -0.9 %, L = 1024 / 2048 +3.4 /
-                            +0.9 %, head_dim 128 +0.5 .. +0.9 %: scalar instructions issue beside the partner wave's vector
-                            instructions, they were never what bounds the step - off */
-#endif
-#if FA_PIPE_LEAN
-    const i32x4 kr0_ = make_raw_rsrc((const char*)kg, k_bytes);
-    const i32x4 vr0_ = make_raw_rsrc((const char*)vg, v_bytes);
 #define FA_DMA_K(J_, SLOT_)                                                                        \
     {                                                                                              \
-        const unsigned ko_ = (unsigned)(J_) * HK * k_slb;                                          \
-        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
-            lds_dma_b128_m0(kr0_, smem_lds + (SLOT_) * KH_B + k_dst[j], k_vo[j] + ko_);            \
-    }
-#define FA_DMA_V(J_, SLOT_)                                                                        \
-    {                                                                                              \
-        const unsigned vo_ = (unsigned)(J_) * HK * v_slb;                                          \
-        _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
-            lds_dma_b128_m0(vr0_, smem_lds + NS * KH_B + (SLOT_) * VH_B + v_dst[j], v_vo[j] + vo_); \
-    }
-#else
-#define FA_DMA_K(J_, SLOT_)                                                                        \
-    if (!HALF || wave < PIECES) {                                                                  \
         const unsigned ko_ = (unsigned)(J_) * HK * k_slb;                                          \
         const i32x4 kr_ = make_raw_rsrc((const char*)kg + ko_, k_bytes - ko_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
             lds_dma_b128(kr_, smem_lds + (SLOT_) * KH_B + k_dst[j], k_vo[j]);                      \
     }
 #define FA_DMA_V(J_, SLOT_)                                                                        \
-    if (!HALF || wave >= PIECES) {                                                                 \
+    {                                                                                              \
         const unsigned vo_ = (unsigned)(J_) * HK * v_slb;                                          \
         const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
             lds_dma_b128(vr_, smem_lds + NS * KH_B + (SLOT_) * VH_B + v_dst[j], v_vo[j]);          \
     }
-#endif
 
     int k_rd[KS];
     {
@@ -307,9 +215,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     const int nh_wg = (kv_end + HK - 1) / HK;                 // steps the workgroup streams
     // steps this wave computes: block b's diagonal step is q_row0/32 + b, so the last QB steps carry a mask
     // (a block whose rows all lie before a step's keys gets P = 0 there)
-    const int nh_w = wave_active ? (causal ? (MIRROR ? rowb[QB - 1] / HK + 1 : q_row0 / HK + QB) : nh_wg) : 0;
-    // the step of block 0's diagonal + QB: what bounds the unmasked hand-ordered steps (= nh_w unless MIRROR)
-    const int nh_a = MIRROR ? rowb[0] / HK + QB : nh_w;
+    const int nh_w = wave_active ? (causal ? q_row0 / HK + QB : nh_wg) : 0;
+    const int nh_a = nh_w;                       // the step of block 0's diagonal + QB: what bounds the unmasked hand-ordered steps
 
     f32x16 o[QB][DT];
     float m[QB], l[QB];
@@ -320,7 +227,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     (void)asel;
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        m[b] = FOLD ? 0.f : -INFINITY;     // (FOLD: the optimistic pass keeps the reference max at 0)
+        m[b] = -INFINITY;
         l[b] = 0.f;
         lsum[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -328,7 +235,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[b][dt][e] = 0.f;
     }
-    const float c = FOLD ? 1.0f : p.scale_log2;   // (FOLD: the scores arrive in log2 units)
+    const float c = p.scale_log2;
     constexpr float P_LIMIT = E::is_f16 ? 32768.0f : 1152921504606846976.0f;   // 2^15 | 2^60
 
     // S[b] = K(slot) Q_b^T for one 32-key step (every K row read feeds all blocks)
@@ -340,11 +247,9 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                        \
             const vec8 kf_ = *(const vec8*)(kb_ + k_rd[ks]);                                       \
             _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                       \
-                if constexpr (AG) { if (ks == 0) MA::bq0(S_[b], kf_, qf[b][ks]); else MA::bq(S_[b], kf_, qf[b][ks]); } \
-                else S_[b] = E::mfma(kf_, qf[b][ks], S_[b]);                                       \
+                S_[b] = E::mfma(kf_, qf[b][ks], S_[b]);                                            \
             }                                                                                      \
         }                                                                                          \
-        if constexpr (AG) FA_MFMA_SETTLE();                                                        \
     }
     // O_b^T += V(slot)^T P_b^T
 #define FA_PV_H(P_, SLOT_)                                                                         \
@@ -358,13 +263,10 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
                     (i16x4 __attribute__((address_space(3)))*)(vp + 512));                         \
                 const i16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);          \
-                _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                   \
-                    if constexpr (AG) MA::acc_a(o[b][dt], __builtin_bit_cast(vec8, v8), P_[b][kk]); \
-                    else o[b][dt] = E::mfma(__builtin_bit_cast(vec8, v8), P_[b][kk], o[b][dt]);    \
-                }                                                                                  \
+                _Pragma("unroll") for (int b = 0; b < QB; ++b)                                     \
+                    o[b][dt] = E::mfma(__builtin_bit_cast(vec8, v8), P_[b][kk], o[b][dt]);         \
             }                                                                                      \
         }                                                                                          \
-        if constexpr (AG) FA_MFMA_SETTLE();                                                        \
     }
 #define FA_MASK_H(S_, J_)                                                                          \
     _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
@@ -409,8 +311,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // landed - this step's own DMA may fly on across the barrier)
 #define FA_ISSUE(I_, KSLOT_, VSLOT_)                                                               \
         const bool dk_ = (I_) + NS - 1 < nh_wg, dv_ = (I_) + NS - 2 < nh_wg;                       \
-        if (dk_ && FA_PIPE_ABL != 2) FA_DMA_K((I_) + NS - 1, KSLOT_)                               \
-        if (dv_ && FA_PIPE_ABL != 2) FA_DMA_V((I_) + NS - 2, VSLOT_)
+        if (dk_) FA_DMA_K((I_) + NS - 1, KSLOT_)                                                   \
+        if (dv_) FA_DMA_V((I_) + NS - 2, VSLOT_)
 #define FA_PUBLISH()                                                                               \
         if (dk_ && dv_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (NS - 3)) : "memory");      \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
@@ -453,9 +355,8 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // MASK_ modes: 0 no mask; 1 causal mask on every block; 2 mask on block 0 only (two blocks: the step of block
     // 0's diagonal); 3 block 0 is dead - all its keys lie after its rows: no softmax, P = 0 - and block 1 is masked
     // (two blocks: the wave's last step)
-// 4 (MIRROR): block 0 is dead, block 1 carries no mask (the one-block steps between the two diagonals of a wave)
 #define FA_ITEM_MASKED(MASK_, B_) ((MASK_) == 1 || ((MASK_) == 2 && (B_) == 0) || ((MASK_) == 3 && (B_) == 1))
-#define FA_ITEM_DEAD(MASK_, B_) (((MASK_) == 3 || (MASK_) == 4) && (B_) == 0)
+#define FA_ITEM_DEAD(MASK_, B_) ((MASK_) == 3 && (B_) == 0)
 #define FA_ITEM_FMA(SC_, V_, MASK_)                                                                \
         {                                                                                          \
             constexpr int b_ = (V_) / 8, e_ = 2 * ((V_) % 8);                                      \
@@ -464,7 +365,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 if (key_ > FA_KLIM(b_)) SC_[b_][e_] = -INFINITY;                                   \
                 if (key_ + 1 > FA_KLIM(b_)) SC_[b_][e_ + 1] = -INFINITY;                           \
             }                                                                                      \
-            if constexpr (!FA_ITEM_DEAD(MASK_, b_) && !FOLD) {   /* (FOLD: the score IS the exponent - c folded into Q, reference max 0) */ \
+            if constexpr (!FA_ITEM_DEAD(MASK_, b_)) {                                              \
                 SC_[b_][e_] = __builtin_fmaf(SC_[b_][e_], c, -mc[b_]);                             \
                 SC_[b_][e_ + 1] = __builtin_fmaf(SC_[b_][e_ + 1], c, -mc[b_]);                     \
             }                                                                                      \
@@ -476,11 +377,6 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 SC_[b_][e_] = fast_exp2(SC_[b_][e_]);                                              \
                 SC_[b_][e_ + 1] = fast_exp2(SC_[b_][e_ + 1]);                                      \
             }                                                                                      \
-        }
-#define FA_ITEM_EXP1(SC_, V_, EL_, MASK_)                                                          \
-        {                                                                                          \
-            constexpr int b_ = (V_) / 8, e_ = 2 * ((V_) % 8) + (EL_);                              \
-            if constexpr (!FA_ITEM_DEAD(MASK_, b_)) SC_[b_][e_] = fast_exp2(SC_[b_][e_]);          \
         }
 #define FA_ITEM_SUM(SC_, PC_, V_, MASK_)                                                           \
         {                                                                                          \
@@ -502,45 +398,13 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // KN_ / VP_ / KI_ / VI_: ring slots of K(I_+1), V(I_-1) and of the DMA targets K(I_+3), V(I_+2) - compile-time
     // constants in the 4-step groups, i-dependent values in the ragged steps; MASK_: mask mode (above);
     // QK_: a next step exists
-#if FA_PIPE_LEAN
-#define FA_ISSUE_FAST(I_, KSLOT_, VSLOT_)                                                          \
-        if (FA_PIPE_ABL != 2) { FA_DMA_K((I_) + NS - 1, KSLOT_) FA_DMA_V((I_) + NS - 2, VSLOT_) }
-#define FA_PUBLISH_FAST()                                                                          \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (NS - 3)) : "memory");                      \
-        FA_PIPE_BARRIER();
-#else
 #define FA_ISSUE_FAST(I_, KSLOT_, VSLOT_) FA_ISSUE(I_, KSLOT_, VSLOT_)
 #define FA_PUBLISH_FAST() FA_PUBLISH()
-#endif
-#define FA_ISSUE_FASTX(I_, KSLOT_, VSLOT_, DMAG_)                                                  \
-        bool dk_ = true, dv_ = true;                                                               \
-        if constexpr (!(DMAG_)) {                                                                  \
-            dk_ = (I_) + NS - 1 < nh_wg; dv_ = (I_) + NS - 2 < nh_wg;                              \
-            if (dk_ && FA_PIPE_ABL != 2) FA_DMA_K((I_) + NS - 1, KSLOT_)                           \
-            if (dv_ && FA_PIPE_ABL != 2) FA_DMA_V((I_) + NS - 2, VSLOT_)                           \
-        }
-// piece PI_ (0 .. 2 PPW - 1: K pieces first) of the step's DMA, issued from inside an MFMA gap
-#define FA_DMA_PIECE(I_, KSLOT_, VSLOT_, PI_)                                                      \
-        if constexpr ((PI_) < PPW) {                                                               \
-            lds_dma_b128_m0(krw_, smem_lds + (KSLOT_) * KH_B + k_dst[(PI_)], k_vo[(PI_)] + (unsigned)((I_) + NS - 1) * HK * k_slb); \
-        } else {                                                                                   \
-            lds_dma_b128_m0(vrw_, smem_lds + NS * KH_B + (VSLOT_) * VH_B + v_dst[(PI_) - PPW], v_vo[(PI_) - PPW] + (unsigned)((I_) + NS - 2) * HK * v_slb); \
-        }
-// PV0_ / QK0_ (MIRROR's one-block steps): whether block 0's PV / QK^T MFMAs are issued at all - a dead block needs neither, except
-// the PV of its diagonal step's P in the step right after that diagonal.  The vector items of the live block(s) are spread
-// over the MFMAs that ARE issued.
-// STEADY_ (the four steps of the loop): AG only - the asm MFMAs drop their leading `s_nop 1` (fa_device.h) and the step's LDS-DMA pieces
-// are issued inside MFMA gaps instead of in front of the first MFMA (unconditionally: a steady step is at least NS steps from the
-// workgroup's last, so K(i + NS - 1) and V(i + NS - 2) always exist).
-#define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_) FA_FASTX(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_, true, true, false)
-#define FA_FASTX(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_, PV0_, QK0_, STEADY_)       \
+#define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_)                             \
     {                                                                                              \
-        constexpr bool DMAG_ = AG && (STEADY_) && FA_PIPE_ABL != 2;                                \
-        constexpr bool PAD_ = !(AG && (STEADY_));                                                  \
-        FA_ISSUE_FASTX(I_, KI_, VI_, DMAG_)                                                        \
+        FA_ISSUE_FAST(I_, KI_, VI_)                                                                \
         constexpr int NK = (QK_) ? KS : 0, NM = NK + 2 * DT, NMF = NM * QB, NV = 8 * QB;           \
         constexpr int VB = (QB == 2 && FA_ITEM_DEAD(MASK_, 0)) ? 8 : 0, NVL = NV - VB;             /* live vector items: VB .. NV - 1 */ \
-        constexpr int NMFL = pipe_live_before(NMF, QB, 2 * DT, PV0_, QK0_);                        /* MFMAs issued */ \
         constexpr int PF_ = FA_PIPE_PF < NM ? FA_PIPE_PF : NM;                                     \
         const unsigned char* kb_ = smem + (KN_) * KH_B;                                            \
         const unsigned char* vb_ = smem_v + (VP_) * VH_B;                                          \
@@ -562,16 +426,9 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         __builtin_amdgcn_sched_barrier(0);                                                         \
         fa_static_for<0, NMF>([&](auto gi_) {                                                      \
             constexpr int n_ = decltype(gi_)::value, g_ = n_ / QB, b_ = n_ % QB;                   \
-            constexpr bool live_ = pipe_mfma_live(n_, QB, 2 * DT, PV0_, QK0_);                     \
-            constexpr int l_ = pipe_live_before(n_, QB, 2 * DT, PV0_, QK0_);                       \
-            if constexpr (!live_) {                                                                \
-                /* (a dead block's MFMA: not issued) */                                            \
-            } else if constexpr (FA_OPND_IS_K(g_, NK)) {                                           \
+            if constexpr (FA_OPND_IS_K(g_, NK)) {                                                  \
                 constexpr int kx_ = FA_OPND_KIDX(g_, NK);                                          \
-                if constexpr (AG) {                                                                \
-                    if constexpr (kx_ == 0) MA::template bq0<PAD_>(SN_[b_], opnd[g_], qf[b_][kx_ < KS ? kx_ : 0]); \
-                    else MA::template bq<PAD_>(SN_[b_], opnd[g_], qf[b_][kx_ < KS ? kx_ : 0]);     \
-                } else if constexpr (kx_ == 0) {                                                   \
+                if constexpr (kx_ == 0) {                                                          \
                     f32x16 z_;                                                                     \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) z_[e] = 0.f;                    \
                     SN_[b_] = E::mfma(opnd[g_], qf[b_][kx_ < KS ? kx_ : 0], z_);                   \
@@ -580,40 +437,25 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 }                                                                                  \
             } else {                                                                               \
                 constexpr int t_ = FA_OPND_VIDX(g_, NK);                                           \
-                if constexpr (AG) MA::template acc_a<PAD_>(o[b_][t_ % DT], opnd[g_], PP_[b_][t_ / DT]); \
-                else o[b_][t_ % DT] = E::mfma(opnd[g_], PP_[b_][t_ / DT], o[b_][t_ % DT]);         \
+                o[b_][t_ % DT] = E::mfma(opnd[g_], PP_[b_][t_ / DT], o[b_][t_ % DT]);              \
             }                                                                                      \
-            /* (AG steady steps) the step's LDS-DMA pieces, one per gap behind the MFMAs 0, 2, 4, ... (the gaps that carry exp + cvt only) */ \
-            if constexpr (DMAG_ && (n_ % 2) == 0 && (n_ / 2) < 2 * PPW) { FA_DMA_PIECE(I_, KI_, VI_, n_ / 2) } \
             if constexpr (b_ == QB - 1 && g_ + PF_ < NM && g_ + PF_ >= NPRE) { FA_OPND_LOAD(g_ + PF_, NK) } \
             /* the NEXT step's V^T fragments, requested once this step's have been consumed */     \
             if constexpr (FA_PIPE_PVFIRST && (QK_) && b_ == QB - 1 && g_ >= NPRE && g_ < 2 * NPRE) { \
                 FA_PRE_LOAD(g_ - NPRE, vnext_)                                                     \
             }                                                                                      \
             /* this MFMA's share of the vector work items */                                      \
-            if constexpr (!live_) {                                                                \
-            } else if constexpr (AG && NMF == 2 * NV) {   /* one wave per SIMD: at most one transcendental and <= 24 issue cycles per MFMA gap */ \
-                constexpr int v_ = n_ / 2;                                                         \
-                if constexpr (n_ % 2 == 0) {                                                       \
-                    if constexpr (v_ + 1 < NV) { FA_ITEM_EXP1(SC_, v_ + 1, 0, MASK_) }             \
-                    FA_ITEM_SUM(SC_, PC_, v_, MASK_)                                               \
-                } else {                                                                           \
-                    if constexpr (v_ + 1 < NV) { FA_ITEM_EXP1(SC_, v_ + 1, 1, MASK_) }             \
-                    if constexpr (v_ + 2 < NV) { FA_ITEM_FMA(SC_, v_ + 2, MASK_) }                 \
-                }                                                                                  \
-            } else {                                                                               \
-            fa_static_for<VB + (l_ * NVL) / NMFL, VB + ((l_ + 1) * NVL) / NMFL>([&](auto vi_) {    \
+            fa_static_for<VB + (n_ * NVL) / NMF, VB + ((n_ + 1) * NVL) / NMF>([&](auto vi_) {      \
                 constexpr int v_ = decltype(vi_)::value;                                           \
                 if constexpr (v_ + 1 < NV) { FA_ITEM_EXP(SC_, v_ + 1, MASK_) }                     \
                 FA_ITEM_SUM(SC_, PC_, v_, MASK_)                                                   \
                 if constexpr (v_ + 2 < NV) { FA_ITEM_FMA(SC_, v_ + 2, MASK_) }                     \
             });                                                                                    \
-            }                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         });                                                                                        \
         _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                           \
             if constexpr (!MSUM) {                                                                 \
-                if constexpr (!AG) bad |= !(ls[b] <= P_LIMIT);   /* (AG: one check per pass on l, as for the matrix-pipe sums) */ \
+                bad |= !(ls[b] <= P_LIMIT);                                                        \
                 l[b] += ls[b];                                                                     \
             }                                                                                      \
             /* pin this step's vector work to this step (hipcc otherwise sinks it below the       \
@@ -625,12 +467,11 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         FA_STEP_STAMP_B()                                                                          \
     }
 #define FA_STEADY(I_, R_, SC_, SN_, PP_, PC_)                                                      \
-    FA_FASTX(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, 0, true, true, true, true)
+    FA_FAST(I_, ((R_) + 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 1) & NSM, ((R_) + NS - 2) & NSM, SC_, SN_, PP_, PC_, 0, true)
     // The ragged steps and the generic steps after the groups of four use FIXED register roles (S(i) in sa,
     // S(i+1) -> sb, P(i-1) in pb, P(i) -> pa) and rotate by copying afterwards: one instantiation each instead of
     // one per parity (parity branches make hipcc shuffle the whole accumulator state through phi copies)
 #define FA_ROTATE()                                                                                \
-    if constexpr (AG) FA_MFMA_SETTLE();   /* (the copies below read what the step's last asm MFMAs wrote) */ \
     _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                               \
         sa[b] = sb[b];                                                                             \
         pb[b][0] = pa[b][0];                                                                       \
@@ -638,8 +479,6 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     }
 #define FA_RAGGED(I_, MASK_, QK_)                                                                  \
     FA_FAST(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, MASK_, QK_)
-#define FA_RAGGEDX(I_, MASK_, QK_, PV0_, QK0_)                                                     \
-    FA_FASTX(I_, ((I_) + 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 1) & NSM, ((I_) + NS - 2) & NSM, sa, sb, pb, pa, MASK_, QK_, PV0_, QK0_, false)
     // generic step (runtime ring slots, compiler's own schedule): the first step, the up to three steps left
     // over by the groups of four, the diagonal step, the drain step and the idle steps of a finished wave.
     // SAFE_ = the fallback pass: a step whose P outgrew the safe range is redone with an exact max.
@@ -653,7 +492,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             float ls[QB];                                                                          \
             const bool diag_ = i_ >= nh_a - QB;                                                    \
             if (diag_) FA_MASK_H(SC_, i_)                                                          \
-            if (i_ == 0 && !(FOLD && !(SAFE_))) FA_MAXR_H(SC_)                                     \
+            if (i_ == 0) FA_MAXR_H(SC_)                                                            \
             FA_SM_H(SC_)                                                                           \
             bool over_ = false;                                                                    \
             _Pragma("unroll") for (int b = 0; b < QB; ++b) over_ |= !(ls[b] <= P_LIMIT);           \
@@ -713,24 +552,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
                 FA_ROTATE()                                                                        \
                 ++i;                                                                               \
             }                                                                                      \
-            if constexpr (MIRROR) {                            /* i = block 0's diagonal step + 1: one-block steps up to block 1's diagonal */ \
-                const bool first_is_last_ = i + 1 == nh_w;     /* (waves NWAVES - 1: the two blocks are neighbours) */ \
-                if (i + 1 < nh_w) {                            /* the step right after block 0's diagonal still owes the PV of that diagonal's P */ \
-                    FA_RAGGEDX(i, 4, true, true, false)                                            \
-                    FA_ROTATE()                                                                    \
-                    ++i;                                                                           \
-                }                                                                                  \
-                for (; i + 1 < nh_w; ++i) {                                                        \
-                    FA_RAGGEDX(i, 4, true, false, false)                                           \
-                    FA_ROTATE()                                                                    \
-                }                                                                                  \
-                if (i < nh_w) {                                /* block 1's diagonal = the wave's last step */ \
-                    if (first_is_last_) { FA_RAGGEDX(i, 3, false, true, true) }                    \
-                    else { FA_RAGGEDX(i, 3, false, false, true) }                                  \
-                    FA_ROTATE()                                                                    \
-                    ++i;                                                                           \
-                }                                                                                  \
-            } else if (i < nh_w) {                             /* the wave's last step */          \
+            if (i < nh_w) {                                    /* the wave's last step */          \
                 if constexpr (CAUSAL) { FA_RAGGED(i, (QB == 2 ? 3 : 1), false) }   /* (block 0 lies wholly before this step's keys) */ \
                 else { FA_RAGGED(i, 1, false) }                                    /* unmasked attention: only keys past L are masked */ \
                 FA_ROTATE()                                                                        \
@@ -767,9 +589,6 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         bad |= sum_left_safe_range(lsum[b][0]);
-        if constexpr (AG && !MSUM) bad |= sum_left_safe_range(l[b]);   // (vector-pipe sums of non-negative P: an overflowed P left them inf for good)
-        // (FOLD: with the reference max at 0 a row whose logits are all far below 0 would underflow; a row owns its diagonal key at least)
-        if constexpr (FOLD) bad |= wave_active && (half_swap_sum(l[b]) + lsum[b][0]) < 8.2718061e-25f;   /* 2^-80 */
     }
     // Did any row of the workgroup leave the safe range?  (All waves must agree: the fallback pass re-streams
     // K/V through the same barriers.)  Practically never taken: logits must outgrow the first step's row max
@@ -783,7 +602,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         __syncthreads();   // (flags are rewritten only by a later launch; this orders the LDS ring reuse)
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
-            m[b] = -INFINITY;                  // (the exact pass finds its own reference max, FOLD or not)
+            m[b] = -INFINITY;
             l[b] = 0.f;
             lsum[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -797,13 +616,9 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #undef FA_ISSUE
 #undef FA_PUBLISH
 #undef FA_ISSUE_FAST
-#undef FA_ISSUE_FASTX
-#undef FA_DMA_PIECE
 #undef FA_PUBLISH_FAST
 #undef FA_STEADY
 #undef FA_FAST
-#undef FA_FASTX
-#undef FA_RAGGEDX
 #undef FA_RAGGED
 #undef FA_ROTATE
 #undef FA_OPND_LOAD
@@ -815,7 +630,6 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 #undef FA_ITEM_MASKED
 #undef FA_ITEM_DEAD
 #undef FA_ITEM_EXP
-#undef FA_ITEM_EXP1
 #undef FA_ITEM_SUM
 #undef FA_GENERIC
 #undef FA_RUN
@@ -831,7 +645,6 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     FA_STAMP(st2_)
     // ---- epilogue: O /= l through LDS, whole-row stores (as fa_fwd_dma_kernel; the K ring is free now)
     if (!wave_active) return;
-    if constexpr (AG) FA_MFMA_SETTLE();
     unsigned char* slab = smem + wave * (32 * ROWB);
     constexpr int CPR = D / 8;
     constexpr int RPI = 64 / CPR;
@@ -852,7 +665,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
             }
         }
         const int row_b = rowb[b] + r;
-        if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * (FOLD ? 0.69314718f : p.scale) + __logf(lt);   /* (FOLD: m is in log2 units) */
+        if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * p.scale + __logf(lt);
 #pragma unroll
         for (int i = 0; i < 32 / RPI; ++i) {
             const int rr = i * RPI + lane / CPR, ch = lane % CPR;
@@ -885,27 +698,9 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
 }
 
 // (two query blocks per wave: hold the register allocator to 2 waves per SIMD = 256 registers)
-template <typename T, int D, int NWAVES, int QB, bool CAUSAL, bool FOLD = false>
+template <typename T, int D, int NWAVES, int QB, bool CAUSAL>
 __global__ __launch_bounds__(NWAVES * 64, QB == 2 ? 2 : 1) void fa_fwd_pipe_kernel(const FwdParams p) {
-    fa_fwd_pipe_body<T, D, NWAVES, QB, CAUSAL, FOLD>(p);
-}
-// the headline shape's kernel with mirrored row blocks (MIRROR above): causal, head_dim 64, 4 waves x 2 blocks, L a multiple of 256
-template <typename T>
-__global__ __launch_bounds__(256, 2) void fa_fwd_pipe_mirror_kernel(const FwdParams p) {
-    fa_fwd_pipe_body<T, 64, 4, 2, true, false, false, true>(p);
-}
-// 8 waves x 2 blocks = 512-row workgroups at head_dim 64 with ONE shared K/V ring (one LDS-DMA piece per wave and step, half the
-// L2 -> LDS traffic per FLOP of the 256-row workgroups), one workgroup per CU, its waves two per SIMD; with or without mirrored blocks
-template <typename T, bool MIRROR>
-__global__ __launch_bounds__(512, 2) void fa_fwd_pipe_w8_kernel(const FwdParams p) {
-    fa_fwd_pipe_body<T, 64, 8, 2, true, false, false, MIRROR>(p);
-}
-// head_dim 128, two query blocks per wave: 64 rows per wave, 256-row workgroups of 4 waves, ONE wave per SIMD with the whole
-// 512-entry register file (O^T and Q^T in AGPRs) - every K row / V^T fragment read from LDS feeds two MFMAs and a streamed
-// K/V step serves 256 rows: half the LDS operand reads and half the L2 -> LDS DMA per FLOP of the 128-row workgroups.
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void fa_fwd_pipe_ag_kernel(const FwdParams p) {
-    fa_fwd_pipe_body<T, 128, 4, 2, CAUSAL, false, true>(p);
+    fa_fwd_pipe_body<T, D, NWAVES, QB, CAUSAL>(p);
 }
 
 template <typename T, int D, bool CAUSAL>
@@ -913,25 +708,10 @@ static hipError_t launch_pipe_c(const FwdParams& p, int waves, int qb, hipStream
     const int64_t grid = (int64_t)p.G8 * p.nq_tiles;
     if (qb == 2) {
         if constexpr (D == 64) {
-            if constexpr (!Elt<T>::is_f16) {   // (the scale fold is selected for bf16 only: fa_capi.cpp)
-                if (p.fold) return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-            }
-#if FA_EXPERIMENTAL   /* A/B material: mirrored row blocks; 512-row workgroups on one shared ring */
-            if constexpr (CAUSAL) {
-                if (waves == 8) return p.mirror ? launch1((const void*)(fa_fwd_pipe_w8_kernel<T, true>), dim3((unsigned)grid), dim3(512), 0, stream, p)
-                                                : launch1((const void*)(fa_fwd_pipe_w8_kernel<T, false>), dim3((unsigned)grid), dim3(512), 0, stream, p);
-                if (p.mirror) return launch1((const void*)(fa_fwd_pipe_mirror_kernel<T>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-            }
-#endif
             if (waves != 4) return hipErrorInvalidValue;
             return launch1((const void*)(fa_fwd_pipe_kernel<T, D, 4, 2, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         } else {
-#if FA_EXPERIMENTAL   /* the one-wave-per-SIMD AGPR variant is A/B material: make EXPERIMENTAL=1 */
-            if (waves != 4) return hipErrorInvalidValue;
-            return launch1((const void*)(fa_fwd_pipe_ag_kernel<T, CAUSAL>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-#else
             return hipErrorInvalidValue;
-#endif
         }
     }
     hipError_t e;

@@ -32,9 +32,6 @@
 
 #include "fa_device.h"
 
-#ifndef FA_EXPERIMENTAL
-#define FA_EXPERIMENTAL 0
-#endif
 #ifndef FA_P16_PF
 #define FA_P16_PF 8          // hand-scheduled step: LDS operands are requested this many operands ahead
 #endif
@@ -57,16 +54,13 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     constexpr int RW = 16 * NQH;                // query rows per wave
     constexpr int BQ = NWAVES * RW, HK = 32, ROWB = D * 2;
     constexpr int SLOT_B = HK * ROWB;           // K slot = V slot (8 KiB at head_dim 128, 4 KiB at 64)
-    // HALF (8 waves at head_dim 64: 4 K pieces + 4 V pieces per step): every wave issues ONE piece per step, waves 0 .. PIECES - 1 a K piece,
-    // the others a V piece
     constexpr int PIECES = SLOT_B / 1024;
-    constexpr bool HALF = PIECES * 2 == NWAVES;
-    constexpr int PPW = HALF ? 1 : PIECES / NWAVES;
-    constexpr int DPS = HALF ? 1 : 2 * PPW;     // LDS-DMA instructions a wave issues per step
+    constexpr int PPW = PIECES / NWAVES;
+    constexpr int DPS = 2 * PPW;                // LDS-DMA instructions a wave issues per step
     constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
     constexpr int RPP = 1024 / ROWB;            // rows per 1-KiB DMA piece
-    constexpr int NDIAG = RW >= HK ? RW / HK : 1;   // a wave's last NDIAG steps carry the causal mask (16-row waves: half a step's keys)
-    static_assert(HALF || (PPW >= 1 && PIECES % NWAVES == 0), "pieces must split evenly over the waves");
+    constexpr int NDIAG = RW / HK;              // a wave's last NDIAG steps carry the causal mask
+    static_assert(RW >= HK && PPW >= 1 && PIECES % NWAVES == 0, "32 | 64 rows per wave; pieces must split evenly over the waves");
     constexpr int NDS = D / 32;                 // 32-wide d slices of the QK^T contraction
     constexpr int NDB = D / 16;                 // 16-row d blocks of O^T
     constexpr int NS = 4, NSM = NS - 1;         // ring slots
@@ -139,7 +133,7 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     int dst[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int pc = HALF ? wave % PIECES : wave + j * NWAVES;
+        const int pc = wave + j * NWAVES;
         const int row = RPP * pc + lane / CPR, cp = lane % CPR;
         // (a chunk past the true head dim: an offset beyond the descriptor's extent - the DMA writes zeros, as for rows past L)
         k_vo[j] = (cp ^ kswz(row)) < dchunks ? (unsigned)row * k_slb + ((cp ^ kswz(row)) << 4) : 0x80000000u;
@@ -151,14 +145,14 @@ __device__ __forceinline__ void fa_fwd_pipe16_body(const FwdParams& p) {
     const unsigned smem_lds = lds_offset(smem);
 
 #define P16_DMA_K(J_, SLOT_)                                                                       \
-    if (!HALF || wave < PIECES) {                                                                  \
+    {                                                                                              \
         const unsigned ko_ = (unsigned)(J_) * HK * k_slb;                                          \
         const i32x4 kr_ = make_raw_rsrc((const char*)kg + ko_, k_bytes - ko_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
             lds_dma_b128(kr_, smem_lds + (SLOT_) * SLOT_B + dst[j], k_vo[j]);                      \
     }
 #define P16_DMA_V(J_, SLOT_)                                                                       \
-    if (!HALF || wave >= PIECES) {                                                                 \
+    {                                                                                              \
         const unsigned vo_ = (unsigned)(J_) * HK * v_slb;                                          \
         const i32x4 vr_ = make_raw_rsrc((const char*)vg + vo_, v_bytes - vo_);                     \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j)                                            \
@@ -518,9 +512,6 @@ template <typename T, bool CAUSAL>
 static hipError_t launch_pipe16_c(const FwdParams& p, int waves, int qb, hipStream_t stream) {
     const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles));
     // 8 waves = 256-row workgroups: half the K/V LDS-DMA pieces per wave and step, half the L2 -> LDS traffic per FLOP
-#if FA_EXPERIMENTAL   /* 8 waves x 16 rows = 128-row workgroups at head_dim 64: twice the waves per row block for under-filled grids */
-    if (p.D == 64 && waves == 8) return launch1((const void*)(fa_fwd_pipe16_kernel<T, 64, 8, 1, CAUSAL>), grid, dim3(512), 0, stream, p);
-#endif
     if (p.D == 64) {   // 4 waves; qb = 32-row query blocks per wave (the host sized p.nq_tiles for it)
         if (qb == 2) return launch1((const void*)(fa_fwd_pipe16_kernel<T, 64, 4, 4, CAUSAL>), grid, dim3(256), 0, stream, p);
         return launch1((const void*)(fa_fwd_pipe16_kernel<T, 64, 4, 2, CAUSAL>), grid, dim3(256), 0, stream, p);

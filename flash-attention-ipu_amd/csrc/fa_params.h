@@ -48,8 +48,6 @@ struct FwdParams {
     int32_t nq_real;
     int32_t sched;         // groups per XCD bunch (>= 1): heavy-first order inside a bunch
     int32_t skipmax;       // f16 only: 1 = reference max from the first tile + overflow-triggered redo
-    int32_t mirror;        // fa_fwd_pipe_kernel, head_dim 64, two blocks per wave, causal, L % 256 == 0: 1 = wave w owns row blocks w and 7 - w (fa_fwd_pipe.hip MIRROR)
-    int32_t fold;          // fa_fwd_pipe_kernel, head_dim 64, two blocks per wave: 1 = scale log2(e) folded into Q, reference max 0 (scaled calls)
     float scale;           // softmax scale
     float scale_log2;      // scale * log2(e)
     ExtraParams ex;
@@ -95,7 +93,6 @@ hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream);
 hipError_t launch_bwd_generic(const BwdParams& p, int dtype, hipStream_t stream);
 hipError_t launch_bwd_f32(const BwdParams& p, hipStream_t stream);   // fa_bwd_f32.hip: fp32, D in {64, 128}
 
-hipError_t launch_fwd_tile(const FwdParams& p, int dtype, int waves, hipStream_t stream);
 hipError_t launch_fwd_dma(const FwdParams& p, int dtype, int waves, int qb, int split, int pair, hipStream_t stream);
 hipError_t launch_fwd_extra(const FwdParams& p, int dtype, hipStream_t stream);   // fa_fwd_extra.hip: mask / bias / dropout (16-bit, D in {64, 128})
 hipError_t launch_bwd_extra(const BwdParams& p, int dtype, hipStream_t stream);   // fa_bwd_extra.hip
@@ -104,7 +101,6 @@ hipError_t launch_fwd_f32(const FwdParams& p, hipStream_t stream);   // fa_fwd_f
 
 hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);   // fa_fwd_pipe.hip
 hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream); // fa_fwd_pipe16.hip
-hipError_t launch_fwd_pp(const FwdParams& p, int dtype, hipStream_t stream);                        // fa_fwd_pp.hip (head_dim 64)
 hipError_t launch_fwd_kh(const FwdParams& p, int dtype, int split, hipStream_t stream);             // fa_fwd_kh.hip
 double probe_mfma_peak(int dtype, int iters, int random_data);
 hipError_t launch_clock_sampler(unsigned long long* out, int spins, hipStream_t stream);   // fa_probe.hip

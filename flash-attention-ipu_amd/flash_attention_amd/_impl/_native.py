@@ -132,18 +132,13 @@ def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale: float = 1.0
     return out
 
 
-_KERNEL_CODE = {"auto": 0, "": 0, None: 0, "dma": ord("d"), "pipe": ord("p"), "pipe16": ord("x"), "pp": ord("P"), "kh": ord("h"), "tile": ord("t")}
+_KERNEL_CODE = {"auto": 0, "": 0, None: 0, "dma": ord("d"), "pipe": ord("p"), "pipe16": ord("x"), "kh": ord("h")}
 _OPTION_AUTO = {"kernel": 0, "qb": 0, "waves": 0, "sched": 0, "skipmax": -1, "f32_generic": 0, "table": 1, "split": 0, "pair": -1,
-                "balance": -1, "fold": -1, "mirror": -1, "subsets": -1}
-
-
-def experimental_kernels() -> bool:
-    """True when the loaded library was built with `make EXPERIMENTAL=1` (kernels 'tile', 'pp' and the head_dim-128 AGPR variant)."""
-    return bool(load_native_library().fa_experimental_kernels())
+                "balance": -1, "subsets": -1}
 
 
 def set_debug_option(name: str, value) -> None:
-    """TEST / TUNING ONLY: fa_debug_set_option (kernel accepts 'dma' | 'pipe' | 'pipe16' | 'pp' | 'kh' | 'tile' | 'auto')."""
+    """TEST / TUNING ONLY: fa_debug_set_option (kernel accepts 'dma' | 'pipe' | 'pipe16' | 'kh' | 'auto')."""
     lib = load_native_library()
     if name == "kernel" and not isinstance(value, int):
         value = _KERNEL_CODE[value]

@@ -49,7 +49,8 @@ extern "C" {
 
 #define FA_ABI_VERSION 6   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
                               fa_fwd_ex / fa_bwd_ex (attention mask or bias, dropout); 5: fa_fwd_ex / fa_bwd_ex take `dropout_state`
-                              (seed and offset in DEVICE memory: graph-safe dropout), fa_experimental_kernels(); 6: fa_plan_t gains xs */
+                              (seed and offset in DEVICE memory: graph-safe dropout), fa_experimental_kernels(); 6: fa_plan_t gains xs, the A/B kernels
+                              (plan kernel 5, debug kernels 't' / 'P', options "fold" / "mirror") are gone */
 
 /* element types (reference allows FLOAT16 and FLOAT, FA.cpp:609; bf16 is new here) */
 enum { FA_DTYPE_F16 = 0, FA_DTYPE_BF16 = 1, FA_DTYPE_F32 = 2 };
@@ -83,8 +84,7 @@ typedef struct fa_plan_t {
                             2 = MFMA kernel, software-pipelined 32-key steps,
                             3 = fp32 MFMA kernel (fp32 inputs, D in {64,128}, 16-byte rows),
                             4 = software-pipelined kernel on v_mfma_f32_16x16x32 (bf16/f16, D in {64,128}),
-                            5 = 32-key steps with the two waves of a SIMD in complementary matrix / vector phases (bf16/f16, D = 64):
-                                a workgroup of 8 waves = two halves of block_q rows each, the same q tile of two groups,
+                            (5: retired - the complementary-phase kernel left the library in ABI 6),
                             6 = 64-key tiles, 64-row workgroups whose 4 waves are (row block, key half) pairs (bf16/f16, D in {64,128}) */
     int32_t block_q;     /* q rows per workgroup */
     int32_t block_kv;    /* keys per LDS tile / step */
@@ -109,9 +109,7 @@ typedef struct fa_plan_t {
 
 int fa_abi_version(void);
 
-/* 1 when the library was built with `make EXPERIMENTAL=1`: it then also carries the kernels no rule and no table row selects
- * (register-staged baseline 't', complementary-phase workgroups 'P', the one-wave-per-SIMD variant of the pipelined kernel at head_dim
- * 128) and fa_debug_set_option("kernel", 't' | 'P') is accepted; 0 in the product build.  [ABI 5]  (No reference counterpart.) */
+/* Always 0 since ABI 6 (kept so that ABI 5 callers link): the A/B kernels of earlier rounds left the library, docs/HISTORY.md. */
 int fa_experimental_kernels(void);
 
 /* thread-local text of the last failure on this thread ("" if none) */
@@ -150,15 +148,12 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  * process until set back to its "auto" value.  The FA_AMD_* environment variables of round 1 are read ONCE, at the
  * first call into the library, into the same knobs; nothing reads the environment per launch.
  *   "kernel"  0 auto | 'd' (64-key tiles, LDS-DMA) | 'p' (pipelined 32-key steps) | 'x' (the same on 16x16x32 MFMAs)
- *             | 'h' (64-row workgroups, waves = (row block, key half) of the 64-key tiles) | 'P' (32-key steps, the two waves of a
- *             SIMD in complementary phases: head_dim 64) | 't' (register-staged baseline)
+ *             | 'h' (64-row workgroups, waves = (row block, key half) of the 64-key tiles)
  *   "qb"      0 auto | 1 | 2        "waves"  0 auto | 1 | 2 | 4 | 8        "sched"  0 auto | n >= 1
  *   "skipmax" -1 auto | 0 | 1       "f32_generic" 0 | 1                    "table"  1 use the tuning table | 0 rules only
  *   "split"   0 auto | 1 | 2 | 4    kv split groups per workgroup ('d' kernel: 4 waves x 32 rows per group; 'h' kernel when forced with it)
  *   "pair"    -1 auto | 0 | 1       q-tile pairs (n - 1 - i, i) per workgroup ('d' kernel, causal, 4 waves)
  *   "balance" -1 auto | 0 | 1       placement-balanced block order of a causal grid below one round of workgroup slots
- *   "fold"    -1 auto (off) | 0 | 1   1 = fold scale log2(e) into Q (pipelined kernel, bf16, head_dim 64, softmax_scale <= 1/4): +5 %, but an
- *                                   error of 2^-9 of the logit's magnitude - for callers who know their logits are small
  *   "subsets" -1 auto | 0 off       q-tile subsets for group counts that leave XCDs idle (fa_plan_t.xs)
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
 int fa_debug_set_option(const char* name, int32_t value);

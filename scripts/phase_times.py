@@ -41,7 +41,7 @@ for name, val in (("kernel", a.kernel), ("waves", a.waves), ("qb", a.qb), ("bala
         assert lib.fa_debug_set_option(name.encode(), v) == 0
 plan = _native.FaPlan()
 assert lib.fa_plan(G, L, D, 1, 1, 1, ctypes.c_float(1.0), 1, ctypes.byref(plan)) == 0
-kern = {0: "dma", 2: "pipe", 4: "pipe16", 5: "pp", 6: "kh"}.get(plan.kernel, str(plan.kernel))
+kern = {0: "dma", 2: "pipe", 4: "pipe16", 6: "kh"}.get(plan.kernel, str(plan.kernel))
 BQ = plan.block_q
 print(f"G={G} L={L} D={D}: kernel={kern} waves={plan.waves} qb={plan.qb} block_q={BQ} grid={plan.grid}")
 assert kern in ("dma", "pipe")

@@ -2,9 +2,8 @@
 
 usage: python scripts/sweep.py [cfg] SPEC [SPEC ...]
   SPEC = "[lib:]K=pipe,W=4,S=4"   lib = name of build/variants/libfa_<lib>.so (default: the shipped library)
-         K kernel (tile|dma|pipe|pipe16|pp|kh), W waves per workgroup, S groups per L2 bunch, Q 32-row query blocks per wave (1|2),
+         K kernel (dma|pipe|pipe16|kh), W waves per workgroup, S groups per L2 bunch, Q 32-row query blocks per wave (1|2),
          P kv split groups per workgroup (dma: 2|4), R q-tile pairs per workgroup (dma: 0|1, default auto), B placement-balanced order (0|1, default auto),
-         M mirrored row blocks of the two-block pipelined kernel (0|1, default auto)
 Each timing = N back-to-back launches between two events; rounds are interleaved across specs.
 """
 import ctypes, os, sys, pathlib, statistics
@@ -51,12 +50,12 @@ def parse(spec):
 
 def setknobs(lib, rest):
     """knobs go through fa_debug_set_option of THAT library (the environment is only read once, at load)"""
-    want = {"kernel": 0, "waves": 0, "sched": 0, "qb": 0, "split": 0, "pair": -1, "balance": -1, "mirror": -1}
+    want = {"kernel": 0, "waves": 0, "sched": 0, "qb": 0, "split": 0, "pair": -1, "balance": -1}
     for kv in rest.split(","):
         if kv:
             k, val = kv.split("=")
-            name = {"K": "kernel", "W": "waves", "S": "sched", "Q": "qb", "P": "split", "R": "pair", "B": "balance", "M": "mirror"}[k]
-            want[name] = (ord("x") if val in ("pipe16", "x") else ord("P") if val in ("pp", "P") else ord("h") if val in ("kh", "h") else ord(val[0])) if name == "kernel" else int(val)
+            name = {"K": "kernel", "W": "waves", "S": "sched", "Q": "qb", "P": "split", "R": "pair", "B": "balance"}[k]
+            want[name] = (ord("x") if val in ("pipe16", "x") else ord("h") if val in ("kh", "h") else ord(val[0])) if name == "kernel" else int(val)
     for name, val in want.items():
         assert lib.fa_debug_set_option(name.encode(), val) == 0, (name, val)
 

@@ -43,8 +43,6 @@ class _Knobs:
 
     def set(self, name, value):
         name = self._NAMES.get(name, name)
-        if name == "kernel" and value in ("tile", "pp") and not self._native.experimental_kernels():
-            pytest.skip(f"kernel '{value}' is A/B material, not in the product library (make EXPERIMENTAL=1)")
         if name == "f32_generic" and isinstance(value, str):
             value = 1 if value.startswith("g") else 0
         if name != "kernel":

@@ -17,13 +17,11 @@ hipError_t launch_bwd_generic(const BwdParams&, int, hipStream_t) { ++g_stub_lau
 hipError_t launch_bwd_f32(const BwdParams&, hipStream_t) { ++g_stub_launches; g_stub_last = 'F'; return hipSuccess; }
 hipError_t launch_fwd_extra(const FwdParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'E'; return hipSuccess; }
 hipError_t launch_bwd_extra(const BwdParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'e'; return hipSuccess; }
-hipError_t launch_fwd_tile(const FwdParams&, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 't'; return hipSuccess; }
 hipError_t launch_fwd_dma(const FwdParams&, int, int, int, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'd'; return hipSuccess; }
 hipError_t launch_fwd_generic(const FwdParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'g'; return hipSuccess; }
 hipError_t launch_fwd_f32(const FwdParams&, hipStream_t) { ++g_stub_launches; g_stub_last = 'f'; return hipSuccess; }
 hipError_t launch_fwd_pipe(const FwdParams&, int, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'p'; return hipSuccess; }
 hipError_t launch_fwd_pipe16(const FwdParams&, int, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'x'; return hipSuccess; }
-hipError_t launch_fwd_pp(const FwdParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'P'; return hipSuccess; }
 hipError_t launch_fwd_kh(const FwdParams&, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'h'; return hipSuccess; }
 double probe_mfma_peak(int, int, int) { return -1.0; }
 hipError_t launch_clock_sampler(unsigned long long*, int, hipStream_t) { return hipSuccess; }

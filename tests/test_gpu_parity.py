@@ -80,31 +80,14 @@ def test_packed_vs_oracle(dtype, G, L, D, nq, nk):
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, 8])
-@pytest.mark.parametrize("D", [64, 128])
-def test_every_tile_variant(knobs, waves, D):
-    """All hardware q-tile sizes (32..256 rows) give the same answer."""
-    fa, native, _ = _mods()
-    from oracle import frozen_randn
-
-    knobs.set("FA_AMD_WAVES", str(waves))
-    qkv = frozen_randn(SEED + waves, (3, 3, 600, D)).to(torch.bfloat16)
-    ref, _ = _oracle(qkv)
-    out = fa.flash_attention_qkv_packed(qkv.cuda(), 1, 1)
-    _check(out, ref, torch.bfloat16, f"waves={waves} D={D}")
-    knobs.set("FA_AMD_SCHED", "1")
-    out_b = fa.flash_attention_qkv_packed(qkv.cuda(), 1, 1)
-    assert torch.equal(out, out_b), "block->tile schedule changed the result"
-
-
-MFMA_KERNELS = [("dma", 1), ("dma", 2), ("pipe", 1), ("pipe", 2), ("tile", 1)]
+MFMA_KERNELS = [("dma", 1), ("dma", 2), ("pipe", 1), ("pipe", 2)]
 
 
 @pytest.mark.parametrize("kernel,qb", MFMA_KERNELS)
 @pytest.mark.parametrize("G,L,D", [(2, 32, 64), (9, 257, 64), (3, 600, 64), (2, 2304, 64), (1, 4608, 64), (2, 1000, 128)])
 def test_every_mfma_kernel(knobs, kernel, qb, G, L, D):
-    """The three MFMA kernels (64-key tiles with LDS-DMA, software-pipelined 32-key steps, register-staged
-    baseline), with one and two 32-row query blocks per wave, against the oracle - whatever the default
+    """The MFMA kernels (64-key tiles with LDS-DMA, software-pipelined 32-key steps), with one and two 32-row
+    query blocks per wave, against the oracle - whatever the default
     selection for a shape is.  (Two blocks exist for head_dim 64 only; the request falls back to one otherwise.)"""
     _, _, with_lse = _mods()
     from oracle import frozen_randn
@@ -158,128 +141,6 @@ def test_pipelined_kernel_on_16x16x32_mfma_head_dim_128(knobs, dtype, scale, G, 
     native.fwd_strided(q, k, v, out, lse, G, L, 128, 1, st, st, st, st, 1, 1, scale)
     _check(out, ref, dtype, f"pipe16 {dtype} scale={scale:.3g} {G}x{L}x128")
     torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
-
-
-@pytest.mark.parametrize("causal", [True, False])
-@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 128 ** -0.5), (torch.float16, 128 ** -0.5)])
-@pytest.mark.parametrize("G,L", [(2, 32), (3, 100), (2, 257), (2, 1000), (1, 4608), (9, 600), (2, 2304)])
-def test_pipelined_kernel_one_wave_per_simd_head_dim_128(knobs, dtype, scale, G, L, causal):
-    """fa_fwd_pipe_ag_kernel (head_dim 128, two 32-row query blocks per wave, 256-row workgroups of 4 waves, one wave per SIMD with
-    O^T and Q^T in AGPRs - the MFMAs that touch them are asm, fa_device.h MfmaAsm): out and logsumexp against the oracle for
-    ragged / short / long sequences (first step only, left-over steps, groups of four, both diagonal steps, drain), bf16 and
-    1/sqrt(D)-scaled f16, causal and unmasked."""
-    _, native, _ = _mods()
-    from oracle import dense_attention_lse, frozen_randn
-
-    if not native.experimental_kernels():
-        pytest.skip("the one-wave-per-SIMD AGPR variant is A/B material, not in the product library (make EXPERIMENTAL=1)")
-    knobs.set("kernel", "pipe")
-    knobs.set("qb", 2)
-    p = native.plan(G, L, 128, dtype, 1, 1, softmax_scale=scale, causal=causal)
-    if L >= 256:      # (shorter sequences fall back to one block per wave, as at head_dim 64)
-        assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (2, 4, 2, 256, 32)
-    x = frozen_randn(SEED + 17 * L + G, (3, G, L, 128)).to(dtype)
-    ref, ref_lse = _oracle(x, scale=scale) if causal else dense_attention_lse(x[0], x[1], x[2], scale=scale, causal=False)
-    q, k, v = x.cuda()
-    out = torch.empty_like(q)
-    lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
-    st = (L * 128, 0, 128)
-    native.fwd_strided(q, k, v, out, lse, G, L, 128, 1, st, st, st, st, 1, 1, scale, causal)
-    _check(out, ref, dtype, f"pipe ag {dtype} scale={scale:.3g} causal={causal} {G}x{L}x128")
-    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
-
-
-@pytest.mark.parametrize("causal", [True, False])
-@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 0.125), (torch.float16, 0.125)])
-@pytest.mark.parametrize("G,L", [(2, 16), (2, 32), (3, 100), (2, 257), (9, 600), (2, 1000), (1, 4608), (12, 1024)])
-def test_pipelined_16x16x32_kernel_with_16_row_waves(knobs, dtype, scale, G, L, causal):
-    """fa_fwd_pipe16_kernel<T, 64, 8, 1> (A/B material): 128-row workgroups of EIGHT waves x 16 rows on v_mfma_f32_16x16x32 -
-    twice the waves per row block, half the dependency chain per step, one LDS-DMA piece per wave and step - for launches with fewer
-    workgroups than the chip has slots.  Out and logsumexp against the oracle (a wave's diagonal step covers half a step's keys)."""
-    _, native, _ = _mods()
-    from oracle import dense_attention_lse, frozen_randn
-
-    if not native.experimental_kernels():
-        pytest.skip("A/B material, not in the product library (make EXPERIMENTAL=1)")
-    knobs.set("kernel", "pipe16")
-    knobs.set("waves", 8)
-    p = native.plan(G, L, 64, dtype, 1, 1, softmax_scale=scale, causal=causal)
-    assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (4, 8, 1, 128, 32)
-    x = frozen_randn(SEED + 31 * L + G, (3, G, L, 64)).to(dtype)
-    ref, ref_lse = _oracle(x, scale=scale) if causal else dense_attention_lse(x[0][None], x[1][None], x[2][None], scale=scale, causal=False)
-    q, k, v = x.cuda()
-    out = torch.empty_like(q)
-    lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
-    st = (L * 64, 0, 64)
-    native.fwd_strided(q, k, v, out, lse, G, L, 64, 1, st, st, st, st, 1, 1, scale, causal)
-    _check(out, ref.reshape(G, L, 64), dtype, f"pipe16 16-row waves {dtype} scale={scale:.3g} causal={causal} {G}x{L}x64")
-    torch.testing.assert_close(lse.cpu().double(), ref_lse.reshape(G, L), atol=LSE_ATOL, rtol=1e-4)
-
-
-@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.float16, 0.125)])
-@pytest.mark.parametrize("G,L", [(3, 512), (9, 1024), (2, 2560), (1, 4608), (2, 4096), (2, 700)])
-def test_512_row_workgroups_on_one_shared_ring(knobs, dtype, scale, G, L):
-    """fa_fwd_pipe_w8_kernel (A/B material): 8 waves x 2 blocks = 512-row workgroups at head_dim 64 streaming K/V through
-    ONE ring (one LDS-DMA piece per wave and step), with and without mirrored row blocks (blocks w and 15 - w): bit-identical to the
-    256-row kernel - every row runs the same program - and equal to the oracle."""
-    _, native, _ = _mods()
-    from oracle import frozen_randn
-
-    if not native.experimental_kernels():
-        pytest.skip("A/B material, not in the product library (make EXPERIMENTAL=1)")
-    x = frozen_randn(SEED + 29 * L + G, (3, G, L, 64)).to(dtype)
-    ref, ref_lse = _oracle(x, scale=scale)
-    q, k, v = x.cuda()
-    st = (L * 64, 0, 64)
-    res = []
-    for waves, mirror in ((4, 0), (8, 0), (8, 1)):
-        knobs.set("kernel", "pipe")
-        knobs.set("qb", 2)
-        knobs.set("waves", waves)
-        knobs.set("mirror", mirror)
-        p = native.plan(G, L, 64, dtype, 1, 1, softmax_scale=scale)
-        assert (p.kernel, p.waves, p.qb, p.block_q) == (2, waves, 2, 64 * waves)
-        out = torch.empty_like(q)
-        lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
-        native.fwd_strided(q, k, v, out, lse, G, L, 64, 1, st, st, st, st, 1, 1, scale)
-        res.append((out, lse))
-    _check(res[1][0], ref, dtype, f"512-row workgroups {dtype} scale={scale:.3g} {G}x{L}x64")
-    torch.testing.assert_close(res[1][1].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
-    for o, l_ in res[1:]:
-        assert torch.equal(res[0][0], o) and torch.equal(res[0][1], l_), "512-row workgroups / mirroring must not change a single bit"
-
-
-@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 0.125), (torch.float16, 0.125)])
-@pytest.mark.parametrize("G,L", [(2, 256), (3, 512), (9, 1024), (2, 2304), (1, 4608), (2, 4096)])
-def test_mirrored_row_blocks_of_the_two_block_pipelined_kernel(knobs, dtype, scale, G, L):
-    """fa_fwd_pipe_mirror_kernel: wave w of a 256-row workgroup owns the 32-row blocks w and 7 - w instead of 2 w and 2 w + 1, runs
-    one-block steps (the dead block's MFMAs are not issued) between its two diagonals, the PV of block 0's diagonal P one step
-    later.  Every row runs the same program as in the unmirrored kernel, so the results are BIT-IDENTICAL to it, and both match
-    the oracle; one-tile, two-tile and many-tile sequences (first step only / left-over steps / groups of four in front of the
-    diagonal region)."""
-    _, native, _ = _mods()
-    from oracle import frozen_randn
-
-    if not native.experimental_kernels():
-        pytest.skip("A/B material, not in the product library (make EXPERIMENTAL=1)")
-    knobs.set("kernel", "pipe")
-    knobs.set("qb", 2)
-    p = native.plan(G, L, 64, dtype, 1, 1, softmax_scale=scale)
-    assert (p.kernel, p.waves, p.qb, p.block_q) == (2, 4, 2, 256)
-    x = frozen_randn(SEED + 23 * L + G, (3, G, L, 64)).to(dtype)
-    ref, ref_lse = _oracle(x, scale=scale)
-    q, k, v = x.cuda()
-    st = (L * 64, 0, 64)
-    res = []
-    for mirror in (0, 1):
-        knobs.set("mirror", mirror)
-        out = torch.empty_like(q)
-        lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
-        native.fwd_strided(q, k, v, out, lse, G, L, 64, 1, st, st, st, st, 1, 1, scale)
-        res.append((out, lse))
-    _check(res[1][0], ref, dtype, f"mirrored {dtype} scale={scale:.3g} {G}x{L}x64")
-    torch.testing.assert_close(res[1][1].cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "mirroring must not change a single bit"
 
 
 @pytest.mark.parametrize("D,split", [(64, 2), (64, 4), (128, 2)])
@@ -396,61 +257,6 @@ def test_pipelined_kernel_on_16x16x32_mfma_head_dim_64(knobs, dtype, scale, G, L
 
 
 @pytest.mark.parametrize("causal", [1, 0])
-@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.bfloat16, 64 ** -0.5), (torch.float16, 64 ** -0.5)])
-@pytest.mark.parametrize("G,L", [(1, 32), (2, 64), (3, 100), (2, 257), (17, 300), (2, 1000), (1, 4608), (9, 600), (16, 2049), (5, 1024)])
-def test_ping_pong_kernel_head_dim_64(knobs, dtype, scale, G, L, causal):
-    """fa_fwd_pp_kernel (fa_fwd_pp.hip: 512-thread workgroups = two 256-row halves, the two waves of a SIMD in complementary matrix /
-    vector phases): out and logsumexp against the oracle - one step only, ragged last steps, waves without rows, odd group counts
-    (a half without a group of its own), group counts that leave XCD classes empty, causal and unmasked."""
-    _, native, _ = _mods()
-    from oracle import dense_attention_lse, frozen_randn
-
-    knobs.set("kernel", "pp")
-    p = native.plan(G, L, 64, dtype, 1, 1, softmax_scale=scale, causal=causal)
-    assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (5, 8, 2, 256, 32)
-    assert p.grid == 8 * (((G + 7) // 8 + 1) // 2) * ((L + 255) // 256)
-    x = frozen_randn(SEED + 19 * L + G, (3, G, L, 64)).to(dtype)
-    if causal:
-        ref, ref_lse = _oracle(x, scale=scale)
-    else:
-        ref, ref_lse = dense_attention_lse(x[0][None], x[1][None], x[2][None], scale=scale, causal=False)
-        ref, ref_lse = ref[0], ref_lse[0]
-    q, k, v = x.cuda()
-    out = torch.full_like(q, float("nan"))
-    lse = torch.full((G, L), float("nan"), device="cuda", dtype=torch.float32)
-    st = (L * 64, 0, 64)
-    native.fwd_strided(q, k, v, out, lse, G, L, 64, 1, st, st, st, st, 1, 1, scale, causal=causal)
-    _check(out, ref, dtype, f"pp {dtype} scale={scale:.3g} causal={causal} {G}x{L}x64")
-    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("step", [3.0, 25.0, 100.0])
-def test_ping_pong_growing_logits_force_the_exact_pass(knobs, dtype, step):
-    """The optimistic pass of fa_fwd_pp_kernel must detect a P that left the safe range and redo the workgroup (both halves) through
-    its exact pass (cdna guide rule 26: force the rare branch).  Group 0 keeps small logits: its half is dragged through the
-    exact pass by its partner and must come out right too."""
-    _, native, with_lse = _mods()
-    from oracle import frozen_randn
-
-    knobs.set("kernel", "pp")
-    knobs.set("skipmax", 1)
-    G, L, D = 18, 1024, 64
-    x = frozen_randn(SEED + 57, (3, G, L, D)) * 0.05
-    u = torch.zeros(D)
-    u[:4] = 1.0
-    tile = torch.arange(L) // 64
-    x[0] += u
-    x[1, 8:] += u[None, None, :] * (step / 4.0) * tile[None, :, None]      # groups 8 .. 17 grow, groups 0 .. 7 (their partners) do not
-    x = x.to(dtype)
-    assert native.plan(G, L, D, dtype, 1, 1).kernel == 5
-    ref, ref_lse = _oracle(x)
-    out, lse = with_lse(x.cuda(), 1, 1)
-    _check(out, ref, dtype, f"pp growing logits step={step}")
-    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
-
-
-@pytest.mark.parametrize("causal", [1, 0])
 @pytest.mark.parametrize("D,dtype,scale", [(64, torch.bfloat16, 1.0), (64, torch.bfloat16, 64 ** -0.5), (64, torch.float16, 1.0), (64, torch.float16, 64 ** -0.5),
                                            (128, torch.bfloat16, 128 ** -0.5), (128, torch.float16, 1.0)])
 @pytest.mark.parametrize("G,L", [(1, 32), (2, 64), (3, 100), (2, 257), (17, 300), (2, 1000), (1, 4608), (9, 600), (5, 1024)])
@@ -558,69 +364,6 @@ def _run_strided(native, x, scale, causal=True):
     st = (L * D, 0, D)
     native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, scale, causal=causal)
     return out, lse
-
-
-@pytest.mark.parametrize("causal", [1, 0])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("G,L", [(2, 300), (3, 1000), (1, 4608), (9, 2049)])
-def test_scale_fold_of_the_pipelined_kernel(knobs, dtype, G, L, causal):
-    """Scaled calls (softmax_scale <= 1/4: the SDPA override's 1 / sqrt(D)) run the two-block pipelined kernel with scale log2(e) folded
-    into the Q fragments and the reference max fixed at 0 (fa_fwd_pipe.hip FOLD) WHEN ASKED TO (fold = 1; off by default: its error grows
-    with the logits' magnitude): out and logsumexp against the oracle at unit-variance logits, with the fold on and off - the two must
-    agree within the rounding of the re-rounded Q."""
-    _, native, _ = _mods()
-    from oracle import dense_attention_lse, frozen_randn
-
-    D, scale = 64, 64 ** -0.5
-    knobs.set("kernel", "pipe")
-    knobs.set("qb", 2)
-    x = frozen_randn(SEED + 37 * L + G, (3, G, L, D)).to(dtype)
-    if causal:
-        ref, ref_lse = _oracle(x, scale=scale)
-    else:
-        ref, ref_lse = dense_attention_lse(x[0][None], x[1][None], x[2][None], scale=scale, causal=False)
-        ref, ref_lse = ref[0], ref_lse[0]
-    res = {}
-    for fold in (1, 0):
-        knobs.set("fold", fold)
-        out, lse = _run_strided(native, x, scale, causal)
-        _check(out, ref, dtype, f"pipe fold={fold} {dtype} causal={causal} {G}x{L}")
-        torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=LSE_ATOL, rtol=1e-4)
-        res[fold] = out
-    if dtype == torch.bfloat16:
-        assert not torch.equal(res[1], res[0]), "the fold was not in force"    # (re-rounded Q: results differ in the last bits)
-        assert (res[1].float() - res[0].float()).abs().max().item() <= 2e-2
-    else:                                                                      # f16 P would overflow from a scaled logit of 11 on: no fold
-        assert torch.equal(res[1], res[0])
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("kind", ["overflow", "underflow", "mixed"])
-def test_scale_fold_leaves_through_the_exact_pass(knobs, dtype, kind):
-    """With the reference max at 0 a P can overflow (scaled logits far above 0: the row sum turns inf / NaN) or a whole row can
-    underflow (every logit far below 0: row sum < 2^-80) - both must send the workgroup through the exact pass and come out right."""
-    _, native, _ = _mods()
-    from oracle import frozen_randn
-
-    G, L, D, scale = 3, 1024, 64, 64 ** -0.5
-    knobs.set("kernel", "pipe")
-    knobs.set("qb", 2)
-    knobs.set("fold", 1)
-    if dtype == torch.float16:
-        knobs.set("skipmax", 1)
-    x = frozen_randn(SEED + 59, (3, G, L, D)) * 0.3
-    u = torch.zeros(D)
-    u[:16] = 1.0                                                   # |u|^2 = 16
-    amp = {"overflow": 9.0, "underflow": -9.0, "mixed": 9.0}[kind]   # q.k = +-81 * 16 = +-1296 -> scaled logit +-162 -> exponent +-234
-    x[0, 1] += u * 9.0
-    x[1, 1] += u * amp
-    if kind == "mixed":
-        x[1, 1, ::2] -= 2 * u * amp                                # every other key far below, the rest far above
-    x = x.to(dtype)
-    ref, ref_lse = _oracle(x, scale=scale)
-    out, lse = _run_strided(native, x, scale)
-    _check(out, ref, dtype, f"pipe fold {kind}")
-    torch.testing.assert_close(lse.cpu().double(), ref_lse, atol=5e-2, rtol=2e-3)
 
 
 @pytest.mark.parametrize("step", [3.0, 25.0, 100.0])

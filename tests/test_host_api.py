@@ -203,21 +203,11 @@ def _check_builtin_rules(native):
     assert native.plan(128, 2048, 64, torch.bfloat16, 8, 8, causal=False).kernel == 0
     assert native.plan(4, 4096, 64, torch.float16, 128, 64).block_q == 32    # 32-row chunks honoured
     assert native.plan(5, 200, 64, torch.bfloat16, 1, 1).grid == 8 * 2       # G padded to the 8 XCDs
-    # the complementary-phase kernel (fa_fwd_pp.hip) is a forced variant only: head_dim 64, skip-max arithmetic; one workgroup =
-    # 8 waves = two 256-row halves (the same q tile of two groups of one XCD class); groups per bunch are counted in pairs
-    if not native.experimental_kernels():      # the product build: the forced variant is refused, nothing changes
-        with pytest.raises(ValueError, match="not in this build"):
-            native.set_debug_option("kernel", "pp")
-        assert native.plan(128, 4096, 64, torch.bfloat16, 8, 8).kernel == 2
-    else:
-      with native.debug_options(kernel="pp"):
-        p = native.plan(128, 4096, 64, torch.bfloat16, 8, 8)
-        assert (p.kernel, p.block_q, p.block_kv, p.waves, p.qb, p.source) == (5, 256, 32, 8, 2, 2)
-        assert p.grid == 8 * 8 * 16 and p.lds_bytes == 2 * (4 * 4096 + 8 * (2048 + 64)) + 32 and p.sched == 4
-        assert native.plan(17, 300, 64, torch.bfloat16, 1, 1).grid == 8 * 2 * 2      # 3 groups in XCD class 0: two pairs
-        assert native.plan(128, 4096, 128, torch.bfloat16, 8, 8).kernel == 0          # head_dim 128: falls back
-        assert native.plan(128, 4096, 64, torch.float16, 8, 8).kernel == 0            # unscaled f16 keeps the row max: falls back
-        assert native.plan(128, 4096, 64, torch.float16, 8, 8, softmax_scale=0.125).kernel == 5
+    # the A/B kernels of earlier rounds (register-staged 'tile', complementary-phase 'pp') left the library with ABI 6: their names are refused
+    for gone in ("pp", "tile"):
+        with pytest.raises(KeyError):
+            native.set_debug_option("kernel", gone)
+    assert native.load_native_library().fa_experimental_kernels() == 0
     assert native.plan(4, 6, 2, torch.float32, 3, 3).kernel == 1             # generic kernel
     assert native.plan(4, 256, 64, torch.float32, 1, 1).kernel == 3             # fp32 MFMA kernel (D 64 / 128)
     assert native.plan(4, 256, 80, torch.float32, 1, 1).kernel == 1

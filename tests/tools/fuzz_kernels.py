@@ -13,7 +13,6 @@ from flash_attention_amd._impl import _native
 from oracle import dense_attention_lse
 
 lib = _native.load_native_library()
-EXPERIMENTAL = _native.experimental_kernels()     # `make EXPERIMENTAL=1`: the register-staged baseline and the complementary-phase kernel exist
 
 
 def run(q, k, v, heads, scale, knobs, causal=True):
@@ -62,16 +61,14 @@ def fuzz(cases, seed, log=print):
           variants.append({"kernel": "pipe16", "waves": rng.choice([4, 8]), "sched": rng.choice([1, 2, 8])})
       else:             # 32 or 64 query rows per wave at head_dim 64
           variants.append({"kernel": "pipe16", "waves": 4, "qb": rng.choice([1, 2]), "sched": rng.choice([1, 2, 8])})
-          if EXPERIMENTAL:
-              variants.append({"kernel": "pp", "sched": rng.choice([1, 2, 8])})      # 512-thread workgroups of two halves in complementary phases
       variants.append({"split": 2 if D == 128 else rng.choice([2, 4]), "sched": rng.choice([1, 2, 8])})   # kv split groups (dma kernel)
       variants.append({"kernel": "kh", "sched": rng.choice([1, 2, 8])})      # 64-row workgroups, waves = (row block, key half) ...
       variants.append({"kernel": "kh", "split": 2 if D == 128 else rng.choice([2, 4]), "balance": rng.choice([0, 1])})   # ... with kv split groups
       if only is not None and case != int(only):
           continue
-      # the baseline of the cheap cross-check: the register-staged kernel where the library has it (make EXPERIMENTAL=1), else the plain
-      # 64-key-tile LDS-DMA kernel with 4 waves x one block (the oracle arbitrates every disagreement either way)
-      base, base_lse = run(q, k, v, H, scale, {"kernel": "tile"} if EXPERIMENTAL else {"kernel": "dma", "waves": 4, "qb": 1, "sched": 1}, causal)
+      # the baseline of the cheap cross-check: the plain 64-key-tile LDS-DMA kernel with 4 waves x one block (the oracle arbitrates every
+      # disagreement either way)
+      base, base_lse = run(q, k, v, H, scale, {"kernel": "dma", "waves": 4, "qb": 1, "sched": 1}, causal)
       ulp = 2.0 ** -6 if dt == torch.bfloat16 else 2.0 ** -9
       ref = None
       if L <= 700:
