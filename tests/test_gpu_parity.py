@@ -191,7 +191,8 @@ def test_q_tile_pairs_per_workgroup(knobs, D, dtype, scale, G, L):
         p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale)
         nq = (L + 127) // 128
         assert (p.kernel, p.waves, p.qb, p.block_q, p.pair) == (0, 4, 1, 128, pair)
-        assert p.grid == (G + 7) // 8 * 8 * ((nq + 1) // 2 if pair else nq)
+        # (pair = 0: a group count that leaves XCDs idle is laid out over (group, q-tile subset) pairs, fa_plan_t.xs - tests/test_gpu_subsets.py)
+        assert p.grid == ((G + 7) // 8 * 8 * ((nq + 1) // 2) if pair else (G * p.xs + 7) // 8 * 8 * ((nq + p.xs - 1) // p.xs))
         out = torch.empty_like(q)
         lse = torch.empty(G, L, device="cuda", dtype=torch.float32)
         native.fwd_strided(q, k, v, out, lse, G, L, D, 1, st, st, st, st, 1, 1, scale)
@@ -286,7 +287,7 @@ def _key_halves_case(knobs, D, dtype, scale, G, L, causal, split, force=None):
         knobs.set("split", force)
     p = native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale, causal=causal)
     assert (p.kernel, p.waves, p.qb, p.block_q, p.block_kv) == (6, 4 * split, 1, 64, 64)
-    assert p.grid == ((G + 7) // 8 * 8) * ((L + 63) // 64)
+    assert p.grid == ((G * p.xs + 7) // 8 * 8) * (((L + 63) // 64 + p.xs - 1) // p.xs)     # (xs: q-tile subsets, tests/test_gpu_subsets.py)
     assert p.lds_bytes == split * (2 * (64 * D * 2 + (D // 32) * (64 * 64 + 64)) + 16)
     x = frozen_randn(SEED + 23 * L + G + D, (3, G, L, D)).to(dtype)
     if causal:
