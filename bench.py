@@ -52,6 +52,7 @@ CONFIGS = {
     "cfg5_shard": (256, 8192, 64, "bf16", (16, 8)),  # configs[4] per-GPU shard at 8 GPUs
     "small_grid": (8, 4096, 64, "bf16", (8, 8)),     # not a BASELINE config: 256 workgroups on 256 CUs (split-KV plan)
     "l1024": (512, 1024, 64, "bf16", (4, 4)),        # not a BASELINE config: the short-sequence regime on a full grid
+    "few_groups": (2, 32768, 64, "bf16", (16, 16)),  # not a BASELINE config: batch 1 x 2 heads, long context - fewer groups than XCDs (q-tile subsets)
     "cfg4_attn": (96, 1024, 64, "bf16", (4, 4)),     # configs[3]'s attention call alone: SDPA override on head-inner [8,12,1024,64] views
     "nb_65536": (8, 65536, 64, "f16", (64, 64)),     # the reference notebook's longest demonstrated context (nb:939, :952-963)
     "cfg2_sdpa": (128, 4096, 64, "bf16", (8, 8)),    # the headline shape through the SDPA override ([8,16,4096,64], scale 1/sqrt(D): sdpa.py:55-59)
@@ -276,7 +277,7 @@ def secondary_attention(name, dev, steps=20, warmup=5, backward=False):
     if backward:
         rec["flops"] = "5GL^2D"
     elif plan is not None:
-        rec["tile"] = f"{plan.block_q}x{plan.block_kv}/{plan.waves}w" + (f"/split{32 * plan.waves * plan.qb // plan.block_q}" if 32 * plan.waves * plan.qb > plan.block_q else "")
+        rec["tile"] = f"{plan.block_q}x{plan.block_kv}/{plan.waves}w" + (f"/split{32 * plan.waves * plan.qb // plan.block_q}" if 32 * plan.waves * plan.qb > plan.block_q else "") + (f"/xs{plan.xs}" if plan.xs > 1 else "")
     return rec
 
 
@@ -780,7 +781,7 @@ def main():
             # BASELINE configs LAST (the driver keeps the tail of stdout), every record compact; the same numbers once more, shorter
             # still, under roofline.other_configs - a key the driver stores verbatim
             sec = {}
-            for name in ("small_grid", "l1024", "nb_65536", "cfg2_sdpa", "cfg2_f16", "cfg4_attn", "cfg5_shard", "cfg3"):
+            for name in ("few_groups", "small_grid", "l1024", "nb_65536", "cfg2_sdpa", "cfg2_f16", "cfg4_attn", "cfg5_shard", "cfg3"):
                 if name != args.config:
                     try:
                         sec[name] = secondary_attention(name, dev)

@@ -31,7 +31,7 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_every_baseline_con
     roof = rec["roofline"]
     assert roof["bound"] == "mfma" and roof["peak"] == 2500.0 and abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-3
     others = roof["other_configs"]
-    for name in ("cfg3", "cfg5_shard", "cfg2_f16", "cfg4_attn", "cfg2_sdpa", "cfg2_bwd", "cfg4_gpt2_fwd", "small_grid", "l1024", "nb_65536"):
+    for name in ("cfg3", "cfg5_shard", "cfg2_f16", "cfg4_attn", "cfg2_sdpa", "cfg2_bwd", "cfg4_gpt2_fwd", "small_grid", "l1024", "nb_65536", "few_groups"):
         assert name in others and "error" not in others[name], (name, others.get(name))
         assert name in rec["secondary"]
     assert list(rec["secondary"])[-4:-2] == ["cfg5_shard", "cfg3"], "the BASELINE configs come last among the forward records"
