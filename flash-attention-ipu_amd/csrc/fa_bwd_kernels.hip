@@ -542,6 +542,13 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     // requested one item ahead, into the registers the same half of the current item has just decoded (see the dQ kernel)
     unsigned mkv[EXTRA == 2 ? 32 : 1];
     (void)mkv;
+    // EXTRA == 1 with a mask: a row-broadcast one (row stride 0: fa_bwd_extra.hip sends every other mask to EXTRA == 2), so the term of a
+    // score depends on its key alone - one load per lane and query head, not one per element; a wave whose 32 keys are all masked for
+    // that head (a padded tail) skips the head's tiles: its P is 0, its dK / dV contribution exactly the zeros already there
+    float kterm = 0.f;
+    int kterm_hq = -1;
+    bool kskip = false;
+    (void)kterm; (void)kterm_hq; (void)kskip;
 #define FA_KV_MASK_PF(J_, HB_)                                                                     \
     if constexpr (EXTRA == 2) {                                                                    \
         if (p.ex.mask != nullptr && wave_active && (J_) < n_items) {                               \
@@ -561,7 +568,15 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         FA_ITEM(J_, hqt_, itt_)                                                                    \
         (void)hqt_; (void)mask_esz;                                                                \
         const int q0 = itt_ * BQ;                                                                  \
-        if (wave_active && (!causal || q0 + BQ - 1 >= key0)) {                                     \
+        if constexpr (EXTRA == 1) {                                                                \
+            if (p.ex.mask != nullptr && wave_active && kterm_hq != (p.ex.m_sh == 0 ? 0 : hqt_)) {  \
+                kterm_hq = p.ex.m_sh == 0 ? 0 : hqt_;                                              \
+                const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqt_) * p.ex.m_sh) * mask_esz; \
+                kterm = mask_load1<T>(p.ex.mask_kind, mb_, 0, kr, p.ex.inv_scale);                 \
+                kskip = __builtin_amdgcn_ballot_w64(kterm != -INFINITY) == 0;                      \
+            }                                                                                      \
+        }                                                                                          \
+        if (wave_active && !(EXTRA == 1 && kskip) && (!causal || q0 + BQ - 1 >= key0)) {           \
             const unsigned char* qb_ = smem + (BUF_) * IMG_B;                                      \
             const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
             const float* rc_ = rowc + (BUF_) * 128;                                                \
@@ -586,12 +601,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                                 else s0[e] += w_ ? 0.f : -INFINITY;                                \
                             }                                                                      \
                             FA_KV_MASK_PF((J_) + 1, hb)                                            \
-                        } else {                                                                   \
-                            const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqt_) * p.ex.m_sh) * mask_esz; \
-                            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                       \
-                                const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;      \
-                                s0[e] += mask_load1<T>(p.ex.mask_kind, mb_, (int64_t)(qq < L ? qq : L - 1) * p.ex.m_sl, kr, p.ex.inv_scale); \
-                            }                                                                      \
+                        } else {   /* one term per key (loaded where the item's query head changed) */ \
+                            _Pragma("unroll") for (int e = 0; e < 16; ++e) s0[e] += kterm;         \
                         }                                                                          \
                     }                                                                              \
                 }                                                                                  \

@@ -1,5 +1,6 @@
 """Forward / backward time of the mask / bias / dropout kernels (fa_fwd_ex / fa_bwd_ex) against the plain kernels on one shape.
-    python scripts/bench_extra.py [B H L D]"""
+    python scripts/bench_extra.py [B H L D] [--only SUBSTRING] [--ours]
+--only keeps the cases whose name contains SUBSTRING; --ours leaves stock SDPA out (for a kernel trace of this repo's launches alone)."""
 import pathlib
 import sys
 
@@ -10,7 +11,11 @@ import torch.nn.functional as F  # noqa: E402
 import flash_attention_amd.auto  # noqa: F401,E402
 from flash_attention_amd._impl import ops  # noqa: E402
 
-B, H, L, D = (int(x) for x in sys.argv[1:5]) if len(sys.argv) >= 5 else (8, 16, 4096, 64)
+ARGS = sys.argv[1:]
+ONLY = ARGS[ARGS.index("--only") + 1] if "--only" in ARGS else None
+OURS = "--ours" in ARGS
+NUMS = [a for a in ARGS if a.isdigit()]
+B, H, L, D = (int(x) for x in NUMS[:4]) if len(NUMS) >= 4 else (8, 16, 4096, 64)
 dt = torch.bfloat16
 q, k, v = (torch.randn(B, H, L, D, device="cuda").to(dt) for _ in range(3))
 g = torch.randn(B, H, L, D, device="cuda").to(dt)
@@ -52,16 +57,18 @@ if full is not None:
 print(f"B={B} H={H} L={L} D={D} bf16; ms per call, this repo's override | stock torch SDPA")
 flops_c, flops_n = 2.0 * B * H * L * L * D, 4.0 * B * H * L * L * D
 for name, kw in cases:
+    if ONLY is not None and ONLY not in name:
+        continue
     fl = flops_c if kw.get("is_causal") else flops_n
     with torch.no_grad():
         a = timeit(lambda: F.scaled_dot_product_attention(q, k, v, **kw))
         try:
-            b = timeit(lambda: stock(q, k, v, **kw))
+            b = float("nan") if OURS else timeit(lambda: stock(q, k, v, **kw))
         except Exception as e:  # noqa: BLE001
             b = float("nan")
     a2 = timeit(fwd_bwd(lambda x, y, z: F.scaled_dot_product_attention(x, y, z, **kw)), 5)
     try:
-        b2 = timeit(fwd_bwd(lambda x, y, z: stock(x, y, z, **kw)), 5)
+        b2 = float("nan") if OURS else timeit(fwd_bwd(lambda x, y, z: stock(x, y, z, **kw)), 5)
     except Exception as e:  # noqa: BLE001
         b2 = float("nan")
     print(f"  {name:38s} fwd {a:7.3f} ({fl / a / 1e9:6.0f} TFLOP/s) | {b:7.3f}    fwd+bwd {a2:7.3f} | {b2:7.3f}")
