@@ -7,10 +7,10 @@
 
 namespace fa {
 
-// MODE 1: mask terms loaded in place; MODE 2: a mask that differs from row to row ([.., L, L]: every element is touched once, nothing
-// of it is in a cache) has its raw data requested one tile ahead (fa_bwd_kernels.hip; bias [1, H, L, L] at B = 8, H = 16, L = 4096:
-// forward + backward 11.2 -> 7.6 ms) - at the price of 8 / 32 more registers, which a key-padding row or a dropout-only launch
-// would pay for nothing (measured: +30 % on those when every launch prefetched).
+// MODE 1: dropout alone, or a row-broadcast mask (row stride 0: key padding, a per-key bias) - its terms depend on the key alone;
+// MODE 2 | 3: a boolean mask | a bias that differs from row to row ([.., L, L]): its tiles travel to LDS by DMA with the operand tiles
+// (fa_bwd_kernels.hip).  B = 8, H = 16, L = 4096, D = 64, forward + backward: bias [1, H, L, L] 9.2 -> 4.8 ms, boolean [B, H, L, L]
+// 7.9 -> 4.4 ms, key padding 5.2 -> 3.1 ms against the in-place loads of the rounds before (profiles/r05_mask).
 template <typename T, int D, int MODE>
 __global__ __launch_bounds__(256) void fa_bwd_dq_extra_kernel(const BwdParams p) {
     fa_bwd_dq_body<T, D, 4, MODE>(p);
@@ -28,7 +28,8 @@ static hipError_t launch_bwd_extra_m(const BwdParams& p, hipStream_t stream) {
 }
 template <typename T, int D>
 static hipError_t launch_bwd_extra_t(const BwdParams& p, hipStream_t stream) {
-    return (p.ex.mask != nullptr && p.ex.m_sl != 0) ? launch_bwd_extra_m<T, D, 2>(p, stream) : launch_bwd_extra_m<T, D, 1>(p, stream);
+    if (p.ex.mask == nullptr || p.ex.m_sl == 0) return launch_bwd_extra_m<T, D, 1>(p, stream);
+    return p.ex.mask_kind == 2 ? launch_bwd_extra_m<T, D, 3>(p, stream) : launch_bwd_extra_m<T, D, 2>(p, stream);
 }
 
 hipError_t launch_bwd_extra(const BwdParams& p, int dtype, hipStream_t stream) {

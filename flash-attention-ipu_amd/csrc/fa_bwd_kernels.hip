@@ -99,8 +99,14 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     typedef T vec4 __attribute__((ext_vector_type(4)));
     constexpr int BQ = NWAVES * 32, BK = 64, KS = GM::KS, DT = GM::DT, IMG_B = GM::IMG_B, PPW = GM::PPW, NB = GM::NB;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NB * IMG_B];   // K0 .. K(NB-1)  V0 .. V(NB-1)
+    // K0 .. K(NB-1)  V0 .. V(NB-1); EXTRA == 2 | 3: plus per buffer the tile's mask image (128 rows x 64 keys: 8 KB of boolean bytes, 16 KB of bias)
+    constexpr int MIMG_B = EXTRA == 3 ? 16384 : 8192, MOFF = 2 * NB * IMG_B;
+    // (EXTRA == 1: per buffer the 64 per-key terms of a row-broadcast mask, fp32, and the tile's "every key masked" flag)
+    constexpr int MT_F = 80;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MOFF + (EXTRA >= 2 ? NB * MIMG_B : EXTRA == 1 ? NB * MT_F * 4 : 0)];
     unsigned char* const smem_v = smem + NB * IMG_B;
+    float* const mterm = (float*)(smem + MOFF);
+    (void)mterm;
 
     int g, qi;
     if (!bwd_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, p.xs_q, p.nq_real, g, qi)) return;
@@ -211,20 +217,64 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
-    // EXTRA: the raw mask data of a 32-key half are requested ONE TILE AHEAD, into the registers the same half of the current tile has
-    // just decoded (a mask row is global memory nobody else has touched: requested when its scores exist, its latency sits between
-    // the score MFMAs and the exponentials of every half tile).  Aligned full tiles only; anything else is loaded in place.
+    // EXTRA == 2 | 3 (a boolean mask | a bias that differs from row to row; the kind is a template argument: decided per element at run
+    // time it costs a branch and a copy of the score tile per four keys): every lane walks its own mask row, so a 4- or 8-byte load per lane touches 32
+    // cache lines per instruction, eight instructions per tile and wave.  The tile's mask image (the workgroup's 128 rows x 64 keys)
+    // travels to LDS with the K and V images instead: LDS-DMA, 16 bytes per lane, whole rows (2 / 4 instructions per wave and tile, one
+    // tile ahead); a lane then reads its 4 keys of a (half, j) with one ds_read_b32 / _b64.  16-byte chunk c of row i sits at chunk
+    // position c ^ (i >> 2 & 3) (bias: c ^ (i >> 1 & 7)): the 32 rows of a wave read the same chunk, which a row-major image keeps on
+    // 4 (2) bank groups.  Needs ExtraParams::mask_vec bit 1; any other mask is loaded in place.
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 mq[EXTRA == 2 ? 8 : 1];
-    (void)mq;
-#define FA_DQ_MASK_PF(T_, HB_)                                                                     \
-    if constexpr (EXTRA == 2) {                                                                    \
-        if (mrow != nullptr && p.ex.mask_vec != 0 && (T_) < n_tiles && (T_) * BK + BK <= L) {      \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
-                const int k0_ = (T_) * BK + 32 * (HB_) + 8 * j + 4 * h;                            \
-                if (p.ex.mask_kind == 2) mq[4 * (HB_) + j] = *(const u32x2*)(mrow + (int64_t)k0_ * 2); \
-                else mq[4 * (HB_) + j].x = *(const unsigned*)(mrow + k0_);                         \
-            }                                                                                      \
+    constexpr bool mbias = EXTRA == 3;
+    const bool mdma = EXTRA >= 2 && p.ex.mask != nullptr && (p.ex.mask_vec & 2) != 0;
+    unsigned m_vo[EXTRA >= 2 ? 4 : 1];
+    int m_rd = 0;
+    (void)mbias; (void)mdma; (void)m_vo; (void)m_rd;
+    if constexpr (EXTRA >= 2) {
+        const unsigned m_slb = (unsigned)p.ex.m_sl * (unsigned)mask_esz;
+        const int rl_ = L - 1 - qi * BQ;                   // (rows past L: the last row again - they are never stored)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pc = wave + 4 * j;
+            const int row = mbias ? 8 * pc + (lane >> 3) : 16 * pc + (lane >> 2);
+            const int cpos = mbias ? (lane & 7) : (lane & 3);
+            m_vo[j] = (unsigned)(row < rl_ ? row : rl_) * m_slb + ((unsigned)(cpos ^ (mbias ? (row >> 1) & 7 : (row >> 2) & 3)) << 4);
+        }
+        const int il = wave * 32 + r;
+        m_rd = mbias ? il * 128 + (((il >> 1) & 7) << 4) + 8 * h : il * 64 + (((il >> 2) & 3) << 4) + 4 * h;
+    }
+    // EXTRA == 1 with a mask - a row-broadcast one (row stride 0: fa_bwd_extra.hip sends every other mask to EXTRA == 2 | 3): the term of
+    // a score depends on its key alone.  Threads 0..63 fetch and decode the 64 terms of a tile one tile ahead (requested BEFORE that
+    // tile's DMA - vmcnt retires in order - and written to LDS at the end of the tile during which they arrived); the tile body adds
+    // them with four broadcast ds_read_b128 per half: no decoding and no mask-kind branch per element.  A tile whose 64 keys are
+    // all masked (a padded tail) is skipped by the whole workgroup: its P is 0.
+    float mt_stage = 0.f;
+    const bool mbc = EXTRA == 1 && p.ex.mask != nullptr;
+    (void)mt_stage; (void)mbc;
+#define FA_MTERM_LOAD(T_)                                                                          \
+    if constexpr (EXTRA == 1) {                                                                    \
+        if (mbc && tid < 64) {                                                                     \
+            const int k_ = (T_) * BK + tid;                                                        \
+            mt_stage = mask_load1<T>(p.ex.mask_kind, mrow, 0, k_ < L ? k_ : L - 1, p.ex.inv_scale); \
+        }                                                                                          \
+    }
+#define FA_MTERM_STORE(BUF_)                                                                       \
+    if constexpr (EXTRA == 1) {                                                                    \
+        if (mbc && tid < 64) {                                                                     \
+            mterm[(BUF_) * MT_F + tid] = mt_stage;                                                 \
+            const bool dead_ = __builtin_amdgcn_ballot_w64(mt_stage != -INFINITY) == 0;            \
+            if (tid == 0) mterm[(BUF_) * MT_F + 64] = dead_ ? 1.f : 0.f;                           \
+        }                                                                                          \
+    }
+#define FA_DMA_MASK(T_, BUF_)                                                                      \
+    if constexpr (EXTRA >= 2) {                                                                    \
+        if (mdma) {                                                                                \
+            const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh + (int64_t)(qi * BQ) * p.ex.m_sl + (T_) * BK) * mask_esz; \
+            const int64_t left_ = ((int64_t)(L - 1 - qi * BQ) * p.ex.m_sl + (L - (T_) * BK)) * mask_esz;   /* to the end of the slice's last row */ \
+            i32x4 mr_ = make_raw_rsrc(mb_, left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu);   \
+            _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   /* (64-bit products leave the scalar unit) */ \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+                if (mbias || j < 2) lds_dma_b128(mr_, smem_lds + MOFF + (BUF_) * MIMG_B + (wave + 4 * j) * 1024, m_vo[j]); \
         }                                                                                          \
     }
 
@@ -238,7 +288,11 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 #define FA_DQ_TILE(T_, BUF_)                                                                       \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
-        if (wave_active && kv0 <= wave_kv_last) {                                                  \
+        bool live_ = wave_active && kv0 <= wave_kv_last;                                           \
+        if constexpr (EXTRA == 1) {                                                                \
+            if (mbc && __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mterm[(BUF_) * MT_F + 64])) != 0) live_ = false; \
+        }                                                                                          \
+        if (live_) {                                                                               \
             const unsigned char* kb_ = smem + (BUF_) * IMG_B;                                      \
             const unsigned char* vb_ = smem_v + (BUF_) * IMG_B;                                    \
             _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {        /* keys kv0 + 32 hb .. +31 */ \
@@ -252,15 +306,23 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
                 }                                                                                  \
                 if constexpr (EXTRA) {                                                             \
                     if (mrow != nullptr) {                                                         \
-                        const bool fast_ = p.ex.mask_vec != 0 && kv0 + BK <= L;                    \
-                        if (EXTRA == 2 && fast_) {   /* requested one tile ago */                  \
+                        const bool fast_ = (p.ex.mask_vec & 1) != 0 && kv0 + BK <= L;              \
+                        if (EXTRA == 1) {           /* the tile's per-key terms, staged one tile ago */ \
+                            typedef float f32x4_ __attribute__((ext_vector_type(4)));              \
+                            const float* mt_ = mterm + (BUF_) * MT_F + 32 * hb + 4 * h;            \
                             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                        \
-                                if (p.ex.mask_kind == 2) {                                         \
-                                    const vec4 b_ = __builtin_bit_cast(vec4, mq[4 * hb + j]);      \
+                                const f32x4_ a_ = *(const f32x4_*)(mt_ + 8 * j);                   \
+                                _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += a_[i]; \
+                            }                                                                      \
+                        } else if (EXTRA >= 2 && mdma) {   /* this lane's row of the tile image */ \
+                            const unsigned char* mi_ = smem + MOFF + (BUF_) * MIMG_B;              \
+                            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                        \
+                                if (mbias) {                                                       \
+                                    const vec4 b_ = __builtin_bit_cast(vec4, *(const u32x2*)(mi_ + (m_rd ^ ((4 * hb + j) << 4)))); \
                                     _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += bias_term((float)b_[i], p.ex.inv_scale); \
                                 } else {                                                           \
-                                    const unsigned w_ = mq[4 * hb + j].x;                          \
-                                    _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += ((w_ >> (8 * i)) & 0xffu) ? 0.f : -INFINITY; \
+                                    const unsigned w_ = *(const unsigned*)(mi_ + (m_rd ^ ((2 * hb + (j >> 1)) << 4)) + 8 * (j & 1)); \
+                                    _Pragma("unroll") for (int i = 0; i < 4; ++i) if (((w_ >> (8 * i)) & 0xffu) == 0) s0[4 * j + i] = -INFINITY; \
                                 }                                                                  \
                             }                                                                      \
                         } else {                                                                   \
@@ -270,7 +332,6 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
                                 _Pragma("unroll") for (int i = 0; i < 4; ++i) s0[4 * j + i] += a_[i]; \
                             }                                                                      \
                         }                                                                          \
-                        FA_DQ_MASK_PF((T_) + 1, hb)                                                \
                     }                                                                              \
                 }                                                                                  \
                 if (kv0 + 32 * hb + 31 > wave_last) {                                              \
@@ -364,8 +425,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 
     // ring of NB buffers: tile t lives in buffer t % NB; at the top of tile t the DMA for tile t + NB - 1 goes out (its buffer
     // was released by the barrier that ended tile t - 1); at the end of tile t only that newest DMA may still be in flight
-    fa_static_for<0, NB - 1>([&](auto bi_) { constexpr int b_ = decltype(bi_)::value; if (b_ < n_tiles) FA_DMA_KV(b_, b_) });
-    if (wave_active) { FA_DQ_MASK_PF(0, 0) FA_DQ_MASK_PF(0, 1) }
+    fa_static_for<0, NB - 1>([&](auto bi_) { constexpr int b_ = decltype(bi_)::value; if (b_ < n_tiles) { FA_MTERM_LOAD(b_) FA_DMA_KV(b_, b_) FA_DMA_MASK(b_, b_) FA_MTERM_STORE(b_) } });
     FA_TILE_BARRIER()
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));   // row operands landed
@@ -376,8 +436,9 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             const int t = t0 + k_;
             if (t < n_tiles) {                                   // (workgroup-uniform)
                 const bool more = t + NB - 1 < n_tiles;
-                if (more) FA_DMA_KV(t + NB - 1, (k_ + NB - 1) % NB)
+                if (more) { FA_MTERM_LOAD(t + NB - 1) FA_DMA_KV(t + NB - 1, (k_ + NB - 1) % NB) FA_DMA_MASK(t + NB - 1, (k_ + NB - 1) % NB) }
                 FA_DQ_TILE(t, k_)
+                if (more) FA_MTERM_STORE((k_ + NB - 1) % NB)
                 if (more && NB > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NB - 2)) : "memory");
                 else lds_dma_wait_all();
                 __syncthreads();
@@ -387,7 +448,9 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 #undef FA_DMA_KV
 #undef FA_TILE_BARRIER
 #undef FA_DQ_TILE
-#undef FA_DQ_MASK_PF
+#undef FA_DMA_MASK
+#undef FA_MTERM_LOAD
+#undef FA_MTERM_STORE
 
     if (!wave_active || qrow >= L) return;
     T* __restrict__ og = (T*)p.dq + (int64_t)bb * p.dq_sb + (int64_t)hh * p.dq_sh + (int64_t)qrow * p.dq_sl;
@@ -423,7 +486,9 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     constexpr int BKW = NWAVES * 32, BQ = 64, KS = GM::KS, DT = GM::DT, IMG_B = GM::IMG_B, PPW = GM::PPW, NB = GM::NB;
 
     // Q0 .. Q(NB-1), dO0 .. dO(NB-1) images, then per-buffer row constants: lse2[64], dsum[64]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NB * IMG_B + NB * 512];
+    // (EXTRA == 2 | 3: plus per buffer the item's mask tile, 64 rows x the workgroup's 128 keys: 8 KB of boolean bytes or 16 KB of bias)
+    constexpr int MIMG_B = EXTRA == 3 ? 16384 : 8192, MOFF = 2 * NB * IMG_B + NB * 512;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MOFF + (EXTRA >= 2 ? NB * MIMG_B : 0)];
     unsigned char* const smem_g = smem + NB * IMG_B;
     float* const rowc = (float*)(smem + 2 * NB * IMG_B);  // [buf][ lse2 0..63 | dsum 0..63 ]
 
@@ -538,29 +603,55 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
     float rc_stage = 0.f;
-    // EXTRA: the raw mask elements of a 32-row half of the NEXT item (this lane's key, the 16 query rows its registers hold) are
-    // requested one item ahead, into the registers the same half of the current item has just decoded (see the dQ kernel)
-    unsigned mkv[EXTRA == 2 ? 32 : 1];
-    (void)mkv;
-    // EXTRA == 1 with a mask: a row-broadcast one (row stride 0: fa_bwd_extra.hip sends every other mask to EXTRA == 2), so the term of a
+    // EXTRA == 2 | 3 (a boolean mask | a bias that differs from row to row): a key-on-the-lane kernel reads the mask down its COLUMNS - from global memory that
+    // is one byte (or one bf16) per lane and row, 32 gather instructions per item and wave on a texture path four waves share (measured:
+    // 5.7 ms against 0.8 ms for the unmasked kernel).  So the item's mask tile travels to LDS the way its Q and dO images do: LDS-DMA,
+    // 16 bytes per lane, one item ahead, rows whole (2 / 4 instructions per wave and item); the lanes then read their column with
+    // ds_read_u8 / _u16.  16-byte chunk c of row i sits at chunk position c ^ 4 [i & 4] (bias: c ^ 8 [i & 4]): the two half-waves of one
+    // read hold rows i and i + 4, which a plain row-major image would put on the same banks.  Needs mask_vec (pointer and strides multiples
+    // of four elements); any other mask is loaded in place, element by element.
+    constexpr bool mbias = EXTRA == 3;
+    const bool mdma = EXTRA >= 2 && p.ex.mask != nullptr && (p.ex.mask_vec & 2) != 0;
+    const unsigned m_slb = (unsigned)p.ex.m_sl * (unsigned)mask_esz;
+    int m_row[EXTRA >= 2 ? 4 : 1];
+    unsigned m_col[EXTRA >= 2 ? 4 : 1];
+    int m_rd = 0;
+    (void)mbias; (void)mdma; (void)m_slb; (void)m_row; (void)m_col; (void)m_rd;
+    if constexpr (EXTRA >= 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pc = wave + 4 * j;
+            const int row = mbias ? 4 * pc + (lane >> 4) : 8 * pc + (lane >> 3);
+            const int cpos = mbias ? (lane & 15) : (lane & 7);
+            m_row[j] = row;
+            m_col[j] = (unsigned)(cpos ^ (((row >> 2) & 1) * (mbias ? 8 : 4))) << 4;
+        }
+        m_rd = mbias ? 4 * h * 256 + (((4 * wave + (r >> 3)) ^ (8 * h)) << 4) + (r & 7) * 2
+                     : 4 * h * 128 + (((2 * wave + (r >> 4)) ^ (4 * h)) << 4) + (r & 15);
+    }
+#define FA_DMA_MASK(J_, BUF_)                                                                      \
+    if constexpr (EXTRA >= 2) {                                                                    \
+        if (mdma) {                                                                                \
+            FA_ITEM(J_, hqm_, itm_)                                                                \
+            const int q0m_ = itm_ * BQ, rl_ = L - 1 - q0m_;                                        \
+            const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqm_) * p.ex.m_sh + (int64_t)q0m_ * p.ex.m_sl + kb * BKW) * mask_esz; \
+            const int64_t left_ = ((int64_t)rl_ * p.ex.m_sl + (L - kb * BKW)) * mask_esz;   /* to the end of the slice's last row */ \
+            i32x4 mr_ = make_raw_rsrc(mb_, left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu);   \
+            _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   /* (64-bit products leave the scalar unit) */ \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+                if (mbias || j < 2) {   /* (rows past L: the last row again - their P is 0) */     \
+                    const int rw_ = m_row[j] < rl_ ? m_row[j] : rl_;                               \
+                    lds_dma_b128(mr_, smem_lds + MOFF + (BUF_) * MIMG_B + (wave + 4 * j) * 1024, (unsigned)rw_ * m_slb + m_col[j]); \
+                }                                                                                  \
+        }                                                                                          \
+    }
+    // EXTRA == 1 with a mask: a row-broadcast one (row stride 0: fa_bwd_extra.hip sends every other mask to EXTRA == 2 | 3), so the term of a
     // score depends on its key alone - one load per lane and query head, not one per element; a wave whose 32 keys are all masked for
     // that head (a padded tail) skips the head's tiles: its P is 0, its dK / dV contribution exactly the zeros already there
     float kterm = 0.f;
     int kterm_hq = -1;
     bool kskip = false;
     (void)kterm; (void)kterm_hq; (void)kskip;
-#define FA_KV_MASK_PF(J_, HB_)                                                                     \
-    if constexpr (EXTRA == 2) {                                                                    \
-        if (p.ex.mask != nullptr && wave_active && (J_) < n_items) {                               \
-            FA_ITEM(J_, hqp_, itp_)                                                                \
-            const char* mbp_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqp_) * p.ex.m_sh) * mask_esz; \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                       \
-                const int qq_ = itp_ * BQ + 32 * (HB_) + (e & 3) + 8 * (e >> 2) + 4 * h;           \
-                const int64_t off_ = (int64_t)(qq_ < L ? qq_ : L - 1) * p.ex.m_sl + kr;            \
-                mkv[16 * (HB_) + e] = p.ex.mask_kind == 2 ? (unsigned)((const unsigned short*)mbp_)[off_] : (unsigned)((const unsigned char*)mbp_)[off_]; \
-            }                                                                                      \
-        }                                                                                          \
-    }
 
 #if FA_BWD_HALVES
 #define FA_DKDV_TILE(J_, BUF_)                                                                     \
@@ -581,7 +672,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
             const float* rc_ = rowc + (BUF_) * 128;                                                \
             _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {       /* query rows q0 + 32 hb .. +31 */ \
-                if (causal && q0 + 32 * hb + 31 < key0) { FA_KV_MASK_PF((J_) + 1, hb) continue; }   /* every query of this half lies before the wave's keys */ \
+                if (causal && q0 + 32 * hb + 31 < key0) continue;   /* every query of this half lies before the wave's keys */ \
                 f32x16 s0, t0;                                                                     \
                 /* dP accumulators start at -Dsum[q] (rowc holds the negated sums) */              \
                 _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                 \
@@ -594,13 +685,23 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 }                                                                                  \
                 if constexpr (EXTRA) {                                                             \
                     if (p.ex.mask != nullptr) {   /* mask[row][this lane's key], one row per register */ \
-                        if constexpr (EXTRA == 2) {   /* requested one item ago */                 \
-                            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                       \
-                                const unsigned w_ = mkv[16 * hb + e];                              \
-                                if (p.ex.mask_kind == 2) s0[e] += bias_term((float)__builtin_bit_cast(T, (unsigned short)w_), p.ex.inv_scale); \
-                                else s0[e] += w_ ? 0.f : -INFINITY;                                \
+                        if constexpr (EXTRA >= 2) {                                                \
+                            if (mdma) {   /* this lane's column of the tile image */               \
+                                const unsigned char* mi_ = smem + MOFF + (BUF_) * MIMG_B + m_rd;   \
+                                if (mbias) {                                                       \
+                                    _Pragma("unroll") for (int e = 0; e < 16; ++e)                 \
+                                        s0[e] += bias_term((float)*(const T*)(mi_ + (32 * hb + (e & 3) + 8 * (e >> 2)) * 256), p.ex.inv_scale); \
+                                } else {                                                           \
+                                    _Pragma("unroll") for (int e = 0; e < 16; ++e)                 \
+                                        s0[e] += mi_[(32 * hb + (e & 3) + 8 * (e >> 2)) * 128] ? 0.f : -INFINITY; \
+                                }                                                                  \
+                            } else {                                                               \
+                                const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqt_) * p.ex.m_sh) * mask_esz; \
+                                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                   \
+                                    const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;  \
+                                    s0[e] += mask_load1<T>(p.ex.mask_kind, mb_, (int64_t)(qq < L ? qq : L - 1) * p.ex.m_sl, kr, p.ex.inv_scale); \
+                                }                                                                  \
                             }                                                                      \
-                            FA_KV_MASK_PF((J_) + 1, hb)                                            \
                         } else {   /* one term per key (loaded where the item's query head changed) */ \
                             _Pragma("unroll") for (int e = 0; e < 16; ++e) s0[e] += kterm;         \
                         }                                                                          \
@@ -662,8 +763,6 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                     }                                                                              \
                 }                                                                                  \
             }                                                                                      \
-        } else {                                                                                   \
-            FA_KV_MASK_PF((J_) + 1, 0) FA_KV_MASK_PF((J_) + 1, 1)                                  \
         }                                                                                          \
     }
 #else
@@ -750,10 +849,10 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         if (b_ < n_items) {
             FA_ROWC_LOAD(b_)
             FA_DMA_QG(b_, b_)
+            FA_DMA_MASK(b_, b_)
             FA_ROWC_STORE(b_)
         }
     });
-    FA_KV_MASK_PF(0, 0) FA_KV_MASK_PF(0, 1)
     lds_dma_wait_all();
     __syncthreads();
 #pragma unroll
@@ -768,6 +867,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 if (more) {
                     FA_ROWC_LOAD(j + NB - 1)
                     FA_DMA_QG(j + NB - 1, (k_ + NB - 1) % NB)
+                    FA_DMA_MASK(j + NB - 1, (k_ + NB - 1) % NB)
                 }
                 FA_DKDV_TILE(j, k_)
                 if (more) FA_ROWC_STORE((k_ + NB - 1) % NB)
@@ -782,7 +882,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #undef FA_ROWC_LOAD
 #undef FA_ROWC_STORE
 #undef FA_DKDV_TILE
-#undef FA_KV_MASK_PF
+#undef FA_DMA_MASK
 
     if (!wave_active || key >= L) return;
     T* __restrict__ dkg = (T*)p.dk + (int64_t)bb * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)key * p.dk_sl;

@@ -583,7 +583,9 @@ int make_extra(const void* mask, int32_t mask_kind, const int64_t* mask_strides,
         ex->mask = mask;
         ex->mask_kind = mask_kind;
         ex->m_sb = mask_strides[0]; ex->m_sh = mask_strides[1]; ex->m_sl = mask_strides[2];
-        ex->mask_vec = vec ? 1 : 0;
+        // bit 1: whole mask tiles may travel to LDS by DMA (the per-row masks of the backward: fa_bwd_kernels.hip) - 128 rows of byte offsets
+        // must fit the 32-bit lane offset of a buffer load
+        ex->mask_vec = vec ? (mask_strides[2] * esz < (1ll << 24) ? 3 : 1) : 0;
     }
     if (!(dropout_p >= 0.0f) || !(dropout_p < 1.0f)) return fail(FA_ERR_BAD_DROPOUT, "dropout_p must be in [0, 1) (got %g)", (double)dropout_p);
     if (dropout_p > 0.0f) {

@@ -53,9 +53,10 @@ __device__ __forceinline__ int k_swizzle(int row) {
 //
 // EXTRA: attention mask / additive bias and dropout (fa_extras.h), exact-max arithmetic only (a mask can hide every key of a
 // tile from a row, so the fixed reference max of the skip-max mode has nothing to stand on); instantiated in fa_fwd_extra.hip.
-// MPRE (EXTRA only): a mask that differs from row to row has the raw data of the NEXT tile requested one tile ahead (16 more registers,
-// which a key-padding row - cache-resident - or a dropout-only launch would pay for nothing: measured +6 % on those).
-template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT, bool PAIR, bool EXTRA = false, bool MPRE = false>
+// MM (EXTRA only) - how a mask reaches the scores: 0 = none (dropout alone) or a row-broadcast mask (row stride 0: its 64 per-key terms of
+// a tile are decoded by 64 threads one tile ahead and staged through LDS); 2 | 3 = a boolean mask | a bias that differs from row to row:
+// the tile's mask image (128 rows x 64 keys) travels to LDS by DMA with the K / V tile.
+template <typename T, int D, int NWAVES, bool SKIP, int QB, int SPLIT, bool PAIR, bool EXTRA = false, int MM = 0>
 __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     static_assert(!EXTRA || !SKIP, "mask / dropout launches use the exact-max arithmetic");
     using E = Elt<T>;
@@ -134,13 +135,68 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const int mask_esz = p.ex.mask_kind == 2 ? (int)sizeof(T) : 1;
     const char* const mask_g = EXTRA && p.ex.mask ? (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh) * mask_esz : nullptr;
     const unsigned drop_kg = EXTRA ? drop_group_key(drop_key0_of(p.ex), (unsigned)g) : 0u;
-    // EXTRA: the raw mask data of the NEXT tile is requested as soon as this tile's has been decoded into the scores (one register set):
-    // a mask row is global memory nobody else has touched - its latency then runs under this tile's softmax and PV product, the barrier
-    // and the next tile's QK^T instead of sitting between QK^T and the softmax
+    // EXTRA, MM 2 | 3 (a mask that differs from row to row): every lane walks its own mask row, so a 4- or 8-byte load per lane touches 32
+    // cache lines per instruction, eight instructions per tile and wave.  The tile's mask image travels to LDS with the K and V tiles
+    // instead: LDS-DMA, 16 bytes per lane, whole rows (2 / 4 instructions per wave and tile, one tile ahead); a lane then reads the 4
+    // keys of a (half, j) with one ds_read_b32 / _b64.  16-byte chunk c of row i sits at chunk position c ^ (i >> 2 & 3) (bias:
+    // c ^ (i >> 1 & 7)): the 32 rows of a wave read the same chunk, which a row-major image keeps on 4 (2) bank groups.  Needs
+    // ExtraParams::mask_vec bit 1; any other mask is loaded in place.  The mask kind is a template argument: decided per element
+    // at run time it costs a branch and a copy of the score tile per four keys.
+    // MM 0 with a mask - a row-broadcast one (fa_fwd_extra.hip sends every other mask to MM 2 | 3): threads 0..63 fetch and decode the 64
+    // per-key terms of a tile one tile ahead (requested BEFORE that tile's DMA - vmcnt retires in order - and written to LDS before the
+    // barrier that publishes the tile); the tile body adds them with broadcast ds_read_b128.  A tile whose 64 keys are all masked (a
+    // padded tail) is skipped by the whole workgroup.
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 mraw[(EXTRA && MPRE) ? 8 : 1];
-    bool mpre_ok = false;
-    (void)mraw; (void)mpre_ok;
+    constexpr int MIMG_B = MM == 3 ? 16384 : 8192, MT_F = 80;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_mk[EXTRA ? (MM >= 2 ? 2 * MIMG_B : 2 * MT_F * 4) : 16];
+    float* const mterm = (float*)smem_mk;
+    constexpr bool mbias = MM == 3;
+    const bool mdma = EXTRA && MM >= 2 && mask_g != nullptr && (p.ex.mask_vec & 2) != 0;
+    const bool mbc = EXTRA && MM == 0 && mask_g != nullptr;
+    static_assert(!EXTRA || (QB == 1 && SPLIT == 1 && NWAVES == 4), "mask staging: one 32-row block per wave, unsplit 4-wave workgroups");
+    unsigned m_vo[(EXTRA && MM >= 2) ? 4 : 1];
+    int m_rd = 0;
+    float mt_stage = 0.f;
+    (void)mterm; (void)mdma; (void)mbc; (void)m_vo; (void)m_rd; (void)mt_stage;
+#define FA_MASK_GEOM(QI_)                                                                          \
+    if constexpr (EXTRA && MM >= 2) {                                                              \
+        const unsigned m_slb_ = (unsigned)p.ex.m_sl * (unsigned)mask_esz;                          \
+        const int rl_ = L - 1 - (QI_) * BQ;          /* (rows past L: the last row again - they are never stored) */ \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+            const int pc = wave + 4 * j;                                                           \
+            const int row = mbias ? 8 * pc + (lane >> 3) : 16 * pc + (lane >> 2);                  \
+            const int cpos = mbias ? (lane & 7) : (lane & 3);                                      \
+            m_vo[j] = (unsigned)(row < rl_ ? row : rl_) * m_slb_ + ((unsigned)(cpos ^ (mbias ? (row >> 1) & 7 : (row >> 2) & 3)) << 4); \
+        }                                                                                          \
+        const int il = wave * 32 + r;                                                              \
+        m_rd = mbias ? il * 128 + (((il >> 1) & 7) << 4) + 8 * h : il * 64 + (((il >> 2) & 3) << 4) + 4 * h; \
+    }
+#define FA_DMA_MASKTILE(QI_, T_, BUF_)                                                             \
+    if constexpr (EXTRA && MM >= 2) {                                                              \
+        if (mdma) {                                                                                \
+            const char* mb_ = mask_g + ((int64_t)((QI_) * BQ) * p.ex.m_sl + (T_) * BK) * mask_esz; \
+            const int64_t left_ = ((int64_t)(L - 1 - (QI_) * BQ) * p.ex.m_sl + (L - (T_) * BK)) * mask_esz;   /* to the end of the slice's last row */ \
+            i32x4 mr_ = make_raw_rsrc(mb_, left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu);   \
+            _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   /* (64-bit products leave the scalar unit) */ \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
+                if (mbias || j < 2) lds_dma_b128(mr_, lds_offset(smem_mk) + (BUF_) * MIMG_B + (wave + 4 * j) * 1024, m_vo[j]); \
+        }                                                                                          \
+    }
+#define FA_MTERM_LOAD(T_)                                                                          \
+    if constexpr (EXTRA && MM == 0) {                                                              \
+        if (mbc && tid < 64) {                                                                     \
+            const int k_ = (T_) * BK + tid;                                                        \
+            mt_stage = mask_load1<T>(p.ex.mask_kind, mask_g, 0, k_ < L ? k_ : L - 1, p.ex.inv_scale); \
+        }                                                                                          \
+    }
+#define FA_MTERM_STORE(BUF_)                                                                       \
+    if constexpr (EXTRA && MM == 0) {                                                              \
+        if (mbc && tid < 64) {                                                                     \
+            mterm[(BUF_) * MT_F + tid] = mt_stage;                                                 \
+            const bool dead_ = __builtin_amdgcn_ballot_w64(mt_stage != -INFINITY) == 0;            \
+            if (tid == 0) mterm[(BUF_) * MT_F + 64] = dead_ ? 1.f : 0.f;                           \
+        }                                                                                          \
+    }
 
     // the operands' true head dim in 16-byte chunks (= D / 8 unless the call runs zero-extended: FwdParams::Dr)
     const int dchunks = p.Dr >> 3;
@@ -245,29 +301,6 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     //     than 2^RESCALE_THR) - unscaled f16, and the fallback pass of the fast mode.
     constexpr bool SKIPMAX = FA_DMA_SKIPMAX && SKIP;
 
-    // EXTRA: request the raw mask data of tile T_ (aligned full tiles only; anything else is loaded in place when its scores exist)
-#define FA_MASK_PREFETCH(T_)                                                                 \
-    if constexpr (EXTRA && MPRE) {                                                                 \
-        if (mask_g != nullptr) {                                                                   \
-            const int kvp_ = (T_) * BK;                                                            \
-            const bool ok_ = p.ex.mask_vec != 0 && wave_active && (T_) < n_tiles && kvp_ + BK <= L && kvp_ <= wave_kv_last;   \
-            mpre_ok = ok_;                                                                   \
-            if (ok_) {                                                                             \
-                /* (rows past L are clamped duplicates: their P must stay finite - the row-sum MFMA multiplies them by 0) */ \
-                const char* mrow_ = mask_g + (int64_t)(qrow < L ? qrow : L - 1) * p.ex.m_sl * mask_esz; \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
-                    const int k0_ = kvp_ + 8 * j + 4 * h;                                          \
-                    if (p.ex.mask_kind == 2) {                                                     \
-                        mraw[j] = *(const u32x2*)(mrow_ + (int64_t)k0_ * 2);                 \
-                        mraw[4 + j] = *(const u32x2*)(mrow_ + (int64_t)(k0_ + 32) * 2);      \
-                    } else {                                                                       \
-                        mraw[j].x = *(const unsigned*)(mrow_ + k0_);                         \
-                        mraw[4 + j].x = *(const unsigned*)(mrow_ + k0_ + 32);                \
-                    }                                                                              \
-                }                                                                                  \
-            }                                                                                      \
-        }                                                                                          \
-    }
     // ---- the pieces of one kv tile (buffer index BUF_ is compile-time); same arithmetic as fa_fwd_tile_kernel
 #define FA_QK(BUF_)                                                                                \
     {                                                                                              \
@@ -283,24 +316,34 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             }                                                                                      \
         }                                                                                          \
         if constexpr (EXTRA) {                                                                     \
-            if (MPRE && mask_g != nullptr && mpre_ok) {   /* prefetched raw data of this tile (QB == 1) */ \
+            if (MM == 0 && mbc) {          /* the tile's per-key terms, staged one tile ago */     \
+                typedef float f32x4_ __attribute__((ext_vector_type(4)));                          \
+                const float* mt_ = mterm + (BUF_) * MT_F + 4 * h;                                  \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
-                    if (p.ex.mask_kind == 2) {                                                     \
-                        const vec4 b0_ = __builtin_bit_cast(vec4, mraw[j]), b1_ = __builtin_bit_cast(vec4, mraw[4 + j]); \
+                    const f32x4_ a0_ = *(const f32x4_*)(mt_ + 8 * j), a1_ = *(const f32x4_*)(mt_ + 32 + 8 * j); \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) { s0[0][4 * j + i] += a0_[i]; s1[0][4 * j + i] += a1_[i]; } \
+                }                                                                                  \
+            } else if (MM >= 2 && mdma) {   /* this lane's row of the tile image */                \
+                const unsigned char* mi_ = smem_mk + (BUF_) * MIMG_B;                              \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
+                    if (mbias) {                                                                   \
+                        const vec4 b0_ = __builtin_bit_cast(vec4, *(const u32x2*)(mi_ + (m_rd ^ (j << 4)))); \
+                        const vec4 b1_ = __builtin_bit_cast(vec4, *(const u32x2*)(mi_ + (m_rd ^ ((4 + j) << 4)))); \
                         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                            \
-                            s0[0][4 * j + i] += bias_term((float)b0_[i], p.ex.inv_scale);              \
-                            s1[0][4 * j + i] += bias_term((float)b1_[i], p.ex.inv_scale);              \
+                            s0[0][4 * j + i] += bias_term((float)b0_[i], p.ex.inv_scale);          \
+                            s1[0][4 * j + i] += bias_term((float)b1_[i], p.ex.inv_scale);          \
                         }                                                                          \
                     } else {                                                                       \
-                        const unsigned w0_ = mraw[j].x, w1_ = mraw[4 + j].x;           \
+                        const unsigned w0_ = *(const unsigned*)(mi_ + (m_rd ^ ((j >> 1) << 4)) + 8 * (j & 1)); \
+                        const unsigned w1_ = *(const unsigned*)(mi_ + (m_rd ^ ((2 + (j >> 1)) << 4)) + 8 * (j & 1)); \
                         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                            \
-                            s0[0][4 * j + i] += ((w0_ >> (8 * i)) & 0xffu) ? 0.f : -INFINITY;      \
-                            s1[0][4 * j + i] += ((w1_ >> (8 * i)) & 0xffu) ? 0.f : -INFINITY;      \
+                            if (((w0_ >> (8 * i)) & 0xffu) == 0) s0[0][4 * j + i] = -INFINITY;     \
+                            if (((w1_ >> (8 * i)) & 0xffu) == 0) s1[0][4 * j + i] = -INFINITY;     \
                         }                                                                          \
                     }                                                                              \
                 }                                                                                  \
             } else if (mask_g != nullptr) {   /* additive terms on the raw scores: bias / scale, or 0 | -inf */ \
-                const bool fast_ = p.ex.mask_vec != 0 && kv0 + BK <= L;                            \
+                const bool fast_ = (p.ex.mask_vec & 1) != 0 && kv0 + BK <= L;                      \
                 _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                   \
                     const int mr_ = qrow + 32 * b < L ? qrow + 32 * b : L - 1;                     \
                     const char* mrow_ = mask_g + (int64_t)mr_ * p.ex.m_sl * mask_esz;              \
@@ -397,12 +440,13 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
             }                                                                                      \
         }                                                                                          \
     }
+#define FA_TILE_DEAD(BUF_) (EXTRA && MM == 0 && mbc && __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mterm[(BUF_) * MT_F + 64])) != 0)
 #define FA_COMPUTE(T_, BUF_, MODE_)                                                                \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
-        if (wave_active && (SPLIT == 1 || (T_) < n_tiles) && kv0 <= wave_kv_last) {                \
+        if (wave_active && (SPLIT == 1 || (T_) < n_tiles) && kv0 <= wave_kv_last && !FA_TILE_DEAD(BUF_)) { \
             f32x16 s0[QB], s1[QB];                                                                 \
-            if (FA_DMA_ABL != 5) { FA_QK(BUF_) FA_MASK_PREFETCH((T_) + tstride) } else {                   \
+            if (FA_DMA_ABL != 5) { FA_QK(BUF_) } else {                                            \
                 _Pragma("unroll") for (int b = 0; b < QB; ++b)                                     \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) { s0[b][e] = o[b][0][e]; s1[b][e] = o[b][1][e]; } \
             }                                                                                      \
@@ -421,19 +465,20 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // one pass over the workgroup's kv tiles (the kv loop is unrolled by two: LDS addresses are base + immediate)
 #define FA_PASS(MODE_)                                                                             \
     {                                                                                              \
-        if (!tile0_requested && (SPLIT == 1 || tfirst < n_tiles)) FA_DMA_TILE(tfirst, 0)           \
+        if (!tile0_requested && (SPLIT == 1 || tfirst < n_tiles)) { FA_MTERM_LOAD(tfirst) FA_DMA_TILE(tfirst, 0) FA_DMA_MASKTILE(qi, tfirst, 0) FA_MTERM_STORE(0) } \
         tile0_requested = false;                                                                   \
-        FA_MASK_PREFETCH(tfirst)                                                                   \
         FA_TILE_BARRIER()                                                                          \
         if (pass == 0) FA_STAMP(st1_)                                                              \
         for (int rr = 0; rr < n_rounds; rr += 2) {              /* (workgroup-uniform bounds) */   \
             const int t = tfirst + rr * tstride;                /* this group's tile of the round */ \
-            if (t + tstride < n_tiles) FA_DMA_TILE(t + tstride, 1)                                 \
+            if (t + tstride < n_tiles) { FA_MTERM_LOAD(t + tstride) FA_DMA_TILE(t + tstride, 1) FA_DMA_MASKTILE(qi, t + tstride, 1) } \
             FA_COMPUTE(t, 0, MODE_)                                                                \
+            if (t + tstride < n_tiles) FA_MTERM_STORE(1)                                           \
             FA_TILE_BARRIER()                                                                      \
             if (rr + 1 < n_rounds) {                                                               \
-                if (t + 2 * tstride < n_tiles) FA_DMA_TILE(t + 2 * tstride, 0)                     \
+                if (t + 2 * tstride < n_tiles) { FA_MTERM_LOAD(t + 2 * tstride) FA_DMA_TILE(t + 2 * tstride, 0) FA_DMA_MASKTILE(qi, t + 2 * tstride, 0) } \
                 FA_COMPUTE(t + tstride, 1, MODE_)                                                  \
+                if (t + 2 * tstride < n_tiles) FA_MTERM_STORE(0)                                   \
                 FA_TILE_BARRIER()                                                                  \
             }                                                                                      \
         }                                                                                          \
@@ -455,6 +500,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     const int wave_last = causal ? q_row0 : L - 1;      // a tile reaching past this key carries a mask for the wave
     const int wave_kv_last = causal ? q_row0 + WQ - 1 : L - 1;   // tiles starting after it hold nothing for the wave
     FA_RESET_STATE()
+    FA_MASK_GEOM(qi)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -577,7 +623,11 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     }   // wave_active
     }   // pass
 #undef FA_DMA_TILE
-#undef FA_MASK_PREFETCH
+#undef FA_MASK_GEOM
+#undef FA_TILE_DEAD
+#undef FA_DMA_MASKTILE
+#undef FA_MTERM_LOAD
+#undef FA_MTERM_STORE
 #undef FA_TILE_BARRIER
 #undef FA_COMPUTE
 #undef FA_PASS

@@ -8,17 +8,18 @@
 
 namespace fa {
 
-// MPRE: the mask's raw data requested one tile ahead - for masks that differ from row to row (fa_fwd_dma.hip)
-template <typename T, int D, bool MPRE>
+// MM: how the mask reaches the scores (fa_fwd_dma.hip) - 0: none, or a row-broadcast one; 2 | 3: a boolean mask | a bias that differs from row to row
+template <typename T, int D, int MM>
 __global__ __launch_bounds__(256) void fa_fwd_extra_kernel(const FwdParams p) {
-    fa_fwd_dma_body<T, D, 4, false, 1, 1, false, true, MPRE>(p);
+    fa_fwd_dma_body<T, D, 4, false, 1, 1, false, true, MM>(p);
 }
 
 template <typename T, int D>
 static hipError_t launch_fwd_extra_t(const FwdParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles)), block(256);
-    return (p.ex.mask != nullptr && p.ex.m_sl != 0) ? launch1((const void*)(fa_fwd_extra_kernel<T, D, true>), grid, block, 0, stream, p)
-                                                    : launch1((const void*)(fa_fwd_extra_kernel<T, D, false>), grid, block, 0, stream, p);
+    if (p.ex.mask == nullptr || p.ex.m_sl == 0) return launch1((const void*)(fa_fwd_extra_kernel<T, D, 0>), grid, block, 0, stream, p);
+    return p.ex.mask_kind == 2 ? launch1((const void*)(fa_fwd_extra_kernel<T, D, 3>), grid, block, 0, stream, p)
+                               : launch1((const void*)(fa_fwd_extra_kernel<T, D, 2>), grid, block, 0, stream, p);
 }
 
 hipError_t launch_fwd_extra(const FwdParams& p, int dtype, hipStream_t stream) {

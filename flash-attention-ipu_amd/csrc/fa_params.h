@@ -12,7 +12,7 @@ struct ExtraParams {
     const void* mask;      // nullptr = none
     int64_t m_sb, m_sh, m_sl;   // mask strides in elements: batch (outer group), head (inner group), row; unit key stride
     int32_t mask_kind;     // 0 none, 1 boolean bytes (non-zero = keep), 2 additive bias in the operand dtype
-    int32_t mask_vec;      // 1 = four consecutive keys may be fetched with one aligned load
+    int32_t mask_vec;      // bit 0: four consecutive keys may be fetched with one aligned load; bit 1: and a row is shorter than 2^24 bytes (LDS-DMA of mask tiles)
     float inv_scale;       // 1 / softmax_scale (a bias is added to the RAW scores as bias / scale)
     uint32_t drop_key0;    // seed and offset folded (fa_capi.cpp); ignored when drop_state is set
     const unsigned long long* drop_state;   // device {seed, offset} (ABI 5: graph-safe dropout), nullptr = drop_key0 holds the folded immediates
