@@ -60,15 +60,22 @@ def _masks(kind, B, H, L, dtype, gen):
         return (0.7 * torch.randn(1, H, L, L, generator=gen)).to(dtype)
     if kind == "bias_row":           # [L] bias along the keys, broadcast over rows
         return torch.randn(L, generator=gen).to(dtype)
+    if kind == "bias_head_key":      # [H, 1, L]: a per-key bias that differs from head to head, each head with its own -inf tail
+        b = torch.randn(H, 1, L, generator=gen)
+        for hh in range(H):
+            b[hh, 0, L - min(L - 1, 70 * (hh + 1)):] = float("-inf")
+        return b.to(dtype)
     raise AssertionError(kind)
 
 
-@pytest.mark.parametrize("kind", ["bool_LL", "bool_padding", "bool_BHLL_dead_rows", "bias_BHLL", "bias_1HLL", "bias_row"])
+@pytest.mark.parametrize("kind", ["bool_LL", "bool_padding", "bool_BHLL_dead_rows", "bias_BHLL", "bias_1HLL", "bias_row", "bias_head_key"])
 @pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.float16, 128)])
-@pytest.mark.parametrize("B,H,Hkv,L", [(2, 3, 3, 200), (1, 4, 2, 256), (2, 2, 1, 333), (1, 2, 2, 1024)])
+@pytest.mark.parametrize("B,H,Hkv,L", [(2, 3, 3, 200), (1, 4, 2, 256), (2, 2, 1, 333), (1, 2, 2, 1024), (1, 2, 1, 2308)])
 def test_masked_forward_and_backward_vs_oracle(kind, dtype, D, B, H, Hkv, L):
-    """attn_mask through fa_fwd_ex / fa_bwd_ex: boolean and additive masks, every broadcast pattern, aligned (one vector load per
-    four keys) and unaligned (L = 200, 333: element loads) strides, grouped K/V heads, rows without any admitted key."""
+    """attn_mask through fa_fwd_ex / fa_bwd_ex: boolean and additive masks, every broadcast pattern, strides that are multiples of four
+    elements (mask tiles by LDS-DMA; L = 200, 2308: rows that are not 16-byte aligned) and strides that are not (L = 333: element loads),
+    grouped K/V heads (a per-head per-key bias under a shared K/V head), rows without any admitted key, key tiles without any
+    admitted key (padding tails), more key blocks and tiles than LDS buffers (L = 2308)."""
     from flash_attention_amd._impl import ops
     from oracle import dense_attention_extra, frozen_randn
 
@@ -94,6 +101,36 @@ def test_masked_forward_and_backward_vs_oracle(kind, dtype, D, B, H, Hkv, L):
     if "dead_rows" not in kind:          # (a dead row's P is 0 in the kernels and NaN in the dense formula: compare live masks only)
         for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
             _grad_close(got, want, f"{name} {kind} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
+
+
+@pytest.mark.parametrize("kind", ["bool", "bias"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_mask_that_is_a_strided_view_equals_its_contiguous_copy(kind, causal):
+    """The mask is passed by its strides (row stride > L, a batch stride of 0, a base that is only 4-element aligned): the kernels' DMA
+    descriptors and lane offsets must address the view, not a dense [L, L] - bit-identical outputs and gradients to the contiguous copy,
+    with and without the causal mask underneath."""
+    from flash_attention_amd._impl import ops
+
+    torch.manual_seed(5)
+    B, H, L, D = 2, 2, 520, 64
+    q, k, v = (torch.randn(B, H, L, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    g = torch.randn(B, H, L, D, device="cuda", dtype=torch.bfloat16)
+    if kind == "bool":
+        big = (torch.rand(1, H, L + 3, L + 24, device="cuda") < 0.8)
+        big[..., torch.arange(L) + 1, torch.arange(L) + 4] = True
+        big = big.view(torch.uint8)
+    else:
+        big = torch.randn(1, H, L + 3, L + 24, device="cuda", dtype=torch.bfloat16)
+    view = big[:, :, 1:1 + L, 4:4 + L].expand(B, H, L, L)
+    assert view.stride() == (0, (L + 3) * (L + 24), L + 24, 1)
+    res = []
+    for m in (view, view.contiguous()):
+        qc, kc, vc = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = ops.attention_extra(qc, kc, vc, m, D ** -0.5, causal)
+        out.backward(g)
+        res.append((out.detach(), qc.grad, kc.grad, vc.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("causal", [True, False])
