@@ -75,13 +75,29 @@ def emit_once(line) -> None:
             print(json.dumps(line), flush=True)
 
 
-def csrc_fingerprint() -> str:
-    """sha256 over the kernel sources: ties a profiled HBM-traffic figure to the code that was profiled."""
+def csrc_fingerprint(kernels=None) -> str:
+    """sha256 over kernel sources: ties a profiled HBM-traffic figure to the code that was profiled.  With `kernels` (the kernel names of a
+    PMC record, e.g. "fa_fwd_pipe_kernel" or "fa_bwd_dq_kernel + fa_bwd_dkdv_kernel") only the device sources those kernels are built
+    from count - the .hip files that define them and every csrc header / .hip they include, transitively - so an edit to another kernel's
+    file does not orphan the figure; without it, every file under csrc/."""
+    csrc = ROOT / "flash-attention-ipu_amd" / "csrc"
+    files = sorted(f for f in csrc.glob("*") if f.suffix in (".hip", ".h", ".cpp"))
+    if kernels:
+        names = set(re.findall(r"fa_\w+_kernel", kernels))
+        text = {f: f.read_text() for f in files}
+        todo = [f for f in files if f.suffix == ".hip" and any(re.search(r"void\s+" + n + r"\s*\(", text[f]) for n in names)]
+        seen = set()
+        while todo:
+            f = todo.pop()
+            if f in seen:
+                continue
+            seen.add(f)
+            todo += [csrc / inc for inc in re.findall(r'#include\s+"([^"]+)"', text[f]) if (csrc / inc) in text]
+        files = sorted(seen)
     h = hashlib.sha256()
-    for f in sorted((ROOT / "flash-attention-ipu_amd" / "csrc").glob("*")):
-        if f.suffix in (".hip", ".h", ".cpp"):
-            h.update(f.name.encode())
-            h.update(f.read_bytes())
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
     return h.hexdigest()[:16]
 
 
@@ -372,8 +388,8 @@ def profiled_traffic(config, plan, kname=None):
         return None, f"unreadable profiles/hbm_traffic.json: {e}"
     if not rec:
         return None, f"no PMC record for {config}"
-    if rec.get("csrc_sha256_16") != csrc_fingerprint():
-        return None, f"PMC record is for kernel sources {rec.get('csrc_sha256_16')}, this build is {csrc_fingerprint()}: re-run scripts/profile.sh"
+    if rec.get("csrc_sha256_16") != csrc_fingerprint(rec.get("kernel")):
+        return None, f"PMC record is for kernel sources {rec.get('csrc_sha256_16')}, this build is {csrc_fingerprint(rec.get('kernel'))}: re-run scripts/profile.sh"
     kname = kname or kernel_name(plan)
     names = lambda t: sorted(x.split(" ")[0] for x in t.split(" + "))  # noqa: E731
     if rec.get("kernel") and names(rec["kernel"]) != names(kname):
@@ -404,10 +420,11 @@ def main():
     ap.add_argument("--no-probes", action="store_true",
                     help="skip the MFMA-peak probes, the clock sampler and the per-step event pass after the timed region: the LAST --steps "
                          "dispatches of the kernel are then the timed region (scripts/profile.sh computes its kernel statistics over them)")
-    ap.add_argument("--print-csrc-fingerprint", action="store_true")
+    ap.add_argument("--print-csrc-fingerprint", nargs="?", const="", default=None, metavar="KERNELS",
+                    help="print the sha256 of the kernel sources (of the named kernels' sources only, when given) and exit")
     args = ap.parse_args()
-    if args.print_csrc_fingerprint:
-        print(csrc_fingerprint())
+    if args.print_csrc_fingerprint is not None:
+        print(csrc_fingerprint(args.print_csrc_fingerprint or None))
         return 0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

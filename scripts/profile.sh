@@ -91,9 +91,9 @@ pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc l2 TCC_HIT_sum TCC_MISS_sum
 pmc grbm GRBM_GUI_ACTIVE
-python3 - "$OUT" "$TAG" "$(python3 $R/bench.py --print-csrc-fingerprint)" <<'PY'
-import csv, json, sys
-out, tag, sha = sys.argv[1:4]
+python3 - "$OUT" "$TAG" "$R" <<'PY'
+import csv, json, subprocess, sys
+out, tag, root = sys.argv[1:4]
 def val(name, counter):     # summed over the kernels of one step
     tot, kerns = 0.0, []
     for r in csv.DictReader(open(f"{out}/pmc_{name}.csv")):
@@ -101,6 +101,8 @@ def val(name, counter):     # summed over the kernels of one step
             tot += float(r["mean_per_dispatch"]); kerns.append(r["kernel"])
     return (tot, kerns) if kerns else (None, [])
 (fetch, kerns), (write, _) = val("fetch", "FETCH_SIZE"), val("write", "WRITE_SIZE")   # KiB per dispatch
+# the fingerprint of the sources these kernels are built from (bench.py csrc_fingerprint)
+sha = subprocess.run([sys.executable, f"{root}/bench.py", "--print-csrc-fingerprint", " + ".join(kerns)], capture_output=True, text=True).stdout.strip()
 rec = {"kernel": " + ".join(kerns), "csrc_sha256_16": sha, "source": f"profiles/{tag}",
        "fetch_size_kib": fetch, "write_size_kib": write,
        "hbm_bytes_per_launch": round((2 * fetch + write) * 1024) if fetch is not None and write is not None else None}
