@@ -167,21 +167,28 @@ def cpu_baseline(L, D, budget_s=9.0):
     }
 
 
-def device_clock_mhz(torch, dev):
-    """Engine clock of the device in MHz: torch's device properties where they carry it, else the highest sclk level rocm-smi lists, else None."""
+def smi_clock_mhz(index):
+    """Highest sclk level rocm-smi lists for device `index`, in MHz, or None.  rocm-smi is a script (a fork + exec): it is asked BEFORE this
+    process makes its first HIP call - a GPU box refuses an exec from a process that has initialised the GPU - and not at all under
+    rocprofv3, whose preloaded tool initialises the GPU before main()."""
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return None
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        vals = [int(m) for m in re.findall(r"\((\d+)Mhz\)", out)]
+        return max(vals) if vals else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def device_clock_mhz(torch, dev, smi_mhz=None):
+    """Engine clock of the device in MHz: torch's device properties where they carry it, else what rocm-smi listed at start-up, else None."""
     props = torch.cuda.get_device_properties(dev)
     for attr in ("clock_rate", "clockRate"):
         v = getattr(props, attr, 0) or 0
         if v:
             return int(v) // 1000
-    try:
-        out = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
-        vals = [int(m) for m in re.findall(r"\((\d+)Mhz\)", out)]
-        if vals:
-            return max(vals)
-    except Exception:  # noqa: BLE001
-        pass
-    return None
+    return smi_mhz
 
 
 def make_op(name, dev, seed=1, backward=False):
@@ -430,6 +437,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)          # (nothing above has imported torch.cuda or made a HIP call)
 
+    smi_mhz = smi_clock_mhz(int(os.environ.get("LOCAL_RANK", "0"))) if int(os.environ.get("RANK", "0")) == 0 else None   # (before the first HIP call)
     import torch
     import torch.distributed as dist
 
@@ -769,7 +777,7 @@ def main():
                        "device": {"name": "cpu (FA_BENCH_REHEARSE=cpu: numbers are meaningless)"} if rehearse_cpu else
                                  {"name": torch.cuda.get_device_name(dev),
                                   "compute_units": torch.cuda.get_device_properties(dev).multi_processor_count,
-                                  "clock_mhz": device_clock_mhz(torch, dev)}},
+                                  "clock_mhz": device_clock_mhz(torch, dev, smi_mhz)}},
             "exchange_bytes_per_rank": {"sent": shard_bytes if do_gather else 0,
                                         "received": ((world - 1) * shard_bytes if args.gather != "root" or rank == 0 else 0) if do_gather else 0} if dist_on else None,
             # what the exchange alone needs when every GPU pair has its own xGMI link and each link carries ONE shard per direction
