@@ -533,17 +533,19 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     const int mask_esz = p.ex.mask_kind == 2 ? (int)sizeof(T) : 1;
 
     const unsigned q_slb = (unsigned)p.q_sl * 2, g_slb = (unsigned)p.do_sl * 2;
-    unsigned q_vo[PPW], g_vo[PPW];
-    int dst[PPW];
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-        const int pc = wave + j * NWAVES;
-        const int row = (2 * (pc & 3) + (lane >> 5)) * 8 + ((lane >> 2) & 7);
-        const int chunk = (pc >> 2) * 4 + ((lane & 3) ^ ((row >> 2) & 3));
-        q_vo[j] = chunk < dchunks ? (unsigned)row * q_slb + (chunk << 4) : 0x80000000u;   // (past the true head dim: zeros)
-        g_vo[j] = chunk < dchunks ? (unsigned)row * g_slb + (chunk << 4) : 0x80000000u;
-        dst[j] = (pc >> 2) * 4096 + (pc & 3) * 1024;
-    }
+    // LDS-DMA geometry: piece pc = wave + 4 j of an image holds rows 16 (pc & 3) .. +15 of its 64-byte column block pc >> 2 - with four waves
+    // every piece of a wave holds the SAME rows and piece j starts 64 j bytes further along them: one lane offset per operand, the piece in the
+    // instruction's immediate (a lane offset per piece is 2 x PPW registers - 16 at head_dim 256, which that kernel spilled)
+    static_assert(NWAVES == 4, "piece = wave + 4 j");
+    const bool d_full = dchunks == D / 8;               // (else: chunks past the true head dim get an offset beyond any extent - zeros)
+    // (head_dim 128 runs at the 256-register limit of two waves per SIMD: there the two offsets are formed per item from an opaque copy of the
+    //  lane index - a dozen scalar-fed vector instructions per 64 MFMAs - instead of being kept, spilled, and reloaded behind a vmcnt(0))
+#define FA_DMA_LANE_OFFSETS()                                                                      \
+        int le_ = lane;                                                                            \
+        if constexpr (D == 128) asm volatile("" : "+v"(le_));                                      \
+        const int d_row = (2 * wave + (le_ >> 5)) * 8 + ((le_ >> 2) & 7);                          \
+        const int d_c0 = (le_ & 3) ^ ((d_row >> 2) & 3);                                           \
+        const unsigned q_vb = (unsigned)d_row * q_slb + (d_c0 << 4), g_vb = (unsigned)d_row * g_slb + (d_c0 << 4);
     const unsigned q_bytes = ((unsigned)(L - 1) * (unsigned)p.q_sl + (unsigned)p.Dr) * 2;
     const unsigned g_bytes = ((unsigned)(L - 1) * (unsigned)p.do_sl + (unsigned)p.Dr) * 2;
     // item J_ of the stream = query tile i0 + J_ % n_sweep of query head hq0 + J_ / n_sweep
@@ -553,13 +555,25 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #define FA_DMA_QG(J_, BUF_)                                                                        \
     {                                                                                              \
         FA_ITEM(J_, hq_, it_)                                                                      \
+        FA_DMA_LANE_OFFSETS()                                                                      \
         const unsigned qo_ = (unsigned)it_ * BQ * q_slb, go_ = (unsigned)it_ * BQ * g_slb;         \
         const i32x4 qr_ = make_raw_rsrc((const char*)(qg0 + (int64_t)hq_ * p.q_sh) + qo_, q_bytes - qo_);   \
         const i32x4 gr_ = make_raw_rsrc((const char*)(gg0 + (int64_t)hq_ * p.do_sh) + go_, g_bytes - go_);  \
         if (FA_BWD_ABL != 2) {                                                                     \
-        _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                          \
-            lds_dma_b128(qr_, smem_lds + (BUF_) * IMG_B + dst[j], q_vo[j]);                        \
-            lds_dma_b128(gr_, smem_lds + (NB + (BUF_)) * IMG_B + dst[j], g_vo[j]);                 \
+        if (d_full) {                                                                              \
+            fa_static_for<0, PPW>([&](auto ji_) {                                                  \
+                constexpr int j = decltype(ji_)::value;                                            \
+                lds_dma_b128_imm<64 * j>(qr_, smem_lds + (BUF_) * IMG_B + j * 4096 + wave * 1024, q_vb); \
+                lds_dma_b128_imm<64 * j>(gr_, smem_lds + (NB + (BUF_)) * IMG_B + j * 4096 + wave * 1024, g_vb); \
+            });                                                                                    \
+        } else {   /* (the lane's chunk through an opaque copy: the per-piece offsets are formed here, not kept in 2 PPW registers across the loop) */ \
+            int c0_ = d_c0;                                                                        \
+            asm volatile("" : "+v"(c0_));                                                          \
+            _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                      \
+                const bool in_ = 4 * j + c0_ < dchunks;                                            \
+                lds_dma_b128(qr_, smem_lds + (BUF_) * IMG_B + j * 4096 + wave * 1024, in_ ? q_vb + 64 * j : 0x80000000u); \
+                lds_dma_b128(gr_, smem_lds + (NB + (BUF_)) * IMG_B + j * 4096 + wave * 1024, in_ ? g_vb + 64 * j : 0x80000000u); \
+            }                                                                                      \
         }                                                                                          \
         }                                                                                          \
     }
@@ -659,6 +673,10 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         FA_ITEM(J_, hqt_, itt_)                                                                    \
         (void)hqt_; (void)mask_esz;                                                                \
         const int q0 = itt_ * BQ;                                                                  \
+        /* (head_dim 128 and up: the half-wave offset through an opaque copy - the row-constant addresses and the diagonal's row numbers \
+           are then formed where they are used; hoisted out of the item loop they are a dozen registers the 256-register kernel spills) */ \
+        int h_t = h;                                                                               \
+        if constexpr (D >= 128) asm volatile("" : "+v"(h_t));                                      \
         if constexpr (EXTRA == 1) {                                                                \
             if (p.ex.mask != nullptr && wave_active && kterm_hq != (p.ex.m_sh == 0 ? 0 : hqt_)) {  \
                 kterm_hq = p.ex.m_sh == 0 ? 0 : hqt_;                                              \
@@ -676,7 +694,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 f32x16 s0, t0;                                                                     \
                 /* dP accumulators start at -Dsum[q] (rowc holds the negated sums) */              \
                 _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                 \
-                    const f32x4 da = *(const f32x4*)(rc_ + 64 + 32 * hb + 8 * gq + 4 * h);         \
+                    const f32x4 da = *(const f32x4*)(rc_ + 64 + 32 * hb + 8 * gq + 4 * h_t);         \
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) { s0[4 * gq + j] = 0.f; t0[4 * gq + j] = da[j]; } \
                 }                                                                                  \
                 _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                \
@@ -698,7 +716,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                             } else {                                                               \
                                 const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqt_) * p.ex.m_sh) * mask_esz; \
                                 _Pragma("unroll") for (int e = 0; e < 16; ++e) {                   \
-                                    const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;  \
+                                    const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h_t;  \
                                     s0[e] += mask_load1<T>(p.ex.mask_kind, mb_, (int64_t)(qq < L ? qq : L - 1) * p.ex.m_sl, kr, p.ex.inv_scale); \
                                 }                                                                  \
                             }                                                                      \
@@ -709,12 +727,12 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 }                                                                                  \
                 if (causal && q0 + 32 * hb < key0 + 31) { /* diagonal: query < key is masked */    \
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) {                               \
-                        const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h;              \
+                        const int qq = q0 + 32 * hb + (e & 3) + 8 * (e >> 2) + 4 * h_t;              \
                         if (qq < key) s0[e] = -INFINITY;                                           \
                     }                                                                              \
                 }                                                                                  \
                 _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                 \
-                    const f32x4 la = *(const f32x4*)(rc_ + 32 * hb + 8 * gq + 4 * h);              \
+                    const f32x4 la = *(const f32x4*)(rc_ + 32 * hb + 8 * gq + 4 * h_t);              \
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                \
                         const int e = 4 * gq + j;                                                  \
                         s0[e] = fast_exp2(__builtin_fmaf(s0[e], c, -la[j]));                       \
@@ -725,9 +743,9 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                     if (p.ex.drop_thr != 0u) {                                                     \
                         const unsigned row0_ = (unsigned)(q0 + 32 * hb);                           \
                         const unsigned kgq_ = drop_group_key(drop_key0_of(p.ex), (unsigned)(bb * p.H + hq0 + hqt_)); \
-                        const unsigned base_ = drop_tile_key(kgq_, row0_, (unsigned)key0) ^ (((row0_ & 0xffffu) | (unsigned)(4 * h)) << 16) ^ ((unsigned)key & 0xffffu); \
+                        const unsigned base_ = drop_tile_key(kgq_, row0_, (unsigned)key0) ^ (((row0_ & 0xffffu) | (unsigned)(4 * h_t)) << 16) ^ ((unsigned)key & 0xffffu); \
                         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                         \
-                            const f32x4 da = *(const f32x4*)(rc_ + 64 + 32 * hb + 8 * gq + 4 * h);   /* -Dsum[row] */ \
+                            const f32x4 da = *(const f32x4*)(rc_ + 64 + 32 * hb + 8 * gq + 4 * h_t);   /* -Dsum[row] */ \
                             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                        \
                                 const int e = 4 * gq + j;                                          \
                                 const bool keep_ = mix32(base_ ^ ((unsigned)((e & 3) + 8 * (e >> 2)) << 16)) >= p.ex.drop_thr; \
@@ -879,14 +897,17 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     }
 #undef FA_ITEM
 #undef FA_DMA_QG
+#undef FA_DMA_LANE_OFFSETS
 #undef FA_ROWC_LOAD
 #undef FA_ROWC_STORE
 #undef FA_DKDV_TILE
 #undef FA_DMA_MASK
 
     if (!wave_active || key >= L) return;
-    T* __restrict__ dkg = (T*)p.dk + (int64_t)bb * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)key * p.dk_sl;
-    T* __restrict__ dvg = (T*)p.dv + (int64_t)bb * p.dv_sb + (int64_t)hh * p.dv_sh + (int64_t)key * p.dv_sl;
+    int key_e = key;                                // (the output rows' addresses are formed here, not carried through the loop)
+    asm volatile("" : "+v"(key_e));
+    T* __restrict__ dkg = (T*)p.dk + (int64_t)bb * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)key_e * p.dk_sl;
+    T* __restrict__ dvg = (T*)p.dv + (int64_t)bb * p.dv_sb + (int64_t)hh * p.dv_sh + (int64_t)key_e * p.dv_sl;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll

@@ -268,14 +268,14 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
     int &waves = c->waves, &qb = c->qb, &split = c->split;
     if (D > 128) {
         // head_dim 192 / 256: the 64-key-tile kernel alone, one workgroup per CU (99 / 132 KB of LDS).  192 fits 8 waves (225 registers, two
-        // waves per SIMD: [3,128,2048,192] 323 -> 269 us, [3,32,8192,192] 970 -> 753 us = 1 096 TFLOP/s); 256 spills 32 registers in that form and
-        // loses 20-35 % (426 -> 531 us), so it keeps 4 waves with the whole register file unless 8 are forced
+        // waves per SIMD: [3,128,2048,192] 323 -> 269 us, [3,32,8192,192] 970 -> 753 us = 1 096 TFLOP/s); 256 spilled 32 registers in that form and
+        // lost 20-35 % (426 -> 531 us): it keeps 4 waves with the whole register file, the 8-wave form is not built
         int w = (D == 192 && r.cq >= 256 && r.L >= 1024 && r.g8 * ((r.L + 255) / 256) >= 256) ? 8 : 4;
-        if (opt.waves == 4 || opt.waves == 8) w = opt.waves;
+        if (opt.waves == 4 || (opt.waves == 8 && D == 192)) w = opt.waves;   // (8 waves at 256 would spill: not built)
         // 256 with the skip-max arithmetic from L = 1024 on: the software-pipelined kernel's 4-wave form (133 KB of rings; one wave per SIMD needs the
         // hand-ordered step to keep the matrix pipe fed: [3,128,2048,256] 428 -> 362 us, [3,32,8192,256] 1 478 -> 1 191 us = 923 TFLOP/s)
         bool pipe256 = D == 256 && r.pipe_ok && r.L >= 1024 && r.cq >= 128;
-        if (opt.kernel == 'd' || opt.waves == 8) pipe256 = false;
+        if (opt.kernel == 'd') pipe256 = false;
         if (opt.kernel == 'p' && D == 256 && r.pipe_ok) pipe256 = true;
         which = pipe256 ? 'p' : 'd'; waves = pipe256 ? 4 : w; qb = 1; split = 1;
         return;

@@ -110,6 +110,21 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned lds_base, unsi
         : "s"(lds_base), "v"(voffset), "s"(rsrc)
         : "memory");
 }
+// the same with a compile-time byte offset (0 .. 4095) added to the lane's: pieces that differ by a constant share one offset register
+template <int IMM>
+__device__ __forceinline__ void lds_dma_b128_imm(i32x4 rsrc, unsigned lds_base, unsigned voffset) {
+    static_assert(IMM >= 0 && IMM < 4096, "12-bit instruction offset");
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, 0 offen offset:%4 lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_base), "v"(voffset), "s"(rsrc), "n"(IMM)
+        : "memory");
+}
 __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_offset(const void* p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;

@@ -532,7 +532,13 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         if (pass + 1 < n_pass) {
             // the pair's second q tile: its Q rows go into the registers the loop has just released, its first K/V tile into
             // buffer 0 (every wave is past the loop's last barrier); both land under the epilogue below
-            FA_LOAD_Q(qd)
+            {   // (through opaque copies of the lane's row and half: the compiler otherwise keeps this load's per-lane addresses - eight
+                //  registers - alive across the whole kv loop of the first q tile, and at 128 registers spills them)
+                const int r0_ = r, h0_ = h;
+                int r = r0_, h = h0_;
+                asm volatile("" : "+v"(r), "+v"(h));
+                FA_LOAD_Q(qd)
+            }
             FA_DMA_TILE(0, 0)
             tile0_requested = true;
 #pragma unroll
@@ -595,6 +601,8 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     constexpr int CPR = D / 8;   // 16-byte chunks per row
     constexpr int ESW = CPR & -CPR;   // the slab's XOR swizzle stays inside aligned groups of this many chunks (the largest power of two in CPR: 8 at head_dim 192)
     if (wave_active) {
+    int lane_e = lane;                                  // (pairs: the store loop's per-lane rows and chunks are recomputed per pass, not kept
+    if constexpr (PAIR) asm volatile("" : "+v"(lane_e));   //  in registers - and spilled - across the kv loops)
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         const float lt = lsum[b][0];
@@ -614,7 +622,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         if (p.lse != nullptr && h == 0 && row_b < L) p.lse[(int64_t)g * L + row_b] = m[b] * p.scale + __logf(lt);
 #pragma unroll
         for (int i = 0; i < CPR / 2; ++i) {                      // 64 chunks per store instruction: 8 rows at D=64, 4 at 128, 2 2/3 at 192, 2 at 256
-            const int rr = (i * 64 + lane) / CPR, ch = (i * 64 + lane) % CPR;
+            const int rr = (i * 64 + lane_e) / CPR, ch = (i * 64 + lane_e) % CPR;
             const u32x4 val = *(const u32x4*)(slab + rr * ROWB + ((ch ^ (rr & (ESW - 1))) << 4));
             const int orow = q_row0 + 32 * b + rr;
             if (orow < L && ch < dchunks && (FA_DMA_ABL != 6 || val.x == 0x12345u)) *(u32x4*)(og + (int64_t)orow * p.o_sl + ch * 8) = val;
@@ -707,10 +715,12 @@ static hipError_t launch_dma_w(const FwdParams& p, int waves, int qb, int split,
 // one workgroup per CU; 234 VGPRs at 192, 256 VGPRs + the accumulators' overflow in AGPRs at 256 (no scratch)
 template <typename T, int D, bool SKIP>
 static hipError_t launch_dma_wide(const FwdParams& p, int waves, int qb, int split, int pair, hipStream_t stream) {
-    if (!((waves == 4 || waves == 8) && qb == 1 && split == 1 && !pair)) return hipErrorInvalidValue;
+    if (!((waves == 4 || (waves == 8 && D == 192)) && qb == 1 && split == 1 && !pair)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((int64_t)p.G8 * p.nq_tiles));
-    return waves == 8 ? launch1((const void*)(fa_fwd_dma_kernel<T, D, 8, SKIP, 1, 1>), grid, dim3(512), 0, stream, p)
-                      : launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 1>), grid, dim3(256), 0, stream, p);
+    if constexpr (D == 192) {   // (8 waves = two per SIMD = 256 registers: head_dim 256 would spill 33 of them - not instantiated)
+        if (waves == 8) return launch1((const void*)(fa_fwd_dma_kernel<T, D, 8, SKIP, 1, 1>), grid, dim3(512), 0, stream, p);
+    }
+    return launch1((const void*)(fa_fwd_dma_kernel<T, D, 4, SKIP, 1, 1>), grid, dim3(256), 0, stream, p);
 }
 template <typename T, bool SKIP>
 static hipError_t launch_dma_wide_d(const FwdParams& p, int waves, int qb, int split, int pair, hipStream_t stream) {
