@@ -521,12 +521,24 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         vec8 z_;
 #pragma unroll
         for (int j = 0; j < 8; ++j) z_[j] = (T)0.f;
+        if constexpr (D >= 192) {             // (the half-wave's chunk offset through an opaque copy: written plainly, the 512-register kernel's
+            int h_p = h;                      //  prologue parked a - never reloaded - address pair in a stack slot)
+            asm volatile("" : "+v"(h_p));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ch_ = 2 * ks + h_p, cc_ = ch_ < dchunks ? ch_ : 0;
+                const vec8 kl_ = *(const vec8*)(kp + 8 * cc_), vl_ = *(const vec8*)(vp + 8 * cc_);
+                kf[ks] = ch_ < dchunks ? kl_ : z_;
+                vf[ks] = ch_ < dchunks ? vl_ : z_;
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {     // (columns past the true head dim, BwdParams::Dr: zeros)
             const int ch_ = 2 * ks + h, cc_ = ch_ < dchunks ? ch_ : 0;
             const vec8 kl_ = *(const vec8*)(kp + 8 * cc_), vl_ = *(const vec8*)(vp + 8 * cc_);
             kf[ks] = ch_ < dchunks ? kl_ : z_;
             vf[ks] = ch_ < dchunks ? vl_ : z_;
+        }
         }
     }
     const float c = p.scale_log2;

@@ -110,10 +110,12 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rsrc, unsigned lds_base, unsi
         : "s"(lds_base), "v"(voffset), "s"(rsrc)
         : "memory");
 }
-// the same with a compile-time byte offset (0 .. 4095) added to the lane's: pieces that differ by a constant share one offset register
+// the same with a compile-time byte offset (0 .. 4095) added to the lane's: pieces that differ by a constant share one offset register.
+// (The instruction's offset field moves BOTH ends of an LDS load - memory address and LDS address: M0 carries lds_base - IMM.)
 template <int IMM>
 __device__ __forceinline__ void lds_dma_b128_imm(i32x4 rsrc, unsigned lds_base, unsigned voffset) {
     static_assert(IMM >= 0 && IMM < 4096, "12-bit instruction offset");
+    lds_base -= IMM;
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"

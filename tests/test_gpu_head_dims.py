@@ -212,8 +212,8 @@ def test_golden_g7_head_dims_from_the_reference():
                                           (232, 2, 1333, True)])
 def test_head_dims_192_and_256_in_both_workgroup_forms(knobs, dtype, waves, D, G, L, causal):
     """head_dim 192 / 256 (and what runs zero-extended at them) through the 64-key-tile kernel with 4 and with 8 waves (192: the rule's
-    choice from 256 workgroups on; 256: forced only - it spills there), unscaled f16 with the exact row max included: out and logsumexp
-    against the fp64 oracle, no store past a row."""
+    choice from 256 workgroups on; 256: no 8-wave form - it would spill 33 registers, and no shipped kernel uses scratch - a forced 8
+    is served by 4), unscaled f16 with the exact row max included: out and logsumexp against the fp64 oracle, no store past a row."""
     from flash_attention_amd._impl import _native
     from oracle import dense_attention_lse, frozen_randn
 
@@ -227,7 +227,8 @@ def test_head_dims_192_and_256_in_both_workgroup_forms(knobs, dtype, waves, D, G
         knobs.set("kernel", "dma")
         knobs.set("waves", waves)
     p = _native.plan(G, L, D, dtype, 1, 1, softmax_scale=scale, causal=causal)
-    assert (p.kernel, p.waves, p.block_q, p.qb) == ((2, 4, 128, 1) if pipe else (0, waves, 32 * waves, 1))
+    w_eff = 4 if (not pipe and waves == 8 and D > 192) else waves
+    assert (p.kernel, p.waves, p.block_q, p.qb) == ((2, 4, 128, 1) if pipe else (0, w_eff, 32 * w_eff, 1))
     x = (frozen_randn(SEED + 41 * L + D, (3, G, L, D)) * (0.8 if dtype == torch.bfloat16 else 0.3)).to(dtype)
     ref, ref_lse = dense_attention_lse(x[0][None].double(), x[1][None].double(), x[2][None].double(), scale=scale, causal=causal)
     q, k, v = x.cuda()

@@ -390,3 +390,28 @@ def test_q_tile_subsets_cover_every_tile_once(native, G, L, D):
     if xs > 1:      # every XCD gets the same number of (group, subset) pairs when G * xs is a multiple of 8
         per_xcd = [sum(1 for (g, q), b in seen.items() if b & 7 == x) for x in range(8)]
         assert max(per_xcd) - min(per_xcd) <= (nq_real + xs - 1) // xs, per_xcd
+
+
+def test_no_shipped_kernel_uses_scratch_memory():
+    """The Makefile compiles every kernel object with -Rpass-analysis=kernel-resource-usage and fails the build on a kernel that needs
+    scratch (csrc register budgets are set so that none does: a spilled register in an attention loop is a reload behind a vmcnt(0)).
+    The remarks it leaves beside the objects are read back here: every instantiation, zero bytes."""
+    import pathlib
+    import re
+
+    obj = pathlib.Path(__file__).resolve().parent.parent / "flash-attention-ipu_amd" / "build" / "obj"
+    remarks = sorted(obj.glob("*.remarks"))
+    if not remarks:
+        pytest.skip("no build/obj/*.remarks (the library was not built by this Makefile here)")
+    kernels = {}
+    for f in remarks:
+        name = None
+        for line in f.read_text().splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and name:
+                kernels[name] = int(m.group(1))
+    assert len(kernels) >= 150, len(kernels)
+    assert {k: v for k, v in kernels.items() if v} == {}
