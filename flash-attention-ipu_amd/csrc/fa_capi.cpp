@@ -625,11 +625,11 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     if (k_strides[2] > (1ll << 32) || v_strides[2] > (1ll << 32)) wide_rows = true;
 
     // the MFMA kernels need 16-byte rows and address K/V rows with 32-bit element offsets from the group base
-    // mask / dropout: the MFMA mask kernel (fa_fwd_extra.hip) for 16-bit operands it takes (head dims up to 128), the generic kernel for
+    // mask / dropout: the MFMA mask kernel (fa_fwd_extra.hip) for 16-bit operands (head dims up to 256, as the plain forward; the BACKWARD's
+    // mask kernels stop at 128 - bwd_impl - because their dK/dV form does not fit the register file at 256), the generic kernel for
     // everything else fa_fwd serves (fp32, other head dims, unaligned rows) - never the fp32 MFMA kernel, which has no mask path
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
-    int64_t Dk0 = kernel_head_dim(D, dtype);
-    if (extra && Dk0 > 128) Dk0 = 0;               // (the mask / dropout kernels stop at head_dim 128: their dK/dV form does not fit the register file at 256)
+    const int64_t Dk0 = kernel_head_dim(D, dtype);
     // (a zero-extended call marks the chunks past the true head dim with the LDS-DMA offset 0x80000000 and relies on the descriptor's range
     //  check to return zeros for it: the K / V extent of a group must then stay below 2^31 BYTES, or that offset is a real address)
     const int64_t kv_extent_limit = (Dk0 != 0 && Dk0 != D) ? (1ll << 31) / elt_size(dtype) : (1ll << 31);

@@ -148,10 +148,11 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // padded tail) is skipped by the whole workgroup.
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     constexpr int MIMG_B = MM == 3 ? 16384 : 8192, MT_F = 80;
-    __shared__ __attribute__((aligned(16))) unsigned char smem_mk[EXTRA ? (MM >= 2 ? 2 * MIMG_B : 2 * MT_F * 4) : 16];
+    constexpr bool MDMA = !(D == 256 && MM == 3);    // (head_dim 256: K / V fill 132 KB - two 16 KB bias images do not fit beside them: that bias is loaded in place)
+    __shared__ __attribute__((aligned(16))) unsigned char smem_mk[EXTRA ? (MM >= 2 ? (MDMA ? 2 * MIMG_B : 16) : 2 * MT_F * 4) : 16];
     float* const mterm = (float*)smem_mk;
     constexpr bool mbias = MM == 3;
-    const bool mdma = EXTRA && MM >= 2 && mask_g != nullptr && (p.ex.mask_vec & 2) != 0;
+    const bool mdma = EXTRA && MM >= 2 && MDMA && mask_g != nullptr && (p.ex.mask_vec & 2) != 0;
     const bool mbc = EXTRA && MM == 0 && mask_g != nullptr;
     static_assert(!EXTRA || (QB == 1 && SPLIT == 1 && NWAVES == 4), "mask staging: one 32-row block per wave, unsplit 4-wave workgroups");
     unsigned m_vo[(EXTRA && MM >= 2) ? 4 : 1];

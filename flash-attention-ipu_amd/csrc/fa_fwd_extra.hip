@@ -2,7 +2,7 @@
 // scaled_dot_product_attention.py:21-28 of the reference rejects).  The kernel IS fa_fwd_dma_body (fa_fwd_dma.hip: 4 waves x 32
 // query rows, 64-key tiles staged by LDS-DMA) instantiated with EXTRA = true and the exact-max arithmetic: the mask terms are
 // added to the score registers of every tile, the dropout decisions are taken on the P registers between the row sums and the
-// PV product.  16-bit operands, head_dim 64 / 128; causal or unmasked underneath.
+// PV product.  16-bit operands, head_dim 64 / 128 / 192 / 256 (and what runs zero-extended at them); causal or unmasked underneath.
 #define FA_DMA_BODY_ONLY 1
 #include "fa_fwd_dma.hip"
 
@@ -22,9 +22,19 @@ static hipError_t launch_fwd_extra_t(const FwdParams& p, hipStream_t stream) {
                                : launch1((const void*)(fa_fwd_extra_kernel<T, D, 2>), grid, block, 0, stream, p);
 }
 
+template <typename T>
+static hipError_t launch_fwd_extra_d(const FwdParams& p, hipStream_t stream) {
+    switch (p.D) {
+        case 64: return launch_fwd_extra_t<T, 64>(p, stream);
+        case 128: return launch_fwd_extra_t<T, 128>(p, stream);
+        case 192: return launch_fwd_extra_t<T, 192>(p, stream);   // (192 / 256: one workgroup per CU - 100 / 133 KB of K / V tiles plus the mask images)
+        case 256: return launch_fwd_extra_t<T, 256>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_fwd_extra(const FwdParams& p, int dtype, hipStream_t stream) {
-    if (dtype == 1) return p.D == 64 ? launch_fwd_extra_t<__bf16, 64>(p, stream) : launch_fwd_extra_t<__bf16, 128>(p, stream);
-    return p.D == 64 ? launch_fwd_extra_t<_Float16, 64>(p, stream) : launch_fwd_extra_t<_Float16, 128>(p, stream);
+    return dtype == 1 ? launch_fwd_extra_d<__bf16>(p, stream) : launch_fwd_extra_d<_Float16>(p, stream);
 }
 
 }  // namespace fa

@@ -133,6 +133,65 @@ def test_mask_that_is_a_strided_view_equals_its_contiguous_copy(kind, causal):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("kind", ["bool_LL", "bool_padding", "bool_BHLL_dead_rows", "bias_BHLL", "bias_1HLL", "bias_head_key"])
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 192), (torch.float16, 256), (torch.bfloat16, 256), (torch.bfloat16, 160), (torch.float16, 232)])
+@pytest.mark.parametrize("B,H,Hkv,L,causal", [(1, 2, 2, 200, False), (2, 2, 1, 520, False), (1, 2, 1, 1284, True)])
+def test_masked_forward_at_head_dims_up_to_256_vs_oracle(kind, dtype, D, B, H, Hkv, L, causal):
+    """fa_fwd_ex at head_dim 192 / 256 and at dims that run zero-extended at them (160, 232): the forward's mask kernels take every head dim
+    the plain forward takes (the backward's stop at 128 - the override sends a call that wants a gradient there to stock SDPA).  Boolean
+    masks and biases through the LDS-DMA tile images (at 256 a bias is loaded in place: the images do not fit beside 132 KB of K / V
+    tiles), row-broadcast masks through the staged key terms, with and without the causal mask underneath, grouped K/V heads."""
+    from flash_attention_amd._impl import ops
+    from oracle import dense_attention_extra, frozen_randn
+
+    gen = torch.Generator().manual_seed(SEED + L + D)
+    q = (frozen_randn(SEED + L, (B, H, L, D)) * 0.5).to(dtype)
+    k = (frozen_randn(SEED + L + 1, (B, Hkv, L, D)) * 0.5).to(dtype)
+    v = (frozen_randn(SEED + L + 2, (B, Hkv, L, D)) * 0.5).to(dtype)
+    mask = _masks(kind, B, H, L, dtype, gen)
+    if causal and mask.dtype == torch.bool and mask.shape[-2] == L:
+        # (under the causal mask a row whose admitted keys all lie in its future has no reference behaviour - torch rejects attn_mask with
+        #  is_causal, the oracle's causal term is the reference's finite -10000, the kernels' is -inf: every row that admits a key admits key 0)
+        mask[..., :1] |= mask.any(-1, keepdim=True)
+    scale = D ** -0.5
+    ref, _ = dense_attention_extra(q.double(), k.double(), v.double(), scale, causal, mask)
+    mc = mask.cuda().expand(B, H, L, L)
+    mc = mc.view(torch.uint8) if mc.dtype == torch.bool else mc
+    if mc.stride(-1) != 1:
+        mc = mc.contiguous()
+    assert ops.supports_extra(q, needs_grad=False) and not ops.supports_extra(q, needs_grad=True)
+    with torch.no_grad():
+        out = ops.attention_extra(q.cuda(), k.cuda(), v.cuda(), mc, scale, causal)
+    _fwd_close(out, ref, f"masked forward {kind} {dtype} {B}x{H}/{Hkv}x{L}x{D} causal={causal}")
+
+
+def test_override_serves_wide_head_masks_without_a_gradient_and_hands_training_calls_to_stock(monkeypatch):
+    """F.scaled_dot_product_attention with attn_mask at head_dim 256: under no_grad the override's own forward (checked against stock's
+    result), with requires_grad stock SDPA end to end (its backward is faster than this repo's scalar fallback) - gradients flow either way."""
+    import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl import ops
+
+    calls = []
+    real = ops.attention_extra
+    monkeypatch.setattr(ops, "attention_extra", lambda *a, **kw: (calls.append(a[0].shape), real(*a, **kw))[1])
+    torch.manual_seed(9)
+    B, H, L, D = 2, 4, 384, 256
+    q, k, v = (torch.randn(B, H, L, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    keep = torch.ones(B, 1, 1, L, device="cuda", dtype=torch.bool)
+    keep[0, ..., L - 77:] = False
+    stock = F.scaled_dot_product_attention.__wrapped__
+    with torch.no_grad():
+        ours = F.scaled_dot_product_attention(q, k, v, attn_mask=keep)
+        ref = stock(q.float(), k.float(), v.float(), attn_mask=keep)
+    assert (ours.float() - ref).abs().max().item() <= 3e-2
+    assert len(calls) == 1                          # this repo's mask kernel ran
+    qg = q.clone().requires_grad_(True)
+    out = F.scaled_dot_product_attention(qg, k, v, attn_mask=keep)
+    out.sum().backward()
+    assert len(calls) == 1                          # ... and did not for the call that wants a gradient
+    assert torch.isfinite(qg.grad.float()).all() and (out.detach().float() - ref).abs().max().item() <= 3e-2
+
+
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("p", [0.1, 0.5])
 @pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.float16, 64), (torch.bfloat16, 128)])
