@@ -32,9 +32,20 @@ static hipError_t launch_bwd_extra_t(const BwdParams& p, hipStream_t stream) {
     return p.ex.mask_kind == 2 ? launch_bwd_extra_m<T, D, 3>(p, stream) : launch_bwd_extra_m<T, D, 2>(p, stream);
 }
 
+// head dims: 64, 128 and 192 (one workgroup per CU there).  256 is not built: its dK/dV form fills all 512 registers without the mask terms
+// (with them it spills, and one instantiation crashes the compiler) - the C ABI sends such a call to the generic kernels, the override to stock SDPA.
+template <typename T>
+static hipError_t launch_bwd_extra_d(const BwdParams& p, hipStream_t stream) {
+    switch (p.D) {
+        case 64: return launch_bwd_extra_t<T, 64>(p, stream);
+        case 128: return launch_bwd_extra_t<T, 128>(p, stream);
+        case 192: return launch_bwd_extra_t<T, 192>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_bwd_extra(const BwdParams& p, int dtype, hipStream_t stream) {
-    if (dtype == 1) return p.D == 64 ? launch_bwd_extra_t<__bf16, 64>(p, stream) : launch_bwd_extra_t<__bf16, 128>(p, stream);
-    return p.D == 64 ? launch_bwd_extra_t<_Float16, 64>(p, stream) : launch_bwd_extra_t<_Float16, 128>(p, stream);
+    return dtype == 1 ? launch_bwd_extra_d<__bf16>(p, stream) : launch_bwd_extra_d<_Float16>(p, stream);
 }
 
 }  // namespace fa

@@ -266,15 +266,24 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             if (tid == 0) mterm[(BUF_) * MT_F + 64] = dead_ ? 1.f : 0.f;                           \
         }                                                                                          \
     }
+    // (the tiles are requested in order: the image's address in the mask and the bytes left to the end of the slice's last row advance
+    //  by one tile per request - two scalar pairs carried through the loop instead of the strides and indices they come from)
+    unsigned long long m_at = 0, m_left = 0;
+    if constexpr (EXTRA >= 2) {
+        m_at = (unsigned long long)((const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh + (int64_t)(qi * BQ) * p.ex.m_sl) * mask_esz);
+        m_left = (unsigned long long)(((int64_t)(L - 1 - qi * BQ) * p.ex.m_sl + L) * mask_esz);
+        m_at = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m_at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m_at);
+        m_left = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m_left >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m_left);
+    }
+    (void)m_at; (void)m_left;
 #define FA_DMA_MASK(T_, BUF_)                                                                      \
     if constexpr (EXTRA >= 2) {                                                                    \
-        if (mdma) {                                                                                \
-            const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh + (int64_t)(qi * BQ) * p.ex.m_sl + (T_) * BK) * mask_esz; \
-            const int64_t left_ = ((int64_t)(L - 1 - qi * BQ) * p.ex.m_sl + (L - (T_) * BK)) * mask_esz;   /* to the end of the slice's last row */ \
-            i32x4 mr_ = make_raw_rsrc(mb_, left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu);   \
-            _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   /* (64-bit products leave the scalar unit) */ \
+        if (mdma) {   /* (tile T_ is the next one in order: asserted by the loop structure below) */ \
+            const i32x4 mr_ = make_raw_rsrc((const char*)m_at, m_left < 0xffffffffull ? (unsigned)m_left : 0xffffffffu); \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \
                 if (mbias || j < 2) lds_dma_b128(mr_, smem_lds + MOFF + (BUF_) * MIMG_B + (wave + 4 * j) * 1024, m_vo[j]); \
+            m_at += (unsigned)(BK * mask_esz);                                                     \
+            m_left -= (unsigned)(BK * mask_esz);                                                   \
         }                                                                                          \
     }
 
