@@ -214,7 +214,10 @@ def fuzz(cases, seed, log=print):
         tol = {torch.float16: 4e-3, torch.bfloat16: 1.5e-2, torch.float32: 1e-5}[dt]
         for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
             got = got.cpu().double()
-            floor = tol * max(1e-1, want.abs().max().item())     # (absolute floor: an exactly-zero gradient - L = 1 - comes out as rounding noise of Dsum)
+            # (absolute floor: a gradient that is exactly zero - L = 1: P = 1, dS = dP - Dsum = 0 - comes out as the rounding noise of the two
+            #  equal sums it is the difference of, so the floor scales with them and with the operand dS multiplies)
+            cancel = (g.double() * ref.detach()).sum(-1).abs().max().item() * max(q0.abs().max().item(), k0.abs().max().item()) * scale
+            floor = tol * max(1e-1, want.abs().max().item(), cancel)
             if not (bool(torch.isfinite(got).all()) and bool(((got - want).abs() <= floor + 2e-2 * want.abs()).all())):
                 bad += 1
                 log(f"MISMATCH grouped-query backward case {case} {name}: B={B} H={H}/{Hkv} L={L} D={D} {dt} scale={scale:.3g} causal={causal} max|d|={(got - want).abs().max().item():.3e}")
