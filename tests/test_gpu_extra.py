@@ -104,6 +104,35 @@ def test_masked_forward_and_backward_vs_oracle(kind, dtype, D, B, H, Hkv, L):
             _grad_close(got, want, f"{name} {kind} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
 
 
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.float16, 128), (torch.bfloat16, 192)])
+def test_key_padding_with_a_batch_entry_that_keeps_no_key_and_tiles_that_keep_none(dtype, D):
+    """A key-padding mask whose first batch entry keeps NO key (every tile of it is skipped by the staged-terms path: its rows are NaN with
+    lse = -inf, as torch's), whose second keeps 70 keys of 700 (ten of its eleven 64-key tiles are skipped, one is ragged) and whose third keeps
+    all: forward against the oracle, gradients of the live entries against autograd through it, the dead entry's gradients finite zeros."""
+    from flash_attention_amd._impl import ops
+    from oracle import dense_attention_extra, frozen_randn
+
+    B, H, Hkv, L = 3, 4, 2, 700
+    q = (frozen_randn(SEED + D, (B, H, L, D)) * 0.6).to(dtype)
+    k = (frozen_randn(SEED + D + 1, (B, Hkv, L, D)) * 0.6).to(dtype)
+    v = (frozen_randn(SEED + D + 2, (B, Hkv, L, D)) * 0.6).to(dtype)
+    g = frozen_randn(SEED + D + 3, (B, H, L, D)).to(dtype)
+    lens = torch.tensor([0, 70, L])
+    mask = (torch.arange(L)[None, :] < lens[:, None]).view(B, 1, 1, L)
+    scale = D ** -0.5
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, _ = dense_attention_extra(qr, kr, vr, scale, False, mask)
+    assert bool(torch.isnan(ref[0]).all()) and not bool(torch.isnan(ref[1:]).any())
+    ref[1:].backward(g[1:].double())
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = ops.attention_extra(qc, kc, vc, mask.cuda().expand(B, H, L, L).view(torch.uint8), scale, False)
+    _fwd_close(out, ref.detach(), f"key padding with an empty entry {dtype} D={D}")
+    out[1:].backward(g[1:].cuda())
+    for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
+        _grad_close(got[1:], want[1:], f"{name} key padding {dtype} D={D}")
+        assert bool((got[0] == 0).all()), f"{name}: the entry without keys must get zero gradients"
+
+
 @pytest.mark.parametrize("kind", ["bool", "bias"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_mask_that_is_a_strided_view_equals_its_contiguous_copy(kind, causal):
