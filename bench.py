@@ -168,17 +168,22 @@ def cpu_baseline(L, D, budget_s=9.0):
 
 
 def smi_clock_mhz(index):
-    """Highest sclk level rocm-smi lists for device `index`, in MHz, or None.  rocm-smi is a script (a fork + exec): it is asked BEFORE this
+    """Highest sclk level rocm-smi lists as supported for device `index`, in MHz, or None.  rocm-smi is a script (a fork + exec): it is asked BEFORE this
     process makes its first HIP call - a GPU box refuses an exec from a process that has initialised the GPU - and not at all under
     rocprofv3, whose preloaded tool initialises the GPU before main()."""
     if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
         return None
-    try:
-        out = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
-        vals = [int(m) for m in re.findall(r"\((\d+)Mhz\)", out)]
-        return max(vals) if vals else None
+    try:   # the highest SUPPORTED sclk level (`--showclocks` reports the current speeds: an idle device shows 95 MHz there, and its 2 000 MHz is the memory clock)
+        return parse_max_sclk(subprocess.run(["rocm-smi", "-d", str(index), "-s"], capture_output=True, text=True, timeout=20).stdout)
     except Exception:  # noqa: BLE001
         return None
+
+
+def parse_max_sclk(text):
+    """the highest level of the 'Supported sclk frequencies' block of `rocm-smi -s`, in MHz, or None"""
+    m = re.search(r"Supported sclk frequencies(.*?)(?:Supported \w+ frequencies|$)", text, re.S)
+    vals = [int(v) for v in re.findall(r"(\d+)Mhz", m.group(1))] if m else []
+    return max(vals) if vals else None
 
 
 def device_clock_mhz(torch, dev, smi_mhz=None):

@@ -41,7 +41,7 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_every_baseline_con
     # round-4 verdict, item 8: the roofline also from the per-step median, the device's clock filled in
     assert roof["frac_median"] > 0 and abs(roof["frac_median"] - roof["achieved_median"] / 2500.0) < 1e-3
     assert abs(roof["achieved_median"] - roof["flops_per_launch"] / (rec["median_ms"] * 1e-3) / 1e12) < 0.5
-    assert rec["config"]["device"]["clock_mhz"] and rec["config"]["device"]["clock_mhz"] > 500
+    assert rec["config"]["device"]["clock_mhz"] and rec["config"]["device"]["clock_mhz"] >= 2100     # (the engine clock's top level, not the 2 000 MHz memory clock)
 
 
 def test_cpu_baseline_uses_every_granted_core():

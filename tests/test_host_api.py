@@ -415,3 +415,19 @@ def test_no_shipped_kernel_uses_scratch_memory():
                 kernels[name] = int(m.group(1))
     assert len(kernels) >= 150, len(kernels)
     assert {k: v for k, v in kernels.items() if v} == {}
+
+
+def test_bench_reads_the_engine_clock_from_the_supported_sclk_levels():
+    """`rocm-smi -s` as an idle MI355X prints it: the engine clock bench.py reports is the highest SUPPORTED sclk level (2 400), not a
+    current speed (an idle device runs at 96 MHz) and not the memory clock (2 000)."""
+    import importlib.util
+    import pathlib
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", pathlib.Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    text = ("GPU[0]\t\t: Supported fclk frequencies on GPU0\nGPU[0]\t\t: 0: 1250Mhz *\nGPU[0]\t\t: Supported mclk frequencies on GPU0\n"
+            "GPU[0]\t\t: 0: 2000Mhz *\nGPU[0]\t\t: Supported sclk frequencies on GPU0\nGPU[0]\t\t: S: 96Mhz *\nGPU[0]\t\t: 0: 500Mhz\n"
+            "GPU[0]\t\t: 1: 2400Mhz\nGPU[0]\t\t: Supported socclk frequencies on GPU0\nGPU[0]\t\t: S: 38Mhz *\nGPU[0]\t\t: 0: 1200Mhz\n")
+    assert bench.parse_max_sclk(text) == 2400
+    assert bench.parse_max_sclk("no such block") is None
