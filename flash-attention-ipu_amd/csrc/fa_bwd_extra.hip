@@ -15,15 +15,22 @@ template <typename T, int D, int MODE>
 __global__ __launch_bounds__(256) void fa_bwd_dq_extra_kernel(const BwdParams p) {
     fa_bwd_dq_body<T, D, 4, MODE>(p);
 }
-template <typename T, int D, int MODE>
+// PASS 0: dK and dV in one sweep; 1 | 2: dV alone | dK alone (fa_bwd_kernels.hip) - head_dim 256, where the single sweep has no register left for the mask terms
+template <typename T, int D, int MODE, int PASS>
 __global__ __launch_bounds__(256) void fa_bwd_dkdv_extra_kernel(const BwdParams p) {
-    fa_bwd_dkdv_body<T, D, 4, MODE>(p);
+    fa_bwd_dkdv_body<T, D, 4, MODE, PASS>(p);
 }
 
 template <typename T, int D, int MODE>
 static hipError_t launch_bwd_extra_m(const BwdParams& p, hipStream_t stream) {
+    const dim3 kgrid((unsigned)((int64_t)p.G8kv * p.nk_tiles));
     hipError_t e = launch1((const void*)(fa_bwd_dq_extra_kernel<T, D, MODE>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
-    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_extra_kernel<T, D, MODE>), dim3((unsigned)((int64_t)p.G8kv * p.nk_tiles)), dim3(256), 0, stream, p);
+    if constexpr (D == 256) {
+        if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_extra_kernel<T, D, MODE, 1>), kgrid, dim3(256), 0, stream, p);
+        if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_extra_kernel<T, D, MODE, 2>), kgrid, dim3(256), 0, stream, p);
+    } else {
+        if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_extra_kernel<T, D, MODE, 0>), kgrid, dim3(256), 0, stream, p);
+    }
     return e;
 }
 template <typename T, int D>
@@ -32,14 +39,15 @@ static hipError_t launch_bwd_extra_t(const BwdParams& p, hipStream_t stream) {
     return p.ex.mask_kind == 2 ? launch_bwd_extra_m<T, D, 3>(p, stream) : launch_bwd_extra_m<T, D, 2>(p, stream);
 }
 
-// head dims: 64, 128 and 192 (one workgroup per CU there).  256 is not built: its dK/dV form fills all 512 registers without the mask terms
-// (with them it spills, and one instantiation crashes the compiler) - the C ABI sends such a call to the generic kernels, the override to stock SDPA.
+// head dims: 64, 128, 192 and 256 (one workgroup per CU from 192 on).  At 256 dK/dV runs as two passes - dV, then dK - of the same body: in
+// one sweep it fills all 512 registers without the mask terms (with them it spilled, and one instantiation crashed the compiler).
 template <typename T>
 static hipError_t launch_bwd_extra_d(const BwdParams& p, hipStream_t stream) {
     switch (p.D) {
         case 64: return launch_bwd_extra_t<T, 64>(p, stream);
         case 128: return launch_bwd_extra_t<T, 128>(p, stream);
         case 192: return launch_bwd_extra_t<T, 192>(p, stream);
+        case 256: return launch_bwd_extra_t<T, 256>(p, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -485,7 +485,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dq_kernel(const BwdParams 
 // ---------------------------------------------------------------------------------------------
 // dK, dV: one workgroup = NWAVES x 32 keys; streams Q and dO tiles of 64 query rows
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int NWAVES, int EXTRA = 0>
+// PASS: 0 = dK and dV in one sweep; 1 = dV alone, 2 = dK alone - the same body with one of the two results never stored, so that the compiler
+// drops its accumulators, its MFMAs and (dV alone) the V^T fragments and the dP product: the head_dim 256 mask / dropout launches run the two
+// passes one after the other (the single sweep fills all 512 registers without the mask terms), at the price of a second S = Q K^T.
+template <typename T, int D, int NWAVES, int EXTRA = 0, int PASS = 0>
 __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -497,7 +500,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     // Q0 .. Q(NB-1), dO0 .. dO(NB-1) images, then per-buffer row constants: lse2[64], dsum[64]
     // (EXTRA == 2 | 3: plus per buffer the item's mask tile, 64 rows x the workgroup's 128 keys: 8 KB of boolean bytes or 16 KB of bias)
     constexpr int MIMG_B = EXTRA == 3 ? 16384 : 8192, MOFF = 2 * NB * IMG_B + NB * 512;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MOFF + (EXTRA >= 2 ? NB * MIMG_B : 0)];
+    constexpr bool MDMA = !(D == 256 && EXTRA == 3);   // (head_dim 256: the Q / dO images fill 128 KB - two 16 KB bias images do not fit beside them: that bias is loaded in place)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MOFF + ((EXTRA >= 2 && MDMA) ? NB * MIMG_B : 0)];
     unsigned char* const smem_g = smem + NB * IMG_B;
     float* const rowc = (float*)(smem + 2 * NB * IMG_B);  // [buf][ lse2 0..63 | dsum 0..63 ]
 
@@ -646,7 +650,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     // read hold rows i and i + 4, which a plain row-major image would put on the same banks.  Needs mask_vec (pointer and strides multiples
     // of four elements); any other mask is loaded in place, element by element.
     constexpr bool mbias = EXTRA == 3;
-    const bool mdma = EXTRA >= 2 && p.ex.mask != nullptr && (p.ex.mask_vec & 2) != 0;
+    const bool mdma = EXTRA >= 2 && MDMA && p.ex.mask != nullptr && (p.ex.mask_vec & 2) != 0;
     const unsigned m_slb = (unsigned)p.ex.m_sl * (unsigned)mask_esz;
     int m_row[EXTRA >= 2 ? 4 : 1];
     unsigned m_col[EXTRA >= 2 ? 4 : 1];
@@ -895,7 +899,10 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     lds_dma_wait_all();
     __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));   // row operands landed
+    for (int ks = 0; ks < KS; ++ks) {   // row operands landed
+        if constexpr (PASS == 1) asm volatile("" : "+v"(kf[ks]));
+        else asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+    }
 
     for (int j0 = 0; j0 < n_items; j0 += NB) {
         fa_static_for<0, NB>([&](auto ki_) {
@@ -940,8 +947,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 wv[j] = (T)dv[dt][4 * rg + j];
             }
             if (4 * dt + rg < dchunks) {
-                *(vec4*)(dkg + 32 * dt + 8 * rg + 4 * h) = wk;
-                *(vec4*)(dvg + 32 * dt + 8 * rg + 4 * h) = wv;
+                if constexpr (PASS != 1) *(vec4*)(dkg + 32 * dt + 8 * rg + 4 * h) = wk;
+                if constexpr (PASS != 2) *(vec4*)(dvg + 32 * dt + 8 * rg + 4 * h) = wv;
             }
         }
     }

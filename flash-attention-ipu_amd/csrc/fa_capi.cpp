@@ -625,8 +625,8 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     if (k_strides[2] > (1ll << 32) || v_strides[2] > (1ll << 32)) wide_rows = true;
 
     // the MFMA kernels need 16-byte rows and address K/V rows with 32-bit element offsets from the group base
-    // mask / dropout: the MFMA mask kernel (fa_fwd_extra.hip) for 16-bit operands (head dims up to 256, as the plain forward; the BACKWARD's
-    // mask kernels stop at 192 - bwd_impl - because their dK/dV form does not fit the register file at 256), the generic kernel for
+    // mask / dropout: the MFMA mask kernels (fa_fwd_extra.hip; fa_bwd_extra.hip for fa_bwd_ex) for 16-bit operands at every head dim the plain
+    // kernels take (up to 256; there the backward's dK/dV runs as a dV pass and a dK pass), the generic kernel for
     // everything else fa_fwd serves (fp32, other head dims, unaligned rows) - never the fp32 MFMA kernel, which has no mask path
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     const int64_t Dk0 = kernel_head_dim(D, dtype);
@@ -781,7 +781,6 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
     }
     const bool extra = ex && (ex->mask != nullptr || ex->drop_thr != 0u);
     if (extra && dtype == FA_DTYPE_F32) mfma = false;       // (the fp32 MFMA kernels have no mask path: generic kernels)
-    if (extra && Dk0 > 192) mfma = false;                   // (nor has the head_dim 256 kernel: its dK/dV form fills the register file without the mask terms)
     if (!mfma && D > 1024) return fail(FA_ERR_BAD_SHAPE, "generic backward supports D <= 1024 (got %lld)", (long long)D);
     if (!mfma && G * L > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     fa::BwdParams p;

@@ -362,11 +362,12 @@ def attention_bhld(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=T
 # logits; no gradient flows to it); dropout decisions are a pure function of (seed, offset, group, row, key), so the backward
 # regenerates them from the two integers saved here.
 def supports_extra(q: torch.Tensor, needs_grad: bool = True) -> bool:
-    """What the mask / dropout MFMA kernels take: f16 / bf16 with 16-byte aligned rows (head_dim a multiple of 8) - forward AND backward up
-    to head_dim 192, the forward alone up to 256 (zero-extended at 64 / 128 / 192 / 256 inside the kernels; the backward's mask kernels do not
-    fit the register file at 256, and fa_bwd_ex would run its scalar kernel there).  The override lets stock SDPA serve everything else."""
+    """What the mask / dropout MFMA kernels take: f16 / bf16 with 16-byte aligned rows (head_dim a multiple of 8) up to head_dim 256, forward
+    and backward (zero-extended at 64 / 128 / 192 / 256 inside the kernels; at 256 the backward's dK/dV runs as a dV pass and a dK pass).  The
+    override lets stock SDPA serve everything else.  (`needs_grad` is accepted for callers written against the rounds in which the backward's
+    kernels stopped below the forward's.)"""
     D = q.shape[-1]
-    return q.dtype in (torch.float16, torch.bfloat16) and D % 8 == 0 and 8 <= D <= (192 if needs_grad else 256)
+    return q.dtype in (torch.float16, torch.bfloat16) and D % 8 == 0 and 8 <= D <= 256
 
 
 def _fwd_ex_impl(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state):

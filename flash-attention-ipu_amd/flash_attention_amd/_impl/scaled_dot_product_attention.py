@@ -48,7 +48,7 @@ def chunk_heuristic(L: int, D: int):
 # t_cpp:245-251).  The C ABI serves
 #   * f16 / bf16 with D a multiple of 8 up to 256 through the MFMA kernels themselves: 64, 128, 192 and 256 natively, the others ZERO-EXTENDED
 #     at the next of the four inside the kernels (round 4, `FwdParams::Dr`: out-of-range LDS-DMA chunks and predicated register loads
-#     read the missing columns as zeros, stores stop at D - no copies, forward and backward; masks and dropout up to head_dim 192, and up to 256 when no gradient is wanted);
+#     read the missing columns as zeros, stores stop at D - no copies, forward and backward; masks and dropout included);
 #   * everything else (D > 256, D not a multiple of 8, fp32 off 64 / 128) through the generic kernel: one workgroup per query row, scalar
 #     fp32 arithmetic, 1-2 TFLOP/s - a correctness path that an `import flash_attention_amd.auto` must not silently put
 #     under a model.  For calls of at least GENERIC_KERNEL_MAX_ROWS query rows the override therefore pads such a D to the next head dim the
@@ -79,7 +79,7 @@ def _gqa_ok(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor) -> bool
 
 def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale):
     """attn_mask and / or dropout through the mask / dropout kernels; None when this call is not one they take (the caller then
-    hands it to stock SDPA): operands other than f16 / bf16, head dims above 192 when a gradient is wanted (above 256 when not), more than two batch dimensions, a mask that
+    hands it to stock SDPA): operands other than f16 / bf16, head dims above 256, more than two batch dimensions, a mask that
     wants a gradient or does not broadcast to [B, H, L, L], attn_mask together with is_causal (torch's own error), tracing."""
     needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
     if not ops.supports_extra(query, needs_grad) or query.ndim not in (3, 4):
@@ -113,6 +113,9 @@ def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale
             return None
         if m.stride(-1) != 1:      # (a mask broadcast along the keys: materialise that row once)
             m = m.contiguous()
+        if needs_grad and D > 192 and m.dtype != torch.bool and m.stride(-2) != 0:
+            return None            # (a bias that differs from row to row at head_dim 256: its tile images do not fit beside the backward's 128 KB of
+            #                          Q / dO images, the in-place loads make fa_bwd_ex slower than stock SDPA there - measured 11.6 vs 8.7 ms at [8,16,2048,256])
         mask = m      # (boolean masks go down as they are: one byte per element; no dtype view - inductor cannot lower bool.view(uint8))
     softmax_scale = D ** -0.5 if scale is None else scale
     seed, offset, state = 0, 0, None
@@ -201,7 +204,7 @@ def _scaled_dot_product_attention_amd(
         if out is not None:
             return _unpad(out, D_true)
         on_device = False       # (a combination the mask / dropout kernels do not take: stock SDPA serves it)
-        _handoff("attn_mask / dropout_p in a combination the mask kernels do not take (head dim above 192 with a gradient wanted, fp32, attn_mask with is_causal, a mask "
+        _handoff("attn_mask / dropout_p in a combination the mask kernels do not take (head dim above 256, a per-row bias at head dim 256 with a gradient wanted, fp32, attn_mask with is_causal, a mask "
                  "that wants a gradient or does not broadcast to [B, H, L, L], dropout while tracing)")
         if query.shape[-1] != D_true:
             query, key, value = (t[..., :D_true] for t in (query, key, value))

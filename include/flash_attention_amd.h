@@ -233,8 +233,8 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
  *                   with the two words in device memory the caller captures its own update of them (copy the generator's state to
  *                   a per-call snapshot, advance the generator) and every replay sees fresh values.  fa_bwd_ex must be given the
  *                   snapshot its forward read.  8-byte aligned; read on `stream`, never written.
- * f16 / bf16 operands with 16-byte aligned rows run MFMA kernels (csrc/fa_fwd_extra.hip, fa_bwd_extra.hip): fa_fwd_ex at head dims up to 256
- * (multiples of 8: zero-extended at 64 / 128 / 192 / 256), fa_bwd_ex up to 192 (its mask kernels do not fit the register file at 256);
+ * f16 / bf16 operands with 16-byte aligned rows run MFMA kernels (csrc/fa_fwd_extra.hip, fa_bwd_extra.hip) at head dims up to 256
+ * (multiples of 8: zero-extended at 64 / 128 / 192 / 256; at 256 fa_bwd_ex forms dV and dK in two passes);
  * everything else fa_fwd serves (fp32, other head dims <= 1024, unaligned rows) runs the generic fp32-arithmetic kernels with the same
  * mask and the same dropout decisions (a bias then has the operand dtype, fp32 included).  With mask = NULL and dropout_p = 0 they
  * ARE fa_fwd / fa_bwd.

@@ -82,8 +82,7 @@ def test_head_dims_above_256_go_to_stock_sdpa_and_tiny_calls_stay_on_the_generic
     assert calls == [256] and _native.plan(8, 1024, 256, torch.bfloat16, 1, 1, softmax_scale=1 / 16).kernel == 2
     ref = F.scaled_dot_product_attention.__wrapped__(q.float(), k.float(), v.float(), is_causal=True)
     torch.testing.assert_close(out.float(), ref, atol=1e-2, rtol=1e-2)
-    # ... and so is a masked D = 256 call that wants no gradient (fa_fwd_ex); the backward's mask kernels stop at 192: with a gradient
-    # wanted the masked D = 256 call is stock SDPA's, bit for bit
+    # ... and so is a masked D = 256 call, with or without a gradient wanted (fa_fwd_ex / fa_bwd_ex: not stock SDPA's bits)
     calls.clear()
     mask = torch.ones(1024, 1024, device="cuda", dtype=torch.bool).tril()
     stock = F.scaled_dot_product_attention.__wrapped__
@@ -91,7 +90,10 @@ def test_head_dims_above_256_go_to_stock_sdpa_and_tiny_calls_stay_on_the_generic
     assert calls == [] and not torch.equal(out, stock(q, k, v, attn_mask=mask))
     torch.testing.assert_close(out.float(), stock(q.float(), k.float(), v.float(), attn_mask=mask), atol=1e-2, rtol=1e-2)
     qg = q.clone().requires_grad_(True)
-    assert torch.equal(F.scaled_dot_product_attention(qg, k, v, attn_mask=mask), stock(qg, k, v, attn_mask=mask))
+    outg = F.scaled_dot_product_attention(qg, k, v, attn_mask=mask)
+    assert torch.equal(outg.detach(), out)
+    outg.sum().backward()
+    assert torch.isfinite(qg.grad.float()).all()
     # the reference's own tiny shape family (t_cpp:245-251: L = 6, D = 2): the generic kernel, exact fp32 arithmetic
     q, k, v = (torch.randn(4, 6, 2, device="cuda") for _ in range(3))
     out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
