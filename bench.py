@@ -167,12 +167,36 @@ def cpu_baseline(L, D, budget_s=9.0):
     }
 
 
-def smi_clock_mhz(index):
-    """Highest sclk level rocm-smi lists as supported for device `index`, in MHz, or None.  rocm-smi is a script (a fork + exec): it is asked BEFORE this
-    process makes its first HIP call - a GPU box refuses an exec from a process that has initialised the GPU - and not at all under
-    rocprofv3, whose preloaded tool initialises the GPU before main()."""
-    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+def tool_preloaded(env=None) -> bool:
+    """True when ANYTHING is preloaded into this process or a ROCm tool interface is configured: a profiler's preloaded library (rocprofv3
+    with --pmc does) initialises the GPU before main(), and a GPU box refuses a fork + exec from a process that has - 24 refused `execvp`
+    in round 5 (gpurun_out/.graft_exec_refused).  Deliberately broad: any non-empty LD_PRELOAD, HSA_TOOLS_LIB, any ROCP_* / ROCPROFILER_* /
+    ROCPROF_* / ROCTRACER_* variable - not a match on the names one SDK version happens to use."""
+    env = os.environ if env is None else env
+    if env.get("LD_PRELOAD", "").strip() or env.get("HSA_TOOLS_LIB", "").strip():
+        return True
+    return any(k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_", "ROCTRACER_")) for k in env)
+
+
+def sysfs_max_sclk_mhz(index, root="/sys/class/drm"):
+    """Highest engine-clock level of the index-th AMD GPU from sysfs (`pp_dpm_sclk`: "0: 500Mhz\n1: 2400Mhz *"): a FILE READ - no child
+    process, so it is safe under a profiler and after the first HIP call.  None where the file is absent or unreadable."""
+    try:
+        cards = sorted((p for p in pathlib.Path(root).glob("card[0-9]*") if (p / "device" / "pp_dpm_sclk").exists()),
+                       key=lambda p: int(re.sub(r"\D", "", p.name) or 0))
+        vals = [int(v) for v in re.findall(r"(\d+)\s*Mhz", (cards[index] / "device" / "pp_dpm_sclk").read_text(), re.I)]
+        return max(vals) if vals else None
+    except (OSError, IndexError, ValueError):
         return None
+
+
+def smi_clock_mhz(index):
+    """Engine clock (top sclk level) of device `index` in MHz, or None - decoration for `config.device`, never a measurement.  sysfs first
+    (no child process at all); `rocm-smi -s` - a script, i.e. a fork + exec - only when nothing is preloaded and no tool interface is
+    configured (tool_preloaded), and only BEFORE this process makes its first HIP call (main() asks first thing)."""
+    mhz = sysfs_max_sclk_mhz(index)
+    if mhz is not None or tool_preloaded():
+        return mhz
     try:   # the highest SUPPORTED sclk level (`--showclocks` reports the current speeds: an idle device shows 95 MHz there, and its 2 000 MHz is the memory clock)
         return parse_max_sclk(subprocess.run(["rocm-smi", "-d", str(index), "-s"], capture_output=True, text=True, timeout=20).stdout)
     except Exception:  # noqa: BLE001
@@ -383,6 +407,131 @@ def secondary_gpt2_forward(dev, batch=8, steps=10, warmup=3):
             "shape": f"GPT-2 small fwd, B={batch} T={T} 12 layers x 12 heads, bf16 autocast, through flash_attention_amd.auto"}
 
 
+def strong_record(name, ctx, steps, warmup, slabs, gather):
+    """A strong-scaling config (BASELINE configs[4]: `cfg5`) as ONE compact record, measured the way the `--config cfg5` headline is:
+    CONFIGS[name] groups IN TOTAL, G/W per rank, `slabs` launches per step through `SlabGather` (slab-cyclic ownership, the gather of
+    slab s under the kernel of slab s + 1), K steps between barrier + synchronize, maximum over ranks.  EVERY rank calls this (it
+    carries collectives); every rank returns the same record.
+
+      value                whole-job TFLOP/s on 2 G L^2 D, exchange included          ms_per_step   the step it comes from
+      kernel_only_value    W x the rate of a gather-free repeat of the same launches  exchange_only_ms   the step's `slabs` gathers alone
+      achieved_GBps_per_link   one shard per link and direction / exchange_only_ms    expected_link_bound_ms   shard / 76 GB/s
+      n1_anchor_kernel_tflops  this GPU's kernel-only rate on the launch shape a ONE-GPU run of the config uses (G_total / slabs groups)
+      scaling_efficiency       value / (W x anchor);  kernel_scaling_efficiency = kernel_only_value / (W x anchor)
+    At W = 1 (`cfg5_full`, the anchor of the 1/2/4/8 curve) nothing is exchanged and the anchor is the run itself."""
+    torch, dist, dev, world, rank, Ev, sync = (ctx[k] for k in ("torch", "dist", "dev", "world", "rank", "Ev", "sync"))
+    import flash_attention_amd as fa
+    from flash_attention_amd._impl import _native
+    from flash_attention_amd.distributed import SlabGather, select_gather_mode
+
+    Gc, L, D, dname, (nq, nk) = CONFIGS[name]
+    if Gc % (world * slabs) != 0:
+        raise ValueError(f"{name}: {Gc} groups do not split over {world} ranks x {slabs} slabs")
+    G, dtype = Gc // world, ctx["DT"][dname]
+    gs = G // slabs
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    qkv = torch.empty(3, G, L, D, dtype=dtype, device=dev)
+    for t3 in range(3):                       # (slab by slab: the fp32 draw of the whole shard would be twice its size again)
+        for s_ in range(slabs):
+            qkv[t3, s_ * gs:(s_ + 1) * gs] = torch.randn(gs, L, D, device=dev, generator=gen).to(dtype)
+    do_gather = ctx["exchange"] and ctx["dist_on"]
+    mode, table, selection = gather, None, "forced (--gather)"
+    if do_gather and gather == "auto":
+        q_sel = qkv[:, :gs].contiguous()
+        step_sel = lambda: fa.flash_attention_qkv_packed(q_sel, nq, nk)   # noqa: E731
+        try:
+            mode, table = select_gather_mode(step_sel(), step=step_sel, reps=3)
+            selection = "auto: fastest kernel + exchange step on this config's slab (maximum over ranks)"
+        except Exception as e:  # noqa: BLE001
+            mode, selection = "allgather", f"auto FAILED ({type(e).__name__}: {e})"[:160] + " -> all-gather"
+        del q_sel
+    elif gather == "auto":
+        mode = "allgather"
+    sg = SlabGather(G, L, D, dtype, dev, slabs=slabs, mode=mode, gather=do_gather, gather_at_world1=ctx["force_dist"])
+
+    def barrier():
+        if ctx["dist_on"]:
+            dist.barrier()
+
+    for _ in range(max(1, warmup)):
+        sg.run(qkv, nq, nk, wait=False)
+    sg.wait()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sg.run(qkv, nq, nk, wait=False)
+    sg.wait()
+    sync()
+    barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    def timed(fn, n):
+        fn()
+        sync()
+        e0, e1 = Ev(), Ev()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        sync()
+        return e0.elapsed_time(e1) / n
+
+    n_k = max(3, steps // 2)
+    kernel_ms = elapsed / steps * 1e3
+    x_ms = 0.0
+    if sg.gather:      # the same launches with no exchange, and the step's exchanges with no launches
+        sgk = SlabGather(G, L, D, dtype, dev, slabs=slabs, gather=False)
+        kernel_ms = timed(lambda: sgk.run(qkv, nq, nk), n_k)
+        del sgk
+        from flash_attention_amd.distributed import gather_output
+
+        def exchanges():
+            for s_ in range(slabs):
+                gather_output(sg.local[s_], out=sg.fulls[0][s_], mode=mode)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            exchanges()
+        sync()
+        x_ms = (time.perf_counter() - t1) / 3 * 1e3
+    anchor_ms, ga = kernel_ms, gs
+    if world > 1:      # the launch a one-GPU run of this config makes: G_total / slabs groups (or this rank's whole shard if that is smaller)
+        ga = min(G, Gc // slabs)
+        qa = qkv[:, :ga].contiguous()
+        anchor_ms = timed(lambda: fa.flash_attention_qkv_packed(qa, nq, nk), max(3, min(8, steps)))
+        del qa
+    red = torch.tensor([elapsed, kernel_ms, x_ms, anchor_ms], dtype=torch.float64, device=ctx["reduce_dev"])
+    if ctx["dist_on"]:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms, x_ms, anchor_ms = red.tolist()
+    flops_total = 2.0 * Gc * L * L * D
+    value = flops_total * steps / elapsed / 1e12
+    kernel_only = world * 2.0 * G * L * L * D / (max(kernel_ms, 1e-9) * 1e-3) / 1e12
+    anchor = 2.0 * ga * L * L * D / (max(anchor_ms, 1e-9) * 1e-3) / 1e12 if world > 1 else kernel_only
+    shard_bytes = G * L * D * qkv.element_size()
+    plan = _native.plan(gs, L, D, dtype, nq, nk) if dev.type == "cuda" else None
+    rec = {"value": round(value, 2), "unit": "TFLOP/s", "scaling": "strong", "n_gpus": world, "steps": steps,
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "kernel_only_value": round(kernel_only, 2),
+           "frac": round(value / (world * PEAK_TFLOPS), 4), "ms": round(elapsed / steps * 1e3, 4),
+           "kernel": kernel_name(plan).replace("fa_", "").replace("_kernel", "") if plan is not None else "cpu",
+           "exchange_only_ms": round(x_ms, 4) if sg.gather else None,
+           "achieved_GBps_per_link": round(shard_bytes / (max(x_ms, 1e-9) * 1e-3) / 1e9, 2) if sg.gather and world > 1 else None,
+           "expected_link_bound_ms": round(shard_bytes / 76e9 * 1e3, 3) if world > 1 else None,
+           "n1_anchor_kernel_tflops": round(anchor, 2),
+           "scaling_efficiency": round(value / (world * anchor), 4) if anchor > 0 else None,
+           "kernel_scaling_efficiency": round(kernel_only / (world * anchor), 4) if anchor > 0 else None,
+           "exchange_selected": mode if sg.gather else None, "exchange_selection": selection if sg.gather else None,
+           "groups_total": Gc, "groups_per_gpu": G, "slabs": slabs, "groups_per_launch": gs,
+           "shape_per_gpu": [3, G, L, D], "dtype": dname}
+    if table is not None:
+        rec["gather_modes"] = {m: [round(r["exchange_only_ms"], 4), round(r["ms_per_step"], 4)] for m, r in table.items()}
+    del sg, qkv
+    return {k: v for k, v in rec.items() if v is not None}      # (a one-GPU record has no exchange fields)
+
+
 def kernel_name(plan):
     return {0: "fa_fwd_dma_kernel", 1: "fa_fwd_generic_kernel", 2: "fa_fwd_pipe_kernel", 3: "fa_fwd_f32_kernel",
             4: "fa_fwd_pipe16_kernel", 6: "fa_fwd_kh_kernel"}[plan.kernel]
@@ -428,6 +577,7 @@ def main():
                     help="N>1: how O is moved - auto (default): RCCL all-gather, direct point-to-point gather and gather to rank 0 are timed on "
                          "the real shard before the ramp, every rank takes the all-reduced maximum and the fastest runs the headline; or force one")
     ap.add_argument("--slabs", type=int, default=8, help="cfg5: slabs per rank (gather of slab s under the kernel of slab s+1)")
+    ap.add_argument("--no-strong", action="store_true", help="N>1: skip the BASELINE configs[4] strong-scaling record (secondary.cfg5_strong) after the weak headline")
     ap.add_argument("--backward", action="store_true", help="N=1: time fa_bwd (dQ + dK/dV kernels) of the config instead of the forward")
     ap.add_argument("--no-probes", action="store_true",
                     help="skip the MFMA-peak probes, the clock sampler and the per-step event pass after the timed region: the LAST --steps "
@@ -439,6 +589,7 @@ def main():
         print(csrc_fingerprint(args.print_csrc_fingerprint or None))
         return 0
 
+    gather_requested = args.gather
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)          # (nothing above has imported torch.cuda or made a HIP call)
 
@@ -475,7 +626,7 @@ def main():
         local_rank = 0
     if rehearse_cpu:
         CONFIGS["tiny"] = (4, 64, 16, "f32", (2, 2))
-        CONFIGS["tiny_strong"] = (16, 64, 16, "f32", (2, 2))
+        CONFIGS["tiny_strong"] = (max(16, 2 * world * args.slabs), 64, 16, "f32", (2, 2))
         STRONG.add("tiny_strong")
         args.config = "tiny_strong" if args.config in STRONG else "tiny"
         args.no_probes = args.no_secondary = args.no_cpu_baseline = True
@@ -563,8 +714,9 @@ def main():
             try:
                 q_sel = qkv[:, :g_launch].contiguous() if strong else qkv
                 step_sel = (lambda: fa.flash_attention_qkv_packed(q_sel, nq, nk)) if op_fn is None else op_fn
-                args.gather, exchange_table = select_gather_mode(step_sel(), step=step_sel, reps=max(2, min(args.steps, 5)))
-                exchange_selection = "auto: fastest kernel + exchange step of the three, timed before the ramp (maximum over ranks)"
+                # ("root" is timed for information only: it completes rank 0's buffer alone, so it never runs the headline unless forced)
+                args.gather, exchange_table = select_gather_mode(step_sel(), step=step_sel, reps=max(2, min(args.steps, 5)), also_time=("root",))
+                exchange_selection = "auto: fastest kernel + exchange step of all-gather / direct (every rank gets all of O), timed before the ramp (maximum over ranks)"
             except Exception as e:  # noqa: BLE001  (the selection must never cost the headline)
                 args.gather = "allgather"
                 exchange_selection = f"auto FAILED ({type(e).__name__}: {e})"[:200] + " -> all-gather"
@@ -576,7 +728,8 @@ def main():
     record = [False]
 
     if strong:
-        sg = SlabGather(G, L, D, dtype, dev, slabs=args.slabs, mode=args.gather, gather=do_gather and not use_gloo)
+        sg = SlabGather(G, L, D, dtype, dev, slabs=args.slabs, mode=args.gather, gather=do_gather and not use_gloo,
+                        gather_at_world1=os.environ.get("FA_BENCH_FORCE_DIST") == "1")
 
         def step(i):
             if record[0]:
@@ -711,6 +864,29 @@ def main():
         t = tc
     elapsed, kernel_ms = t[0].item(), t[1].item()
 
+    ctx = {"torch": torch, "dist": dist, "dev": dev, "world": world, "rank": rank, "Ev": Ev, "sync": sync, "DT": DT, "dist_on": dist_on,
+           "exchange": not args.no_gather and not use_gloo, "force_dist": os.environ.get("FA_BENCH_FORCE_DIST") == "1",
+           "reduce_dev": "cpu" if (use_gloo or rehearse_cpu) else dev}
+    # ---- N > 1, the driver's plain `bench.py --gpus N`: BASELINE configs[4] (strong: 2048 groups in total, SlabGather, its own exchange
+    # selection) right after the weak headline, in the same launch and process group -> secondary.cfg5_strong.  Every rank runs it.
+    cfg5_strong = None
+    if dist_on and not strong and op_fn is None and not args.no_strong:
+        drain()
+        name5 = "tiny_strong" if rehearse_cpu else "cfg5"
+
+        def strong_gave_up():      # a stuck collective must not cost the weak headline, which is already measured
+            if rank == 0 and line_box[0] is not None:
+                line_box[0].setdefault("secondary", {})["cfg5_strong"] = {"error": "did not finish within 300 s (a rank left a collective?)"}
+                emit_once(line_box[0])
+            sys.stdout.flush()
+            os._exit(4)
+
+        strong_watchdog = threading.Timer(300.0, strong_gave_up)
+        strong_watchdog.daemon = True
+    else:
+        strong_watchdog = None
+    line_box = [None]
+
     rc = 0
     line = None
     shard_bytes = G * L * D * qkv.element_size() if dist_on else 0
@@ -790,6 +966,10 @@ def main():
             "expected_link_bound_ms": round(shard_bytes / 76e9 * 1e3, 3) if do_gather else None,
             "pct_mfma_peak": round(100.0 * total_tflops / (world * PEAK_TFLOPS), 2),
             "kernel_only_value": round(world * achieved, 2),
+            # value / (N x the one-GPU kernel-only rate of this launch shape, measured in THIS run on every rank: events around the launches,
+            # slowest rank): how much of N kernels' worth of work the job delivers once the exchange is in (1.0 = the exchange is free)
+            "n1_anchor_kernel_tflops": round(achieved, 2),
+            "scaling_efficiency": round(total_tflops / (world * achieved), 4) if achieved > 0 else None,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": traffic_note if traffic is None else "rocprofv3 PMC passes (profiles/), FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE",
@@ -817,6 +997,14 @@ def main():
                         sec[name] = secondary_attention(name, dev)
                     except Exception as e:  # noqa: BLE001  (a secondary record must never cost the headline)
                         sec[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            # the one-GPU anchor of BASELINE configs[4]'s 1/2/4/8 strong-scaling curve: all 2 048 groups on this GPU, the same slab launches
+            try:
+                torch.cuda.empty_cache()
+                sec["cfg5_full"] = strong_record("cfg5", ctx, steps=5, warmup=1, slabs=args.slabs, gather="auto")
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                sec["cfg5_full"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            sec["cfg3"] = sec.pop("cfg3")          # (BASELINE configs stay last among the forward records)
             try:
                 sec["cfg2_bwd"] = secondary_attention("cfg2", dev, steps=10, warmup=3, backward=True)
             except Exception as e:  # noqa: BLE001
@@ -838,10 +1026,19 @@ def main():
         if len(json.dumps(line)) > 7600 and isinstance(line.get("secondary"), dict):
             for v in line["secondary"].values():
                 if isinstance(v, dict):
-                    for k2 in ("median_ms", "min_ms", "alg_bytes", "shape", "tile"):
+                    for k2 in ("median_ms", "min_ms", "alg_bytes", "shape", "tile", "shape_per_gpu", "unit", "steps", "ms"):
                         v.pop(k2, None)
         if len(json.dumps(line)) > 7600:
             line.pop("ramp", None)
+    line_box[0] = line
+    if strong_watchdog is not None:
+        strong_watchdog.start()
+        try:
+            cfg5_strong = strong_record(name5, ctx, steps=max(3, min(args.steps, 10)), warmup=2, slabs=args.slabs, gather=gather_requested)
+        except Exception as e:  # noqa: BLE001  (deterministic host-side failures - a group count that does not divide - hit every rank alike)
+            cfg5_strong = {"error": f"{type(e).__name__}: {e}"[:200]}
+        finally:
+            strong_watchdog.cancel()
     # N > 1: the exchange table of the selection above (per mode: the exchange alone - what the links deliver - and kernel + exchange per
     # step, overlapped the way the headline overlaps them; maxima over ranks)
     gather_modes = None
@@ -855,11 +1052,13 @@ def main():
                 "received_bytes_busiest_rank": (world - 1) * (shard_bytes // launches_per_step),
                 # one shard per link and direction: what one xGMI link carried (0 at world size 1: nothing crosses a link)
                 "achieved_GBps_per_link": round((shard_bytes // launches_per_step) / (max(x_ms, 1e-9) * 1e-3) / 1e9, 2) if world > 1 else 0.0,
-                "selected": mode == args.gather,
+                "selected": mode == args.gather, "eligible": bool(rec_.get("eligible", True)),   # ("root" completes rank 0's buffer only: timed, never auto-selected)
             }
     if rank == 0:
         if gather_modes is not None:
-            line["secondary"] = {"gather_modes": gather_modes}
+            line.setdefault("secondary", {})["gather_modes"] = gather_modes
+        if cfg5_strong is not None:
+            line.setdefault("secondary", {})["cfg5_strong"] = cfg5_strong
         emit_once(line)
     if dist_on:
         dist.barrier()

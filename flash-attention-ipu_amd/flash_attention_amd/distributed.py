@@ -26,6 +26,9 @@ from ._impl import _native
 from ._impl.flash_attention_qkv_packed import flash_attention_qkv_packed
 
 GATHER_MODES = ("allgather", "direct", "root")
+# the exchanges that leave the FULL [G, L, D] on every rank - the only ones an automatic selection may return: "root" moves 1/W of the
+# traffic and completes rank 0's buffer alone, so it is not interchangeable with the other two (and would always win a timing contest)
+FULL_GATHER_MODES = ("allgather", "direct")
 
 
 def shard_range(num_groups: int, rank: int, world_size: int) -> Tuple[int, int]:
@@ -85,8 +88,15 @@ def gather_output(out_local: torch.Tensor, group=None, out: Optional[torch.Tenso
     return out
 
 
-def select_gather_mode(out_local: torch.Tensor, step=None, group=None, reps: int = 3, clock=None, modes=GATHER_MODES):
-    """Measure the ways to move O on THIS machine and agree on the fastest: (mode, table).
+def select_gather_mode(out_local: torch.Tensor, step=None, group=None, reps: int = 3, clock=None, modes=FULL_GATHER_MODES,
+                       also_time=()):
+    """Measure the ways to move O on THIS machine and agree on the fastest of `modes`: (mode, table).
+
+    `modes` defaults to the two exchanges after which EVERY rank holds the full [G, L, D] (what `flash_attention_qkv_packed_sharded` and
+    `SlabGather` promise); the returned mode is always one of them.  `also_time` (e.g. ("root",)) adds informational rows to the table
+    that are timed the same way but never selected: "root" leaves W - 1 ranks with their own shard only and moves 1/W of the bytes, so
+    ranking it against the full gathers would compare different results.  Passing modes=GATHER_MODES is the explicit opt-in to let
+    "root" win (a caller that needs O on rank 0 only).
 
     xGMI gives every GPU pair a link of its own, so the direct point-to-point gather should beat a ring all-gather -
     but RCCL's all-gather is not necessarily a ring, and which one wins is a property of the node, so it is timed, not assumed.
@@ -105,7 +115,9 @@ def select_gather_mode(out_local: torch.Tensor, step=None, group=None, reps: int
     bufs = [torch.empty((world * out_local.shape[0], *out_local.shape[1:]), dtype=out_local.dtype, device=out_local.device) for _ in range(2)]
     reps = max(1, int(reps))
     times = []
-    for mode in modes:
+    modes = tuple(modes)
+    timed = modes + tuple(m for m in also_time if m not in modes)
+    for mode in timed:
         gather_output(out_local, group=group, out=bufs[0], mode=mode)            # warm-up (connections, first-use setup)
         sync()
         dist.barrier(group)
@@ -134,7 +146,8 @@ def select_gather_mode(out_local: torch.Tensor, step=None, group=None, reps: int
     tm = torch.tensor(times, dtype=torch.float64, device=out_local.device)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX, group=group)
     tm = tm.tolist()
-    table = {m: {"exchange_only_ms": tm[2 * i], "ms_per_step": tm[2 * i + 1] if step is not None else None} for i, m in enumerate(modes)}
+    table = {m: {"exchange_only_ms": tm[2 * i], "ms_per_step": tm[2 * i + 1] if step is not None else None, "eligible": m in modes}
+             for i, m in enumerate(timed)}
     key = "ms_per_step" if step is not None else "exchange_only_ms"
     best = min(modes, key=lambda m: (table[m][key], modes.index(m)))
     return best, table
@@ -143,7 +156,9 @@ def select_gather_mode(out_local: torch.Tensor, step=None, group=None, reps: int
 def flash_attention_qkv_packed_sharded(qkv_local: torch.Tensor, num_chunks_q: int, num_chunks_kv: int,
                                        group=None, gather: bool = True, mode: str = "allgather") -> torch.Tensor:
     """Each rank passes ITS shard `qkv_local` [3, G/W, L, D]; returns the full [G, L, D] on every rank
-    (or the local [G/W, L, D] with gather=False).  No collective touches Q, K or V."""
+    (or the local [G/W, L, D] with gather=False).  No collective touches Q, K or V.
+    mode "root" is the one exception to "on every rank": only rank 0's result is complete, the other ranks' buffers hold their own
+    shard at its place and uninitialised memory elsewhere."""
     out_local = flash_attention_qkv_packed(qkv_local, num_chunks_q, num_chunks_kv)
     if not gather or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return out_local
@@ -167,12 +182,13 @@ class SlabGather:
     of TWO buffers used alternately: a tensor returned by `run` stays valid until the run after the next one starts."""
 
     def __init__(self, groups_local: int, L: int, D: int, dtype, device, slabs: int = 4, group=None,
-                 mode: str = "allgather", gather: bool = True):
+                 mode: str = "allgather", gather: bool = True, gather_at_world1: bool = False):
         if groups_local % slabs != 0:
             raise ValueError(f"local groups {groups_local} must be divisible by slabs={slabs}")
         self.group, self.mode, self.slabs = group, mode, slabs
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.gather = gather and self.world > 1
+        # (gather_at_world1: run the exchange calls even when this rank is alone - a copy - so that a one-GPU box exercises the backend's path)
+        self.gather = gather and (self.world > 1 or (gather_at_world1 and dist.is_initialized()))
         self.gs = groups_local // slabs
         self.local = torch.empty((slabs, self.gs, L, D), dtype=dtype, device=device)
         self.fulls = [torch.empty((slabs, self.world * self.gs, L, D), dtype=dtype, device=device) for _ in range(2)] if self.gather else None

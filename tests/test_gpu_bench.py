@@ -34,7 +34,14 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_every_baseline_con
     for name in ("cfg3", "cfg5_shard", "cfg2_f16", "cfg4_attn", "cfg2_sdpa", "cfg2_bwd", "cfg4_gpt2_fwd", "small_grid", "l1024", "nb_65536", "few_groups"):
         assert name in others and "error" not in others[name], (name, others.get(name))
         assert name in rec["secondary"]
-    assert list(rec["secondary"])[-4:-2] == ["cfg5_shard", "cfg3"], "the BASELINE configs come last among the forward records"
+    assert list(rec["secondary"])[-5:-2] == ["cfg5_shard", "cfg5_full", "cfg3"], "the BASELINE configs come last among the forward records"
+    # round-5 verdict, item 1: the one-GPU anchor of BASELINE configs[4]'s strong-scaling curve - all 2 048 groups on this GPU, the slab launches of the N > 1 flow
+    full = rec["secondary"]["cfg5_full"]
+    assert "error" not in full, full
+    assert full["n_gpus"] == 1 and full["groups_total"] == full["groups_per_gpu"] == 2048 and full["slabs"] == 8 and full["groups_per_launch"] == 256
+    assert full["value"] > 500 and 0.9 < full["scaling_efficiency"] <= 1.0 + 1e-6 and abs(full["frac"] - full["value"] / 2500.0) < 1e-3
+    assert others["cfg5_full"]["tflops"] == full["value"]
+    assert 0.9 < rec["scaling_efficiency"] <= 1.0 + 1e-6 and rec["n1_anchor_kernel_tflops"] == roof["achieved"]
     g4 = others["cfg4_gpt2_fwd"]      # the GPT-2 step also replays from a HIP graph (the override's launches are capture-safe)
     assert g4["graph_ms"] and g4["graph_ms"] < 1.3 * g4["step_ms"]
     assert others["cfg3"]["kernel"] == "fwd_pipe16" and others["cfg3"]["tflops"] > 0 and others["cfg2_f16"]["frac"] > 0

@@ -2,6 +2,7 @@
 (loads, exports every declared symbol, validates arguments).  No GPU compute calls."""
 
 import ctypes
+import os
 import json
 import math
 import pathlib
@@ -431,3 +432,55 @@ def test_bench_reads_the_engine_clock_from_the_supported_sclk_levels():
             "GPU[0]\t\t: 1: 2400Mhz\nGPU[0]\t\t: Supported socclk frequencies on GPU0\nGPU[0]\t\t: S: 38Mhz *\nGPU[0]\t\t: 0: 1200Mhz\n")
     assert bench.parse_max_sclk(text) == 2400
     assert bench.parse_max_sclk("no such block") is None
+
+
+def _load_bench():
+    import importlib.util
+    import pathlib
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", pathlib.Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+@pytest.mark.parametrize("var,value", [("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so"), ("LD_PRELOAD", "/some/other/tool.so"),
+                                       ("HSA_TOOLS_LIB", "libsomething.so"), ("ROCP_TOOL_LIBRARIES", "x"), ("ROCPROFILER_REGISTER_FORCE_LOAD", "1"),
+                                       ("ROCPROF_COUNTERS", "pmc: SQ_WAVES"), ("ROCPROFILER_SDK_ANYTHING_NEW", "1"), ("ROCTRACER_DOMAIN", "hip")])
+def test_bench_never_spawns_a_child_when_a_tool_is_preloaded(monkeypatch, tmp_path, var, value):
+    """Round-5 verdict, item 5: under rocprofv3 (whose preloaded library initialises the GPU before main()) bench.py must not fork + exec
+    `rocm-smi` - the GPU box refuses that exec.  Whatever the preload or tool variable is called, no subprocess is started; the engine clock
+    then comes from sysfs (a file read) or is None."""
+    import subprocess
+
+    bench = _load_bench()
+    for k in list(os.environ):
+        if k in ("LD_PRELOAD", "HSA_TOOLS_LIB") or k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_", "ROCTRACER_")):
+            monkeypatch.delenv(k)
+    assert not bench.tool_preloaded()
+    monkeypatch.setenv(var, value)
+    assert bench.tool_preloaded()
+
+    def refuse(*a, **kw):
+        raise AssertionError(f"bench.py started a child process with {var} set: {a}")
+
+    monkeypatch.setattr(subprocess, "run", refuse)
+    monkeypatch.setattr(subprocess, "Popen", refuse)
+    monkeypatch.setattr(bench, "sysfs_max_sclk_mhz", lambda index: None)      # (no sysfs clock file: the rocm-smi branch would be next)
+    assert bench.smi_clock_mhz(0) is None
+
+
+def test_bench_engine_clock_from_sysfs_needs_no_child_process(monkeypatch, tmp_path):
+    import subprocess
+
+    bench = _load_bench()
+    for i, text in ((1, "0: 500Mhz\n1: 2400Mhz *\n"), (0, "0: 500Mhz *\n1: 2100Mhz\n")):
+        d = tmp_path / f"card{i}" / "device"
+        d.mkdir(parents=True)
+        (d / "pp_dpm_sclk").write_text(text)
+    (tmp_path / "card2" / "device").mkdir(parents=True)       # (a display adapter without the file is skipped)
+    assert bench.sysfs_max_sclk_mhz(0, root=str(tmp_path)) == 2100 and bench.sysfs_max_sclk_mhz(1, root=str(tmp_path)) == 2400
+    assert bench.sysfs_max_sclk_mhz(2, root=str(tmp_path)) is None and bench.sysfs_max_sclk_mhz(0, root=str(tmp_path / "absent")) is None
+    monkeypatch.setattr(bench, "sysfs_max_sclk_mhz", lambda index: 2400)
+    monkeypatch.setattr(subprocess, "run", lambda *a, **kw: (_ for _ in ()).throw(AssertionError("no child process when sysfs answers")))
+    assert bench.smi_clock_mhz(0) == 2400
