@@ -652,7 +652,9 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         unsigned long long st3_;
         FA_STAMP(st3_)
         if (p.stamps != nullptr && lane == 0) {
-            unsigned long long* sp = p.stamps + (((int64_t)g * nslot + qd) * (NWAVES * SPLIT) + wave_all) * 16;
+            // (q-tile subsets: g is the REAL group and qd the group-wide depth - the record index uses the group's real tile count, which the
+            //  buffer covers: G8v * nq_tiles >= G * nq_real)
+            unsigned long long* sp = p.stamps + (((int64_t)g * (p.xs > 1 ? nq_r : nslot) + qd) * (NWAVES * SPLIT) + wave_all) * 16;
             int tot_tiles = 0;   // kv tiles this workgroup streamed (both q tiles of a pair)
             for (int ps = 0; ps < n_pass; ++ps) {
                 const int qi_ = ps == 0 ? nq_r - 1 - qd : qd;

@@ -43,8 +43,9 @@ struct FwdParams {
     int32_t nq_tiles;      // q tiles per group of the block map (with xs > 1: per (group, subset) pair = ceil(nq_real / xs))
     int32_t xs;            // q-tile subsets per group (>= 1).  Groups go to XCDs by index mod 8; a group count that leaves XCDs idle or
                            // unevenly loaded (G = 2: six of eight idle; G = 12: four XCDs with two groups, four with one) is served as
-                           // G xs (group, subset) pairs, xs = 8 / gcd(G, 8): G, G8 and nq_tiles then describe the PAIRS, subset s of a
-                           // group holds its q tiles of depth s, s + xs, ... (depth 0 = the last, heaviest tile) and nq_real its tile count
+                           // G xs (group, subset) pairs - xs the smallest of 2, 4, 8 that wastes under 9 % of the slots, 1 when the L2 budget
+                           // or the tile count forbids subsets (fa_capi.cpp subsets_for): G, G8 and nq_tiles then describe the PAIRS, subset s
+                           // of a group holds its q tiles of depth s, s + xs, ... (depth 0 = the last, heaviest tile), nq_real its tile count
     int32_t nq_real;
     int32_t sched;         // groups per XCD bunch (>= 1): heavy-first order inside a bunch
     int32_t skipmax;       // f16 only: 1 = reference max from the first tile + overflow-triggered redo
@@ -54,6 +55,18 @@ struct FwdParams {
     int32_t perm_n;        // > 0: the first perm_n slots of every XCD run the work item perm[slot] (fa_fwd_dma.hip; fa_capi.cpp balanced_order)
     uint8_t perm[128];
     unsigned long long* stamps;   // measurement builds only (-DFA_STAMPS, scripts/phase_times.py): 16 u64 per wave, else null
+};
+
+// team lists (fa_fwd_tl.hip): a causal head_dim-64 launch as G8 x nw workgroups of two 4-wave teams; workgroup type w of a group runs
+// prog[w][team][0 .. TL_MAXU): units qi | t0 << 8 | t1 << 16 | kind << 24 - q tile qi (128 rows), its 64-key tiles t0 .. t1 - 1, kind 0 = none,
+// 1 = the whole q tile, 2 | 3 = the first | second kv range of a q tile split over the two teams (always a team's LAST unit: the halves
+// fold through LDS after the loop); rounds[w] = the longer team's tile count.  Built by fa_capi.cpp build_team_lists.
+constexpr int TL_MAXW = 16, TL_MAXU = 3;
+struct TlParams {
+    FwdParams p;
+    int32_t nw;                        // workgroup types per group
+    uint8_t rounds[TL_MAXW];
+    uint32_t prog[TL_MAXW][2][TL_MAXU];
 };
 
 // backward (fa_bwd_kernels.hip)
@@ -102,6 +115,7 @@ hipError_t launch_fwd_f32(const FwdParams& p, hipStream_t stream);   // fa_fwd_f
 hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);   // fa_fwd_pipe.hip
 hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream); // fa_fwd_pipe16.hip
 hipError_t launch_fwd_kh(const FwdParams& p, int dtype, int split, hipStream_t stream);             // fa_fwd_kh.hip
+hipError_t launch_fwd_tl(const TlParams& tp, int dtype, hipStream_t stream);                        // fa_fwd_tl.hip
 double probe_mfma_peak(int dtype, int iters, int random_data);
 hipError_t launch_clock_sampler(unsigned long long* out, int spins, hipStream_t stream);   // fa_probe.hip
 

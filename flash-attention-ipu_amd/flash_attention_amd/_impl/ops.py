@@ -302,6 +302,56 @@ class _PackedAttentionFn(torch.autograd.Function):
         return _bwd_qkv_packed_impl(qkv, out, dout, lse), None, None
 
 
+# ---- eager training on [B, H, L, D] views: no reshape, no copies, the caller's layout kept ---------------------------------------------
+# What the override calls for a 4-D query that wants gradients (round-5 verdict, item 3).  The [G, L, D] route above reshapes q, k, v - three
+# autograd view nodes for contiguous operands and three COPIES (plus their backward) for the head-inner slices of a fused [B, T, 3C]
+# projection, nanoGPT's layout - and views the result back.  Here the kernels read the operands through their batch / head strides (as the
+# inference path always did) and write `out`, dQ, dK, dV in the LAYOUT OF THE OPERANDS: a head-inner query gets a head-inner result (the
+# usual `.transpose(1, 2).contiguous()` after attention is then free) and head-inner gradients.  One fp32 allocation carries LSE and the
+# backward's Dsum workspace; dQ, dK, dV are one allocation when query and key / value heads agree.
+def _dense_like(t: torch.Tensor, lead: int = 0) -> torch.Tensor:
+    """an uninitialised tensor of t's shape ([lead,] B, H, L, D) laid out as t is: head-inner if t is, contiguous otherwise"""
+    B, H, L, D = t.shape
+    st = (L * H * D, D, H * D, 1) if t.stride(1) < t.stride(2) else (H * L * D, L * D, D, 1)
+    if lead:
+        return torch.empty_strided((lead, B, H, L, D), (B * H * L * D,) + st, dtype=t.dtype, device=t.device)
+    return torch.empty_strided((B, H, L, D), st, dtype=t.dtype, device=t.device)
+
+
+class _BhldAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal):
+        out = _dense_like(q)
+        q, k, v = _rows(q), _rows(k), _rows(v)
+        B, H, L, _ = q.shape
+        stash = torch.empty((2, B * H, L), dtype=torch.float32, device=q.device)      # [0] LSE, [1] the backward's Dsum workspace
+        if out.numel() > 0:
+            _native.fwd_bhld(q, k, v, out, stash.data_ptr(), num_chunks_q, num_chunks_kv, softmax_scale, causal)
+        ctx.save_for_backward(q, k, v, out, stash)
+        ctx.softmax_scale, ctx.causal = softmax_scale, causal
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, k, v, out, stash = ctx.saved_tensors
+        dout = _rows(dout)
+        if k.shape[1] == q.shape[1] and all(ctx.needs_input_grad[:3]):
+            dq, dk, dv = _dense_like(q, 3).unbind(0)          # (freed together; one allocation)
+        else:
+            dq, dk, dv = _dense_like(q), _dense_like(k), _dense_like(v)
+        if dq.numel() > 0:
+            p0 = stash.data_ptr()
+            _native.bwd_bhld(q, k, v, out, dout, p0, dq, dk, dv, p0 + stash.stride(0) * 4, ctx.softmax_scale, ctx.causal)
+        return dq, dk, dv, None, None, None, None
+
+
+def attention_bhld_train(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
+    """[B, H, L, D] query, [B, H_kv, L, D] key / value -> out [B, H, L, D] in the query's layout, differentiable (eager only: under
+    torch.compile the override keeps the traced custom ops)."""
+    return _BhldAttentionFn.apply(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+
+
 def attention(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=True):
     """[G, L, D] operands -> out [G, L, D], differentiable: eager fast path, custom op under torch.compile."""
     if torch.compiler.is_compiling():
@@ -514,9 +564,14 @@ def init_graph_dropout_state(device=None, seed: Optional[int] = None) -> torch.T
     return st
 
 
+def graph_dropout_state(device) -> Optional[torch.Tensor]:
+    """the device-resident dropout state of `device`, or None while nothing has created it"""
+    return _GRAPH_DROPOUT_STATE.get(_device_index(device))
+
+
 def capture_dropout_state(device, numel: int) -> torch.Tensor:
-    """Inside graph capture: this call's snapshot of the device-resident state (what its kernels read), the live state advanced past the
-    `numel` decisions of the launch - two captured device operations."""
+    """Inside graph capture - a HIP graph or a torch.compile trace: this call's snapshot of the device-resident state (what its kernels
+    read), the live state advanced past the `numel` decisions of the launch - two captured / traced device operations."""
     st = _GRAPH_DROPOUT_STATE.get(_device_index(device))
     if st is None:
         raise RuntimeError("flash_attention_amd: dropout under graph capture needs the device-resident generator state - run one eager "

@@ -12,8 +12,8 @@ Same mechanism, guards, messages and chunk heuristic as the reference override
   * on the GPU the four modes the reference rejects (sdpa.py:21-37) are served instead of raising: is_causal=False, grouped
     K/V heads (with enable_gqa=True, as stock SDPA demands), `attn_mask` (boolean or additive, anything broadcastable to
     [B, H, L, L]) and `dropout_p > 0` - the last two by the mask / dropout kernels (fa_fwd_ex / fa_bwd_ex) for f16 / bf16 at
-    head_dim 64 / 128, by stock SDPA (`orig_fn`) for everything those kernels do not take.  Off the GPU they raise exactly
-    like the reference.
+    every head dim up to 256 that is a multiple of 8 (forward and backward; eager, under HIP-graph capture and under torch.compile), by
+    stock SDPA (`orig_fn`) for what those kernels do not take.  Off the GPU they raise exactly like the reference.
 """
 
 import logging
@@ -80,12 +80,16 @@ def _gqa_ok(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor) -> bool
 def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale):
     """attn_mask and / or dropout through the mask / dropout kernels; None when this call is not one they take (the caller then
     hands it to stock SDPA): operands other than f16 / bf16, head dims above 256, more than two batch dimensions, a mask that
-    wants a gradient or does not broadcast to [B, H, L, L], attn_mask together with is_causal (torch's own error), tracing."""
+    wants a gradient or does not broadcast to [B, H, L, L], attn_mask together with is_causal (torch's own error), dropout traced
+    before the device-resident generator state exists."""
     needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
     if not ops.supports_extra(query, needs_grad) or query.ndim not in (3, 4):
         return None
-    if torch.compiler.is_compiling() and dropout_p > 0.0:
-        return None       # (the generator state is host state: a traced graph gets stock SDPA's dropout; masks trace through fwd_ex)
+    if torch.compiler.is_compiling() and dropout_p > 0.0 and ops.graph_dropout_state(query.device) is None:
+        # torch.compile: the kernels take (seed, offset) from the DEVICE-resident generator state (below), which must exist before the trace -
+        # an H2D copy cannot be traced.  One eager dropout call on the device (a warm-up step) or flash_attention_amd.init_graph_dropout_state()
+        # creates it; until then a traced dropout call is stock SDPA's (once it exists the dictionary guard fails and the call is re-traced).
+        return None
     if attn_mask is not None and (is_causal or attn_mask.requires_grad or not attn_mask.is_cuda):
         return None
     if not (0.0 <= dropout_p < 1.0):
@@ -120,7 +124,11 @@ def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale
     softmax_scale = D ** -0.5 if scale is None else scale
     seed, offset, state = 0, 0, None
     if dropout_p > 0.0:
-        if torch.cuda.is_current_stream_capturing():     # graph capture: (seed, offset) from device memory, fresh on every replay
+        if torch.compiler.is_compiling():
+            # traced: the state tensor is a graph INPUT, its snapshot a traced clone, its advance a traced in-place add (functionalised into a
+            # copy back to the input) - every call of the compiled graph draws fresh decisions, its backward re-reads the snapshot it saved
+            state = ops.capture_dropout_state(query.device, B * H * L * L)
+        elif torch.cuda.is_current_stream_capturing():     # graph capture: (seed, offset) from device memory, fresh on every replay
             state = ops.capture_dropout_state(query.device, B * H * L * L)
         else:
             seed, offset = ops.next_dropout_seed(query.device, B * H * L * L)
@@ -205,7 +213,7 @@ def _scaled_dot_product_attention_amd(
             return _unpad(out, D_true)
         on_device = False       # (a combination the mask / dropout kernels do not take: stock SDPA serves it)
         _handoff("attn_mask / dropout_p in a combination the mask kernels do not take (head dim above 256, a per-row bias at head dim 256 with a gradient wanted, fp32, attn_mask with is_causal, a mask "
-                 "that wants a gradient or does not broadcast to [B, H, L, L], dropout while tracing)")
+                 "that wants a gradient or does not broadcast to [B, H, L, L], dropout traced before init_graph_dropout_state())")
         if query.shape[-1] != D_true:
             query, key, value = (t[..., :D_true] for t in (query, key, value))
     if on_device:
@@ -222,6 +230,10 @@ def _scaled_dot_product_attention_amd(
             return _unpad(ops.attention_bhld(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal), D_true)
         if gqa:   # training with grouped K/V heads: resolved inside the forward AND the backward kernels (no expanded K/V)
             return _unpad(ops.attention_gqa(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal), D_true)
+        if query.ndim == 4 and query.numel() > 0 and not torch.compiler.is_compiling():
+            # eager training on the [B, H, L, D] views as they are: no reshape (for the head-inner slices of a fused projection that was three
+            # copies), result and gradients in the operands' layout, cached stride blocks (ops._BhldAttentionFn)
+            return _unpad(ops.attention_bhld_train(query, key, value, softmax_scale, num_chunks_q, num_chunks_kv, causal), D_true)
         out = ops.attention(query.reshape(-1, L, D), key.reshape(-1, L, D), value.reshape(-1, L, D),
                             softmax_scale, num_chunks_q, num_chunks_kv, causal)
         return _unpad(out.view(*batch_shape, L, D), D_true)

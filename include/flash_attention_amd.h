@@ -102,9 +102,13 @@ typedef struct fa_plan_t {
                             2 = a debug override was in force (fa_debug_set_option / FA_AMD_* at load) */
     int32_t pair;        /* 1 = a workgroup owns two q tiles, (n - 1 - i) then i, one after the other (causal, 64-key tiles) [ABI 4] */
     int32_t balanced;    /* 1 = placement-balanced block order (a causal grid below one round of the chip's workgroup slots) [ABI 4] */
-    int32_t xs;          /* q-tile subsets per group [ABI 6]: groups go to the 8 XCDs by index mod 8; where G leaves XCDs idle or unevenly loaded
-                            (G < 8, G = 12, ...) the launch is laid out over G * xs (group, subset) pairs, xs = 8 / gcd(G, 8), subset s of a
-                            group = its q tiles s, s + xs, ... counted from the last; 1 = groups map whole */
+    int32_t xs;          /* q-tile subsets per group [ABI 6]: groups go to the 8 XCDs by index mod 8; where G wastes an eighth of the XCD slots or
+                            more (G < 8, G = 12, ...) the launch is laid out over G * xs (group, subset) pairs, subset s of a group = its q
+                            tiles s, s + xs, ... counted from the last.  xs = the SMALLEST of 2, 4, 8 whose G * xs pairs waste less than 9 % of
+                            the slots (G = 25 -> 4, not 8); 1 = groups map whole - also when every subset would not get a tile
+                            (ceil(L / 256) < xs) or when the pairs one XCD then holds no longer share its L2 (pairs per XCD x K/V bytes of
+                            a group > 8 MB with K/V < 4 MB per group: G = 7 at large L -> 1).  fa_capi.cpp subsets_for();
+                            measured in profiles/r05_subsets/ab_final_rule.txt */
 } fa_plan_t;
 
 int fa_abi_version(void);

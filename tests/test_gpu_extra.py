@@ -554,3 +554,52 @@ def test_attn_mask_stays_on_the_hip_path_under_torch_compile():
     assert torch.equal(out, eager)
     for a, b in zip(gc, ge):
         assert torch.equal(a, b)
+
+
+def test_dropout_stays_on_the_hip_path_under_torch_compile():
+    """Round-5 verdict, item 6: the last mode that silently left the HIP path in a compiled training step.  torch.compile(fullgraph=True) of a
+    block with dropout_p > 0: the override reads (seed, offset) from the device-resident generator state - a graph input whose snapshot and
+    advance are traced device operations - and calls `flash_attention_amd::fwd_ex` / `bwd_ex`; two calls of the compiled block draw two masks,
+    and each call's forward AND gradients equal oracle/dropout.py's decisions for the state that call read."""
+    import flash_attention_amd
+    import flash_attention_amd.auto  # noqa: F401
+    from flash_attention_amd._impl import _native
+    from flash_attention_amd._impl import scaled_dot_product_attention as sdpa_mod
+    from oracle import dense_attention_extra, frozen_randn
+
+    B, H, L, D, dtype, p = 2, 3, 256, 64, torch.bfloat16, 0.2
+    dev = torch.device("cuda", 0)
+    q, k, v = ((frozen_randn(SEED + 51 + i, (B, H, L, D)) * 0.6).to(dtype).to(dev).requires_grad_(True) for i in range(3))
+    dout = frozen_randn(SEED + 57, (B, H, L, D)).to(dtype).to(dev)
+    torch.manual_seed(4321)
+    state = flash_attention_amd.init_graph_dropout_state(dev)
+    calls = {"fwd": 0, "bwd": 0}
+    real_f, real_b = _native.fwd_ex, _native.bwd_ex
+    _native.fwd_ex = lambda *a, **kw: (calls.__setitem__("fwd", calls["fwd"] + 1), real_f(*a, **kw))[1]
+    _native.bwd_ex = lambda *a, **kw: (calls.__setitem__("bwd", calls["bwd"] + 1), real_b(*a, **kw))[1]
+    handoffs = set(sdpa_mod._HANDOFF_REASONS)
+    try:
+        def block(q, k, v):
+            return F.scaled_dot_product_attention(q * 1.0, k, v, dropout_p=p, is_causal=True)
+
+        compiled = torch.compile(block, fullgraph=True)
+        results = []
+        for _ in range(2):
+            seed, offset = (int(x) for x in state.tolist())          # what this call's kernels will read
+            out = compiled(q, k, v)
+            gq, gk, gv = torch.autograd.grad(out, (q, k, v), dout)
+            torch.cuda.synchronize()
+            results.append((seed, offset, out.detach().clone(), gq.clone(), gk.clone(), gv.clone()))
+    finally:
+        _native.fwd_ex, _native.bwd_ex = real_f, real_b
+    assert calls == {"fwd": 2, "bwd": 2}, f"the compiled block must call fa_fwd_ex / fa_bwd_ex, not stock SDPA: {calls}"
+    assert set(sdpa_mod._HANDOFF_REASONS) == handoffs, "no hand-off to stock SDPA"
+    assert results[0][1] != results[1][1], "the traced in-place add must advance the device-resident offset on every call"
+    assert not torch.equal(results[0][2], results[1][2]), "two calls of a compiled dropout block must draw two masks"
+    for seed, offset, o_, gq_, gk_, gv_ in results:
+        qr, kr, vr = (t.detach().cpu().double().requires_grad_(True) for t in (q, k, v))
+        ref, _ = dense_attention_extra(qr, kr, vr, D ** -0.5, True, None, p, seed, offset)
+        ref.backward(dout.cpu().double())
+        _fwd_close(o_, ref.detach(), f"compiled dropout forward (seed {seed}, offset {offset})")
+        for name, got, want in (("dq", gq_, qr.grad), ("dk", gk_, kr.grad), ("dv", gv_, vr.grad)):
+            _grad_close(got, want, f"compiled dropout {name} (offset {offset})")
