@@ -91,29 +91,38 @@ __device__ __forceinline__ bool bwd_block_map(int G8, int G, int sched, int nblk
 // dS = P o (dP - Dsum)  (Dsum = rowsum(dO o O) still equals sum_j P_j dP_j);  dV sees  keep ? P / (1 - p) : 0.
 // EXTRA: 0 plain, 1 mask / dropout with the mask loaded in place, 2 the same with the mask's raw data requested one tile ahead (masks
 // that differ from row to row: [.., L, L]; a key-padding or key-bias row is cache-resident and gains nothing from 8 - 32 more registers)
-template <typename T, int D, int NWAVES, int EXTRA = 0>
+// QS > 1 (kv split groups, for grids that cannot fill the chip - the mirror of the forward's SPLIT, fa_fwd_dma.hip): QS groups of NWAVES waves own
+// the SAME query rows; group s streams the kv tiles s, s + QS, ... through buffers of its own, in lock step with the others (one workgroup
+// barrier per round), and the groups' dQ partial sums meet in LDS after the loop, added in group order (deterministic).  A launch of at most
+// one workgroup per CU lasts as long as its heaviest row block's kv chain; the chain shrinks QS-fold.
+template <typename T, int D, int NWAVES, int EXTRA = 0, int QS = 1>
 __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     using GM = BwdGeom<T, D, NWAVES>;
     typedef T vec4 __attribute__((ext_vector_type(4)));
     constexpr int BQ = NWAVES * 32, BK = 64, KS = GM::KS, DT = GM::DT, IMG_B = GM::IMG_B, PPW = GM::PPW, NB = GM::NB;
+    static_assert(QS == 1 || EXTRA == 0, "kv split groups: the plain kernels only");
 
     // K0 .. K(NB-1)  V0 .. V(NB-1); EXTRA == 2 | 3: plus per buffer the tile's mask image (128 rows x 64 keys: 8 KB of boolean bytes, 16 KB of bias)
     constexpr int MIMG_B = EXTRA == 3 ? 16384 : 8192, MOFF = 2 * NB * IMG_B;
     // (EXTRA == 1: per buffer the 64 per-key terms of a row-broadcast mask, fp32, and the tile's "every key masked" flag)
     constexpr int MT_F = 80;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MOFF + (EXTRA >= 2 ? NB * MIMG_B : EXTRA == 1 ? NB * MT_F * 4 : 0)];
-    unsigned char* const smem_v = smem + NB * IMG_B;
-    float* const mterm = (float*)(smem + MOFF);
-    (void)mterm;
+    constexpr int GROUP_B = MOFF + (EXTRA >= 2 ? NB * MIMG_B : EXTRA == 1 ? NB * MT_F * 4 : 0);
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[QS * GROUP_B];
 
     int g, qi;
     if (!bwd_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, p.xs_q, p.nq_real, g, qi)) return;
 
     const int L = p.L;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int ws = QS == 1 ? 0 : wave_all / NWAVES;                    // kv split group of this wave
+    const int wave = QS == 1 ? wave_all : wave_all - ws * NWAVES;      // its row block inside the group
+    const int tid = (int)threadIdx.x - ws * (NWAVES * 64), lane = tid & 63;
+    unsigned char* const smem = smem_all + ws * GROUP_B;
+    unsigned char* const smem_v = smem + NB * IMG_B;
+    float* const mterm = (float*)(smem + MOFF);
+    (void)mterm;
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.H, hh = g - bb * p.H;
     const T* __restrict__ kg = (const T*)p.k + (int64_t)bb * p.k_sb + (int64_t)(hh / p.kv_div) * p.k_sh;   // (grouped-query K/V head)
@@ -163,7 +172,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             for (int j = 0; j < 8; ++j) acc += (float)of[j] * (float)dof[ks][j];
         }
         dsum = half_swap_sum(acc);
-        if (h == 0 && qrow < L) p.dsum[(int64_t)g * L + qrow] = dsum;
+        if (h == 0 && qrow < L && ws == 0) p.dsum[(int64_t)g * L + qrow] = dsum;
     }
     const float ndsum = -dsum;
     const float c = p.scale_log2;
@@ -434,19 +443,22 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 
     // ring of NB buffers: tile t lives in buffer t % NB; at the top of tile t the DMA for tile t + NB - 1 goes out (its buffer
     // was released by the barrier that ended tile t - 1); at the end of tile t only that newest DMA may still be in flight
-    fa_static_for<0, NB - 1>([&](auto bi_) { constexpr int b_ = decltype(bi_)::value; if (b_ < n_tiles) { FA_MTERM_LOAD(b_) FA_DMA_KV(b_, b_) FA_DMA_MASK(b_, b_) FA_MTERM_STORE(b_) } });
+    // (kv split groups: the group's j-th tile is tile ws + QS j; n_local of them; every group keeps the workgroup's n_rounds barriers)
+    const int n_rounds = QS == 1 ? n_tiles : (n_tiles + QS - 1) / QS;
+    const int n_local = QS == 1 ? n_tiles : (n_tiles - ws + QS - 1) / QS;
+    fa_static_for<0, NB - 1>([&](auto bi_) { constexpr int b_ = decltype(bi_)::value; if (b_ < n_local) { FA_MTERM_LOAD(b_) FA_DMA_KV(ws + QS * b_, b_) FA_DMA_MASK(b_, b_) FA_MTERM_STORE(b_) } });
     FA_TILE_BARRIER()
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));   // row operands landed
 
-    for (int t0 = 0; t0 < n_tiles; t0 += NB) {
+    for (int t0 = 0; t0 < n_rounds; t0 += NB) {
         fa_static_for<0, NB>([&](auto ki_) {
             constexpr int k_ = decltype(ki_)::value;
             const int t = t0 + k_;
-            if (t < n_tiles) {                                   // (workgroup-uniform)
-                const bool more = t + NB - 1 < n_tiles;
-                if (more) { FA_MTERM_LOAD(t + NB - 1) FA_DMA_KV(t + NB - 1, (k_ + NB - 1) % NB) FA_DMA_MASK(t + NB - 1, (k_ + NB - 1) % NB) }
-                FA_DQ_TILE(t, k_)
+            if (t < n_rounds) {                                  // (workgroup-uniform)
+                const bool more = t + NB - 1 < n_local;
+                if (more) { FA_MTERM_LOAD(t + NB - 1) FA_DMA_KV(ws + QS * (t + NB - 1), (k_ + NB - 1) % NB) FA_DMA_MASK(t + NB - 1, (k_ + NB - 1) % NB) }
+                if (QS == 1 || t < n_local) FA_DQ_TILE(ws + QS * t, k_)
                 if (more) FA_MTERM_STORE((k_ + NB - 1) % NB)
                 if (more && NB > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NB - 2)) : "memory");
                 else lds_dma_wait_all();
@@ -461,6 +473,29 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 #undef FA_MTERM_LOAD
 #undef FA_MTERM_STORE
 
+    // kv split groups: fold the other groups' dQ^T partial sums into group 0 through LDS, one group at a time in group order (every buffer is
+    // free after the loop's last barrier; a lane's values sit at [value][lane]: conflict-free writes and reads)
+    if constexpr (QS > 1) {
+        float* xb = (float*)smem_all + wave * (DT * 16 * 64) + lane;
+        static_assert(NWAVES * DT * 16 * 64 * 4 <= QS * GROUP_B, "exchange area must fit the K/V buffers");
+        for (int sg = 1; sg < QS; ++sg) {
+            if (sg > 1) __syncthreads();                // (group 0 has read the previous group's values)
+            if (ws == sg) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) xb[(dt * 16 + e) * 64] = dq[dt][e];
+            }
+            __syncthreads();
+            if (ws == 0) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dq[dt][e] += xb[(dt * 16 + e) * 64];
+            }
+        }
+        if (ws != 0) return;
+    }
     if (!wave_active || qrow >= L) return;
     T* __restrict__ og = (T*)p.dq + (int64_t)bb * p.dq_sb + (int64_t)hh * p.dq_sh + (int64_t)qrow * p.dq_sl;
 #pragma unroll
@@ -476,9 +511,9 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 }
 
 #ifndef FA_BWD_BODY_ONLY
-template <typename T, int D, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dq_kernel(const BwdParams p) {
-    fa_bwd_dq_body<T, D, NWAVES>(p);
+template <typename T, int D, int NWAVES, int QS = 1>
+__global__ __launch_bounds__(NWAVES * QS * 64) void fa_bwd_dq_kernel(const BwdParams p) {
+    fa_bwd_dq_body<T, D, NWAVES, 0, QS>(p);
 }
 #endif
 
@@ -488,8 +523,12 @@ __global__ __launch_bounds__(NWAVES * 64) void fa_bwd_dq_kernel(const BwdParams 
 // PASS: 0 = dK and dV in one sweep; 1 = dV alone, 2 = dK alone - the same body with one of the two results never stored, so that the compiler
 // drops its accumulators, its MFMAs and (dV alone) the V^T fragments and the dP product: the head_dim 256 mask / dropout launches run the two
 // passes one after the other (the single sweep fills all 512 registers without the mask terms), at the price of a second S = Q K^T.
-template <typename T, int D, int NWAVES, int EXTRA = 0, int PASS = 0>
+// QS > 1 (query-sweep split groups, for grids that cannot fill the chip): QS groups of NWAVES waves own the SAME 128 keys; group s streams the
+// items s, s + QS, ... of the (head, query tile) stream through buffers of its own, in lock step with the others, and the groups' dK^T / dV^T
+// partial sums meet in LDS after the loop, added in group order (deterministic: no atomics, as everywhere in this backward).
+template <typename T, int D, int NWAVES, int EXTRA = 0, int PASS = 0, int QS = 1>
 __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
+    static_assert(QS == 1 || (EXTRA == 0 && PASS == 0), "query-sweep split groups: the plain kernels only");
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     using GM = BwdGeom<T, D, NWAVES>;
@@ -501,9 +540,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     // (EXTRA == 2 | 3: plus per buffer the item's mask tile, 64 rows x the workgroup's 128 keys: 8 KB of boolean bytes or 16 KB of bias)
     constexpr int MIMG_B = EXTRA == 3 ? 16384 : 8192, MOFF = 2 * NB * IMG_B + NB * 512;
     constexpr bool MDMA = !(D == 256 && EXTRA == 3);   // (head_dim 256: the Q / dO images fill 128 KB - two 16 KB bias images do not fit beside them: that bias is loaded in place)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MOFF + ((EXTRA >= 2 && MDMA) ? NB * MIMG_B : 0)];
-    unsigned char* const smem_g = smem + NB * IMG_B;
-    float* const rowc = (float*)(smem + 2 * NB * IMG_B);  // [buf][ lse2 0..63 | dsum 0..63 ]
+    constexpr int GROUP_B = MOFF + ((EXTRA >= 2 && MDMA) ? NB * MIMG_B : 0);
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[QS * GROUP_B];
 
     // Grouped-query attention: the workgroup owns 128 keys of ONE K/V head and sweeps the query tiles of all kv_div query
     // heads that read it, one head after the other, as one stream of (head, query tile) items: dK and dV of the shared
@@ -512,8 +550,11 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     if (!bwd_block_map(p.G8kv, p.Gkv, p.sched_kv, p.nk_tiles, false, p.xs_kv, p.nk_real, g, kb)) return;   // key block 0 is the heaviest
 
     const int L = p.L;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int ws = QS == 1 ? 0 : wave_all / NWAVES;                    // query-sweep split group of this wave
+    const int wave = QS == 1 ? wave_all : wave_all - ws * NWAVES;      // its 32 keys inside the group
+    const int tid = (int)threadIdx.x, lane = tid & 63;                 // (tid: the unsplit kernel's thread index; split groups use wave / lane)
+    // (per group: Q / dO images, then rowc = [buf][ lse2 0..63 | dsum 0..63 ] - the pointers are formed inside the group's copy of the loop)
     const int r = lane & 31, h = lane >> 5;
     const int bb = g / p.Hkv, hh = g - bb * p.Hkv;                 // batch entry, K/V head
     const int hq0 = hh * p.kv_div;                                 // its first query head
@@ -602,24 +643,28 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         }                                                                                          \
         }                                                                                          \
     }
-    const unsigned smem_lds = lds_offset(smem);
     // row constants of q tile I_: threads 0..63 fetch lse*log2e, 64..127 fetch -Dsum; rows past L get
     // lse2 = +inf (P = 0) and Dsum = 0
     const float* __restrict__ lse_g0 = p.lse + ((int64_t)bb * p.H + hq0) * L;       // [G, L] rows of query head hq0
     const float* __restrict__ dsum_g0 = p.dsum + ((int64_t)bb * p.H + hq0) * L;
+    // (the group's threads 0..63 / 64..127: with split groups told by the wave index, a scalar - the group-local thread index would be one more
+    //  register in a kernel that has none left at head_dim 128)
+#define RC_W0 (QS == 1 ? tid < 64 : wave == 0)
+#define RC_W1 (QS == 1 ? (tid >= 64 && tid < 128) : wave == 1)
+#define RC_IDX (QS == 1 ? tid : wave * 64 + lane)
 #define FA_ROWC_LOAD(J_)                                                                           \
     {                                                                                              \
         FA_ITEM(J_, hq_, it_)                                                                      \
         const int rr_ = it_ * BQ + (tid & 63);                                                     \
-        rc_stage = (tid < 64) ? INFINITY : 0.f;                                                    \
-        if (tid < 64 && rr_ < L) {                                                                 \
+        rc_stage = RC_W0 ? INFINITY : 0.f;                                                         \
+        if (RC_W0 && rr_ < L) {                                                                    \
             const float l_ = lse_g0[(int64_t)hq_ * L + rr_];                                       \
             rc_stage = (EXTRA && l_ == -INFINITY) ? INFINITY : l_ * LOG2E;   /* a fully masked row: P = 0 */ \
         }                                                                                          \
-        if (tid >= 64 && tid < 128 && rr_ < L) rc_stage = -dsum_g0[(int64_t)hq_ * L + rr_];   /* negated: see the dP accumulators */ \
+        if (RC_W1 && rr_ < L) rc_stage = -dsum_g0[(int64_t)hq_ * L + rr_];   /* negated: see the dP accumulators */ \
     }
 #define FA_ROWC_STORE(BUF_) \
-    if (tid < 128) rowc[(BUF_) * 128 + tid] = rc_stage;
+    if (RC_W0 || RC_W1) rowc[(BUF_) * 128 + RC_IDX] = rc_stage;
 
     int a_rd[KS];
 #pragma unroll
@@ -887,12 +932,25 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     // ring of NB buffers (see fa_bwd_dq_kernel).  The row constants of an item travel through one staging register: loaded
     // BEFORE that item's DMA is issued - vmcnt retires in order, so waiting for them at the end of a tile does not wait for
     // the newer DMA - and stored to the item's buffer at the end of the tile during which they were loaded.
+    // (query-sweep split groups: the group's j-th item is item ws + QS j; n_local of them; every group keeps the workgroup's n_rounds barriers.
+    //  Each group runs a copy of the loop of its own in which its index - and with it every LDS address - is a compile-time constant, as in the
+    //  unsplit kernel: with the group's LDS base in a register the head_dim 128 kernel, which has none to spare, spilled seven.)
+    const int n_rounds = QS == 1 ? n_items : (n_items + QS - 1) / QS;
+    const int ws_dyn = ws;
+    fa_static_for<0, QS>([&](auto wi_) {
+    constexpr int ws = decltype(wi_)::value;
+    if (ws_dyn != ws) return;
+    unsigned char* const smem = smem_all + ws * GROUP_B;
+    unsigned char* const smem_g = smem + NB * IMG_B;
+    float* const rowc = (float*)(smem + 2 * NB * IMG_B);
+    const unsigned smem_lds = lds_offset(smem);
+    const int n_local = QS == 1 ? n_items : (n_items - ws + QS - 1) / QS;
     fa_static_for<0, NB - 1>([&](auto bi_) {
         constexpr int b_ = decltype(bi_)::value;
-        if (b_ < n_items) {
-            FA_ROWC_LOAD(b_)
-            FA_DMA_QG(b_, b_)
-            FA_DMA_MASK(b_, b_)
+        if (b_ < n_local) {
+            FA_ROWC_LOAD(ws + QS * b_)
+            FA_DMA_QG(ws + QS * b_, b_)
+            FA_DMA_MASK(ws + QS * b_, b_)
             FA_ROWC_STORE(b_)
         }
     });
@@ -904,18 +962,18 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         else asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
     }
 
-    for (int j0 = 0; j0 < n_items; j0 += NB) {
+    for (int j0 = 0; j0 < n_rounds; j0 += NB) {
         fa_static_for<0, NB>([&](auto ki_) {
             constexpr int k_ = decltype(ki_)::value;
             const int j = j0 + k_;
-            if (j < n_items) {                                   // (workgroup-uniform)
-                const bool more = j + NB - 1 < n_items;
+            if (j < n_rounds) {                                  // (workgroup-uniform)
+                const bool more = j + NB - 1 < n_local;
                 if (more) {
-                    FA_ROWC_LOAD(j + NB - 1)
-                    FA_DMA_QG(j + NB - 1, (k_ + NB - 1) % NB)
-                    FA_DMA_MASK(j + NB - 1, (k_ + NB - 1) % NB)
+                    FA_ROWC_LOAD(ws + QS * (j + NB - 1))
+                    FA_DMA_QG(ws + QS * (j + NB - 1), (k_ + NB - 1) % NB)
+                    FA_DMA_MASK(ws + QS * (j + NB - 1), (k_ + NB - 1) % NB)
                 }
-                FA_DKDV_TILE(j, k_)
+                if (QS == 1 || j < n_local) FA_DKDV_TILE(ws + QS * j, k_)
                 if (more) FA_ROWC_STORE((k_ + NB - 1) % NB)
                 if (more && NB > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NB - 2)) : "memory");
                 else lds_dma_wait_all();
@@ -923,14 +981,47 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             }
         });
     }
+    });   // (split group ws)
 #undef FA_ITEM
 #undef FA_DMA_QG
 #undef FA_DMA_LANE_OFFSETS
 #undef FA_ROWC_LOAD
 #undef FA_ROWC_STORE
+#undef RC_W0
+#undef RC_W1
+#undef RC_IDX
 #undef FA_DKDV_TILE
 #undef FA_DMA_MASK
 
+    // query-sweep split groups: fold the other groups' dK^T and dV^T partial sums into group 0 through LDS - one group and one of the two
+    // gradients at a time, in that order (every buffer is free after the loop's last barrier; a lane's values at [value][lane])
+    if constexpr (QS > 1) {
+        float* xb = (float*)smem_all + wave * (DT * 16 * 64) + lane;
+        static_assert(NWAVES * DT * 16 * 64 * 4 <= QS * GROUP_B, "exchange area must fit the Q / dO buffers");
+        for (int sg = 1; sg < QS; ++sg) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                if (sg > 1 || which > 0) __syncthreads();           // (group 0 has read the previous values)
+                if (ws == sg) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) xb[(dt * 16 + e) * 64] = which == 0 ? dk[dt][e] : dv[dt][e];
+                }
+                __syncthreads();
+                if (ws == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            if (which == 0) dk[dt][e] += xb[(dt * 16 + e) * 64];
+                            else dv[dt][e] += xb[(dt * 16 + e) * 64];
+                        }
+                }
+            }
+        }
+        if (ws != 0) return;
+    }
     if (!wave_active || key >= L) return;
     int key_e = key;                                // (the output rows' addresses are formed here, not carried through the loop)
     asm volatile("" : "+v"(key_e));
@@ -956,19 +1047,39 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 
 #ifndef FA_BWD_BODY_ONLY
 // (head_dim 128: 254 + 4 registers as allocated freely - held to 256 = two waves per SIMD)
-template <typename T, int D, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64, D == 128 ? 2 : 1) void fa_bwd_dkdv_kernel(const BwdParams p) {
-    fa_bwd_dkdv_body<T, D, NWAVES>(p);
+template <typename T, int D, int NWAVES, int QS = 1>
+__global__ __launch_bounds__(NWAVES * QS * 64, D == 128 ? 2 : QS == 3 ? 3 : 1) void fa_bwd_dkdv_kernel(const BwdParams p) {
+    fa_bwd_dkdv_body<T, D, NWAVES, 0, 0, QS>(p);
 }
 
 // ---------------------------------------------------------------------------------------------
 // host-side launcher: dQ (which also publishes Dsum), then dK/dV on the same stream (4-wave workgroups)
 // ---------------------------------------------------------------------------------------------
+// (p.qs_q / p.qs_kv: split groups of the two grids - 1, or for grids of at most one workgroup per CU 3 at head_dim 64 and 2 at head_dim 128:
+//  what the kernels' registers leave room for - fa_capi.cpp bwd_impl)
 template <typename T, int D>
 static hipError_t launch_bwd_t(const BwdParams& p, hipStream_t stream) {
-    hipError_t e = launch1((const void*)(fa_bwd_dq_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8 * p.nq_tiles)), dim3(256), 0, stream, p);
-    if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), dim3((unsigned)((int64_t)p.G8kv * p.nk_tiles)), dim3(256), 0, stream, p);
-    return e;
+    const dim3 qgrid((unsigned)((int64_t)p.G8 * p.nq_tiles)), kgrid((unsigned)((int64_t)p.G8kv * p.nk_tiles));
+    hipError_t e;
+    if constexpr (D == 64) {
+        e = p.qs_q == 3   ? launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 3>), qgrid, dim3(768), 0, stream, p)
+            : p.qs_q == 2 ? launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 2>), qgrid, dim3(512), 0, stream, p)
+                          : launch1((const void*)(fa_bwd_dq_kernel<T, D, 4>), qgrid, dim3(256), 0, stream, p);
+        if (e != hipSuccess) return e;
+        return p.qs_kv == 3   ? launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4, 3>), kgrid, dim3(768), 0, stream, p)
+               : p.qs_kv == 2 ? launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4, 2>), kgrid, dim3(512), 0, stream, p)
+                              : launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), kgrid, dim3(256), 0, stream, p);
+    } else if constexpr (D == 128) {
+        e = p.qs_q == 2 ? launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 2>), qgrid, dim3(512), 0, stream, p)
+                        : launch1((const void*)(fa_bwd_dq_kernel<T, D, 4>), qgrid, dim3(256), 0, stream, p);
+        if (e != hipSuccess) return e;
+        // (no split dK/dV at head_dim 128: the unsplit kernel fills its 256 registers; the split form spilled eight - not built)
+        return launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), kgrid, dim3(256), 0, stream, p);
+    } else {
+        e = launch1((const void*)(fa_bwd_dq_kernel<T, D, 4>), qgrid, dim3(256), 0, stream, p);
+        if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), kgrid, dim3(256), 0, stream, p);
+        return e;
+    }
 }
 
 hipError_t launch_bwd(const BwdParams& p, int dtype, hipStream_t stream) {

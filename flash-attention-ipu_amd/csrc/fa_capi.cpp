@@ -48,7 +48,7 @@ struct Options {
     std::atomic<int> pair{-1};      // -1 auto, 0 | 1 q-tile pairs per workgroup (fa_fwd_dma.hip, causal)
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
     std::atomic<int> subsets{-1};   // -1 auto, 0 off: q-tile subsets for group counts that leave XCDs idle (FwdParams::xs)
-    std::atomic<int> tlw{0};        // 0 auto, else workgroup types per group of the team-list plan (fa_fwd_tl.hip)
+    std::atomic<int> bsplit{-1};    // -1 auto, 0 off, 2 | 3: split groups inside the backward's workgroups (BwdParams::qs_q / qs_kv), forced where a kernel has that form
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -56,9 +56,8 @@ std::once_flag g_opt_once;
 std::atomic<void*> g_stamp_buf{nullptr};
 std::atomic<int64_t> g_stamp_bytes{0};
 
-int parse_kernel(const char* v) {   // dma | pipe | pipe16 | kh | tl
+int parse_kernel(const char* v) {   // dma | pipe | pipe16 | kh
     if (!v) return 0;
-    if (strcmp(v, "tl") == 0 || v[0] == 't') return 't';
     if (strcmp(v, "kh") == 0 || v[0] == 'h') return 'h';
     if (strcmp(v, "pipe16") == 0 || v[0] == 'x') return 'x';
     return (v[0] == 'd' || v[0] == 'p') ? v[0] : 0;
@@ -77,7 +76,7 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_PAIR")) { if (*e) g_opt.pair = atoi(e); }
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
         if (const char* e = getenv("FA_AMD_SUBSETS")) { if (*e) g_opt.subsets = atoi(e); }
-        if (const char* e = getenv("FA_AMD_TLW")) g_opt.tlw = atoi(e);
+        if (const char* e = getenv("FA_AMD_BSPLIT")) { if (*e) g_opt.bsplit = atoi(e); }
     });
     return g_opt;
 }
@@ -134,9 +133,6 @@ struct Selection {
     int perm_n;      // 'd' | 'h': > 0 = placement-balanced order of the XCD's first perm_n slots
     uint8_t perm[128];
     int xs;          // q-tile subsets per group (FwdParams::xs); 1 = groups map to XCDs whole
-    int tl_nw;       // 't': workgroup types per group, their rounds and unit lists (fa_params.h TlParams)
-    uint8_t tl_rounds[fa::TL_MAXW];
-    uint32_t tl_prog[fa::TL_MAXW][2][fa::TL_MAXU];
 };
 
 // Groups go to XCDs by index mod 8 (a group's K/V then live in ONE XCD's L2).  A group count that is not a multiple of 8 leaves XCDs idle
@@ -191,92 +187,6 @@ int balanced_order(int n_slots, const int* weight, uint8_t* perm) {
     for (int c = 0; c < kCusPerXcd; ++c)
         for (int k = 0; k < cnt[c]; ++k) perm[c + kCusPerXcd * k] = (uint8_t)items[c][k];   // a CU's heaviest item in its first round
     return n_slots;
-}
-
-// Team lists (fa_fwd_tl.hip): pack the q tiles of ONE group - tile counts n[0 .. nq) - into at most `wmax` workgroups of two teams so that the
-// longest team chain is as short as it can be.  For a chain bound C: every q tile longer than C is cut in two kv ranges that become the LAST
-// units of the two teams of a workgroup of their own (they fold through LDS after the loop); the other q tiles, longest first, go whole into
-// the team with the least room that still takes them (in front of a half, or into a fresh workgroup), at most TL_MAXU units per team.  The
-// smallest C with a packing wins; returns the number of workgroup types (heaviest first) or 0 when no packing beats one q tile per workgroup.
-struct TlBuild { int nw; uint8_t rounds[fa::TL_MAXW]; uint32_t prog[fa::TL_MAXW][2][fa::TL_MAXU]; int weight[fa::TL_MAXW]; int chain; };
-bool tl_pack(int nq, const int* n, int C, int wmax, TlBuild* out) {
-    struct Team { int used, nu; uint32_t u[fa::TL_MAXU]; bool has_half; uint32_t half; int half_len; };
-    Team tm[fa::TL_MAXW][2];
-    memset(tm, 0, sizeof(tm));
-    int nw = 0;
-    const auto word = [](int qi, int t0, int t1, int kind) { return (uint32_t)qi | (uint32_t)t0 << 8 | (uint32_t)t1 << 16 | (uint32_t)kind << 24; };
-    for (int i = nq - 1; i >= 0; --i) {           // halves first: one workgroup each
-        if (n[i] <= C) continue;
-        const int a = (n[i] + 1) / 2;
-        if (a > C || nw == wmax) return false;
-        tm[nw][0].has_half = tm[nw][1].has_half = true;
-        tm[nw][0].half = word(i, 0, a, 2);     tm[nw][0].half_len = a;
-        tm[nw][1].half = word(i, a, n[i], 3);  tm[nw][1].half_len = n[i] - a;
-        tm[nw][0].used = a; tm[nw][1].used = n[i] - a;
-        ++nw;
-    }
-    int order[64], cnt = 0;
-    for (int i = 0; i < nq; ++i) if (n[i] <= C) order[cnt++] = i;
-    for (int i = 1; i < cnt; ++i) {               // whole q tiles, longest first
-        const int v = order[i];
-        int j = i - 1;
-        while (j >= 0 && n[order[j]] < n[v]) { order[j + 1] = order[j]; --j; }
-        order[j + 1] = v;
-    }
-    for (int k = 0; k < cnt; ++k) {
-        const int i = order[k];
-        int bw = -1, bt = -1;
-        for (int w = 0; w < nw; ++w)
-            for (int t = 0; t < 2; ++t) {
-                const Team& T = tm[w][t];
-                if (T.used + n[i] > C || T.nu + (T.has_half ? 1 : 0) >= fa::TL_MAXU) continue;
-                if (bw < 0 || T.used > tm[bw][bt].used) { bw = w; bt = t; }       // best fit: the fullest team that still takes it
-            }
-        if (bw < 0) {
-            if (nw == wmax) return false;
-            bw = nw++; bt = 0;
-        }
-        Team& T = tm[bw][bt];
-        T.u[T.nu++] = word(i, 0, n[i], 1);
-        T.used += n[i];
-    }
-    // emit, heaviest workgroup type first
-    int idx[fa::TL_MAXW];
-    for (int w = 0; w < nw; ++w) idx[w] = w;
-    for (int a = 1; a < nw; ++a) {
-        const int v = idx[a];
-        int j = a - 1;
-        while (j >= 0 && tm[idx[j]][0].used + tm[idx[j]][1].used < tm[v][0].used + tm[v][1].used) { idx[j + 1] = idx[j]; --j; }
-        idx[j + 1] = v;
-    }
-    memset(out, 0, sizeof(*out));
-    out->nw = nw;
-    out->chain = 0;
-    for (int a = 0; a < nw; ++a) {
-        const int w = idx[a];
-        for (int t = 0; t < 2; ++t) {
-            Team& T = tm[w][t];
-            int nu = 0;
-            for (int k = 0; k < T.nu; ++k) out->prog[a][t][nu++] = T.u[k];
-            if (T.has_half) out->prog[a][t][nu++] = T.half;
-        }
-        const int rd = tm[w][0].used > tm[w][1].used ? tm[w][0].used : tm[w][1].used;
-        out->rounds[a] = (uint8_t)rd;
-        out->weight[a] = tm[w][0].used + tm[w][1].used;
-        if (rd > out->chain) out->chain = rd;
-    }
-    return nw > 0;
-}
-int build_team_lists(int nq, const int* n, int wmax, TlBuild* out) {
-    if (nq < 2 || nq > 64 || wmax < 1) return 0;
-    if (wmax > fa::TL_MAXW) wmax = fa::TL_MAXW;
-    int total = 0, nmax = 0;
-    for (int i = 0; i < nq; ++i) { if (n[i] < 1 || n[i] > 255) return 0; total += n[i]; if (n[i] > nmax) nmax = n[i]; }
-    int lo = (nmax + 1) / 2;
-    if ((total + 2 * wmax - 1) / (2 * wmax) > lo) lo = (total + 2 * wmax - 1) / (2 * wmax);
-    for (int C = lo; C < nmax; ++C)               // (C = nmax is the plain grid's chain: nothing gained)
-        if (tl_pack(nq, n, C, wmax, out)) return out->nw;
-    return 0;
 }
 
 // ---- the selection, in four steps that each do one thing: built-in rules -> measured table -> debug overrides -> ONE constraints pass
@@ -343,7 +253,6 @@ void apply_overrides(const Request& r, const Options& opt, Choice* c) {
     if (fk == 'd') { which = 'd'; if (!fq) qb = 1; }
     else if (fk == 'x' && pipe_ok) { which = 'x'; waves = (fw == 8 && D == 128) ? 8 : 4; if (!fq) qb = 1; }
     else if (fk == 'h') { which = 'h'; waves = 4; qb = 1; }
-    else if (fk == 't') { which = 't'; waves = 4; qb = 1; split = 1; }
     else if (fk == 'p' && pipe_ok && (waves <= 4 || D == 128)) { which = 'p'; if (!fq) qb = (D == 64 && L >= 256 && waves == 4 && cq >= 256) ? 2 : 1; }
     if (fq == 1) qb = 1;
     if (fq == 2 && D == 64 && L >= 256 && waves == 4 && cq >= 256) qb = 2;
@@ -377,9 +286,6 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
     if (which == 'p' && ((waves > 4 && D != 128) || !r.pipe_ok)) which = 'd';   // (8-wave pipelined workgroups exist at head_dim 128 only)
     if (which == 'x' && !r.pipe_ok) which = 'd';
     if (which == 'h') { waves = 4; qb = 1; if (!(split == 1 || split == 2 || (split == 4 && D == 64))) split = 1; }
-    // team lists: causal head_dim 64 on 128-row q tiles, at most 64 of them (tile indices travel in bytes)
-    if (which == 't' && !(D == 64 && r.causal && r.L > 128 && r.L <= 8192)) which = 'd';
-    if (which == 't') { waves = 4; qb = 1; split = 1; }
     if (which == 'x') { waves = (waves == 8 && D == 128) ? 8 : 4; if (D == 128) qb = 1; }
     if (qb == 2 && !(D == 64 && waves == 4)) qb = 1;
     if (split > 1 && !((which == 'd' || which == 'h') && waves == 4 && qb == 1 && (split == 2 || (split == 4 && D == 64)))) split = 1;
@@ -388,49 +294,9 @@ void apply_constraints(const Request& r, const Options& opt, Choice* c) {
 // q-tile pairs and the placement-balanced order ('d', causal), then the plan's geometry
 void finish_mfma_plan(const Request& r, const Options& opt, Choice& c, Selection* sel) {
     fa_plan_t* plan = &sel->plan;
-    const int64_t L = r.L, D = r.D, g8 = r.g8;
-    sel->tl_nw = 0;
-    if (c.which == 't') {     // team lists: build them, or fall back to the plain 64-key-tile grid when no packing shortens the chain
-        const int nq = (int)((L + 127) / 128);
-        int n[64];
-        for (int i = 0; i < nq && i < 64; ++i) { const int64_t kv_end = (i + 1) * 128 < L ? (i + 1) * 128 : L; n[i] = (int)((kv_end + 63) / 64); }
-        // two 66 KB workgroups per CU: 512 slots; by default as many workgroup types per group as keep the launch within ONE round of them
-        int wmax = opt.tlw > 0 ? (int)opt.tlw : (int)(512 / g8);
-        TlBuild b;
-        const int nw = (sel->xs == 1 && nq <= 64) ? build_team_lists(nq, n, wmax, &b) : 0;
-        if (nw > 0) {
-            sel->tl_nw = nw;
-            memcpy(sel->tl_rounds, b.rounds, sizeof(b.rounds));
-            memcpy(sel->tl_prog, b.prog, sizeof(b.prog));
-            sel->pair = 0;
-            sel->split = 1;
-            sel->perm_n = 0;
-            const int64_t ng = g8 / 8;
-            if (ng * nw <= 64 && ng * nw <= 128 && opt.balance != 0) {      // all resident (two per CU, 32 CUs per XCD): even out the CUs' tile sums
-                int weight[128];
-                for (int s_ = 0; s_ < ng * nw; ++s_) weight[s_] = b.weight[s_ / ng];
-                sel->perm_n = balanced_order((int)(ng * nw), weight, sel->perm);
-            }
-            plan->kernel = 7;
-            plan->pair = 0;
-            plan->balanced = sel->perm_n > 0;
-            plan->waves = 8;
-            plan->qb = 1;
-            plan->block_q = 128;
-            plan->block_kv = 64;
-            plan->skipmax = r.skip;
-            plan->source = c.source;
-            plan->grid = g8 * nw;
-            plan->lds_bytes = 2 * (2 * 64 * D * 2 + 2 * (D / 32) * (64 * 64 + 64)) + 32;
-            plan->sched = 1;
-            plan->xs = 1;
-            sel->which = 't';
-            return;
-        }
-        c.which = 'd';
-    }
     const char which = c.which;
     const int waves = c.waves, qb = c.qb, split = c.split, sched = c.sched;
+    const int64_t L = r.L, D = r.D, g8 = r.g8;
     const int es = r.es;
     int pair = 0;
     {
@@ -524,7 +390,6 @@ int select_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t nq, int3
     sel->pair = 0;
     sel->perm_n = 0;
     sel->xs = 1;
-    sel->tl_nw = 0;
     plan->chunk_q = (int32_t)(L / nq);
     plan->chunk_kv = (int32_t)(L / nk);
     int64_t g8 = (G + 7) / 8 * 8;
@@ -591,7 +456,7 @@ const OptionName kOptionNames[] = {
     {"sched", &Options::sched, 0, 1 << 20}, {"skipmax", &Options::skipmax, -1, 1},
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
     {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"subsets", &Options::subsets, -1, 0},
-    {"tlw", &Options::tlw, 0, fa::TL_MAXW},
+    {"bsplit", &Options::bsplit, -1, 3},
 };
 
 }  // namespace
@@ -632,8 +497,8 @@ int fa_debug_set_option(const char* name, int32_t value) {
     for (const OptionName& o : kOptionNames) {
         if (strcmp(o.name, name) != 0) continue;
         if (value < o.lo || value > o.hi) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: %s=%d out of range [%d, %d]", name, value, o.lo, o.hi);
-        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 'h' || value == 't'))
-            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x', 'h' or 't'");
+        if (o.field == &Options::kernel && !(value == 0 || value == 'd' || value == 'p' || value == 'x' || value == 'h'))
+            return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: kernel must be 0, 'd', 'p', 'x' or 'h'");
         if (o.field == &Options::waves && !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: waves must be 0, 1, 2, 4 or 8");
         if (o.field == &Options::split && value == 3) return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: split must be 0, 1, 2 or 4");
@@ -641,19 +506,6 @@ int fa_debug_set_option(const char* name, int32_t value) {
         return FA_OK;
     }
     return fail(FA_ERR_BAD_OPTION, "fa_debug_set_option: unknown option '%s'", name);
-}
-
-// TEST ONLY: the team lists fa_fwd would run for a causal head_dim-64 call of sequence length L with at most wmax workgroup types per group
-// (fa_fwd_tl.hip; fa_params.h TlParams): returns the number of types (0 = no packing shortens the chain), fills rounds[16] and prog[16][2][3].
-int fa_debug_team_lists(int64_t L, int32_t wmax, uint8_t* rounds, uint32_t* prog) {
-    if (!rounds || !prog || L < 1 || L > 8192) return 0;
-    const int nq = (int)((L + 127) / 128);
-    int n[64];
-    for (int i = 0; i < nq; ++i) { const int64_t kv_end = (i + 1) * 128 < L ? (i + 1) * 128 : L; n[i] = (int)((kv_end + 63) / 64); }
-    TlBuild b;
-    const int nw = build_team_lists(nq, n, wmax, &b);
-    if (nw > 0) { memcpy(rounds, b.rounds, sizeof(b.rounds)); memcpy(prog, b.prog, sizeof(b.prog)); }
-    return nw;
 }
 
 int fa_debug_set_stamp_buffer(void* device_buffer, int64_t bytes) {
@@ -832,16 +684,6 @@ int fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse,
     }
     hipStream_t st = (hipStream_t)stream;
     if (extra_mfma) { p.perm_n = 0; p.skipmax = 0; }
-    if (sel.which == 't' && !extra_mfma) {
-        fa::TlParams tp;
-        tp.p = p;
-        tp.nw = sel.tl_nw;
-        memcpy(tp.rounds, sel.tl_rounds, sizeof(tp.rounds));
-        memcpy(tp.prog, sel.tl_prog, sizeof(tp.prog));
-        const hipError_t et = fa::launch_fwd_tl(tp, dtype, st);
-        if (et != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(et));
-        return FA_OK;
-    }
     hipError_t e = extra_mfma         ? fa::launch_fwd_extra(p, dtype, st)
                    : sel.which == 'g' ? fa::launch_fwd_generic(p, dtype, st)
                    : sel.which == 'f' ? fa::launch_fwd_f32(p, st)
@@ -998,6 +840,21 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
             p.nk_tiles = (p.nk_real + xk - 1) / xk;
             p.sched_kv = cap_sched(p.sched_kv, p.G8kv);
         }
+    }
+    // Split groups inside the workgroups (fa_bwd_kernels.hip QS) for grids of at most one workgroup per CU: such a launch lasts as long as its
+    // heaviest block's chain - [1,8192,64]: 64 workgroups, the longest sweeping 128 tiles with one wave per SIMD, 0.07 of peak -
+    // and the chain shrinks with the groups: 3 at head_dim 64 (144 / 164 registers: three waves per SIMD), 2 at head_dim 128 (two).
+    p.qs_q = p.qs_kv = 1;
+    if (mfma && !extra && dtype != FA_DTYPE_F32 && (p.D == 64 || p.D == 128) && options().bsplit != 0) {
+        const int qs_max = p.D == 64 ? 3 : 2;
+        const int forced = options().bsplit > 0 ? (options().bsplit > qs_max ? qs_max : (int)options().bsplit) : 0;
+        if (forced == 1) { /* (1 = unsplit) */ }
+        else if (forced > 1) p.qs_q = p.qs_kv = forced;
+        else if (L >= 1024) {
+            if ((int64_t)p.G * p.nq_tiles <= 256) p.qs_q = qs_max;
+            if ((int64_t)p.Gkv * p.nk_tiles <= 256) p.qs_kv = qs_max;
+        }
+        if (p.D == 128) p.qs_kv = 1;       // (the head_dim 128 dK/dV kernel has no split form: it fills its 256 registers unsplit)
     }
     if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     p.scale = softmax_scale;

@@ -57,18 +57,6 @@ struct FwdParams {
     unsigned long long* stamps;   // measurement builds only (-DFA_STAMPS, scripts/phase_times.py): 16 u64 per wave, else null
 };
 
-// team lists (fa_fwd_tl.hip): a causal head_dim-64 launch as G8 x nw workgroups of two 4-wave teams; workgroup type w of a group runs
-// prog[w][team][0 .. TL_MAXU): units qi | t0 << 8 | t1 << 16 | kind << 24 - q tile qi (128 rows), its 64-key tiles t0 .. t1 - 1, kind 0 = none,
-// 1 = the whole q tile, 2 | 3 = the first | second kv range of a q tile split over the two teams (always a team's LAST unit: the halves
-// fold through LDS after the loop); rounds[w] = the longer team's tile count.  Built by fa_capi.cpp build_team_lists.
-constexpr int TL_MAXW = 16, TL_MAXU = 3;
-struct TlParams {
-    FwdParams p;
-    int32_t nw;                        // workgroup types per group
-    uint8_t rounds[TL_MAXW];
-    uint32_t prog[TL_MAXW][2][TL_MAXU];
-};
-
 // backward (fa_bwd_kernels.hip)
 struct BwdParams {
     const void* q; const void* k; const void* v; const void* o; const void* dout;
@@ -91,6 +79,10 @@ struct BwdParams {
     int32_t xs_q, nq_real, xs_kv, nk_real;
     float scale, scale_log2;
     ExtraParams ex;
+    // split groups inside a workgroup (fa_bwd_kernels.hip QS; 1 = none): qs_q kv split groups of a dQ workgroup, qs_kv query-sweep split groups
+    // of a dK/dV workgroup - for grids of at most one workgroup per CU, where the launch lasts as long as its heaviest block's chain.  (Read by
+    // the host-side launcher only; last, so that no field the kernels read moved.)
+    int32_t qs_q, qs_kv;
 };
 // One launch, reporting ITS OWN status: hipLaunchKernel returns this launch's result, whereas hipGetLastError()
 // after a <<<>>> launch also returns (and clears) a stale error left on the thread by an unrelated earlier HIP
@@ -115,7 +107,6 @@ hipError_t launch_fwd_f32(const FwdParams& p, hipStream_t stream);   // fa_fwd_f
 hipError_t launch_fwd_pipe(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream);   // fa_fwd_pipe.hip
 hipError_t launch_fwd_pipe16(const FwdParams& p, int dtype, int waves, int qb, hipStream_t stream); // fa_fwd_pipe16.hip
 hipError_t launch_fwd_kh(const FwdParams& p, int dtype, int split, hipStream_t stream);             // fa_fwd_kh.hip
-hipError_t launch_fwd_tl(const TlParams& tp, int dtype, hipStream_t stream);                        // fa_fwd_tl.hip
 double probe_mfma_peak(int dtype, int iters, int random_data);
 hipError_t launch_clock_sampler(unsigned long long* out, int spins, hipStream_t stream);   // fa_probe.hip
 

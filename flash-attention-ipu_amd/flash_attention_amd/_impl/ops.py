@@ -581,6 +581,27 @@ def capture_dropout_state(device, numel: int) -> torch.Tensor:
     return snap
 
 
+# torch.compile: the same two device operations as ONE opaque op that mutates its argument.  Written as plain traced ops (clone, then an in-place
+# add on the graph input) the snapshot is a value the partitioner may RECOMPUTE in the backward graph from the input - which by then holds the
+# advanced state: the backward drew a different mask than its forward (measured: forward on the oracle, 56 % of dQ off).  An op that mutates
+# an input is never recomputed; its result is saved like any activation, so the backward re-reads exactly the snapshot its forward read.
+@custom_op("flash_attention_amd::advance_dropout_state", mutates_args=("state",))
+def advance_dropout_state(state: torch.Tensor, numel: int) -> torch.Tensor:
+    snap = state.clone()
+    state[1:].add_(((numel + 3) // 4) * 4)
+    return snap
+
+
+@advance_dropout_state.register_fake
+def _(state, numel):
+    return torch.empty_like(state)
+
+
+def traced_dropout_state(device, numel: int) -> torch.Tensor:
+    """Inside a torch.compile trace: this call's snapshot of the device-resident state (the state tensor is a graph input; see above)."""
+    return advance_dropout_state(_GRAPH_DROPOUT_STATE[_device_index(device)], numel)
+
+
 def next_dropout_seed(device, numel: int):
     """(seed, offset) for one dropout launch, drawn from torch's generator of `device` the way its own dropout kernels do: the
     generator's seed and its running offset, which is advanced past the `numel` decisions of this launch - so torch.manual_seed

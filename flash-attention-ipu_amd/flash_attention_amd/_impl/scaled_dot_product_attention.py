@@ -125,9 +125,9 @@ def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale
     seed, offset, state = 0, 0, None
     if dropout_p > 0.0:
         if torch.compiler.is_compiling():
-            # traced: the state tensor is a graph INPUT, its snapshot a traced clone, its advance a traced in-place add (functionalised into a
-            # copy back to the input) - every call of the compiled graph draws fresh decisions, its backward re-reads the snapshot it saved
-            state = ops.capture_dropout_state(query.device, B * H * L * L)
+            # traced: the state tensor is a graph INPUT; snapshot + advance are one opaque op that mutates it (ops.advance_dropout_state) -
+            # every call of the compiled graph draws fresh decisions, its backward re-reads the snapshot its forward saved
+            state = ops.traced_dropout_state(query.device, B * H * L * L)
         elif torch.cuda.is_current_stream_capturing():     # graph capture: (seed, offset) from device memory, fresh on every replay
             state = ops.capture_dropout_state(query.device, B * H * L * L)
         else:

@@ -23,7 +23,6 @@ hipError_t launch_fwd_f32(const FwdParams&, hipStream_t) { ++g_stub_launches; g_
 hipError_t launch_fwd_pipe(const FwdParams&, int, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'p'; return hipSuccess; }
 hipError_t launch_fwd_pipe16(const FwdParams&, int, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'x'; return hipSuccess; }
 hipError_t launch_fwd_kh(const FwdParams&, int, int, hipStream_t) { ++g_stub_launches; g_stub_last = 'h'; return hipSuccess; }
-hipError_t launch_fwd_tl(const TlParams&, int, hipStream_t) { ++g_stub_launches; g_stub_last = 't'; return hipSuccess; }
 double probe_mfma_peak(int, int, int) { return -1.0; }
 hipError_t launch_clock_sampler(unsigned long long*, int, hipStream_t) { return hipSuccess; }
 }  // namespace fa

@@ -92,7 +92,7 @@ int main() {
                                         if (!mfma16) { EXPECT(pl.kernel == 1 || (pl.kernel == 3 && (D == 64 || D == 128))); continue; }
                                         if (Dk > 128) EXPECT(((pl.kernel == 0 && pl.lds_bytes == (Dk == 192 ? 99072 : 132096)) || (pl.kernel == 2 && Dk == 256 && pl.waves == 4 && pl.skipmax == 1 && pl.lds_bytes == 133136))
                                                             && (pl.waves == 4 || pl.waves == 8) && pl.qb == 1 && pl.block_q == 32 * pl.waves && !pl.pair);   // the 64-key-tile kernel unsplit, or (256, skip-max) the pipelined kernel's 4-wave form - whatever was forced
-                                        EXPECT(pl.kernel == 0 || pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 6);   // (plan kernel 5 was retired with ABI 6; 7 = team lists only when forced)
+                                        EXPECT(pl.kernel == 0 || pl.kernel == 2 || pl.kernel == 4 || pl.kernel == 6);   // (plan kernel 5 was retired with ABI 6)
                                         EXPECT(pl.qb == 1 || pl.qb == 2);
                                         EXPECT(pl.waves == 1 || pl.waves == 2 || pl.waves == 4 || pl.waves == 8 || pl.waves == 16);
                                         EXPECT(pl.waves <= 16 && 64 * pl.waves <= 1024);                            // a workgroup is at most 1024 threads
@@ -123,7 +123,7 @@ int main() {
         for (int i = 0; i < 11; ++i) EXPECT(fa_debug_set_option(names[i], autos[i]) == FA_OK);
         EXPECT(checked > 100000);
         EXPECT(fa_experimental_kernels() == 0);
-        EXPECT(fa_debug_set_option("kernel", 'P') == FA_ERR_BAD_OPTION);   // (retired with ABI 6; 't' names the round-6 team-list kernel)
+        EXPECT(fa_debug_set_option("kernel", 't') == FA_ERR_BAD_OPTION && fa_debug_set_option("kernel", 'P') == FA_ERR_BAD_OPTION);   // (retired with ABI 6; round 6's team-list kernel borrowed 't' for one commit: profiles/r06_tl)
     }
     // ---- debug options
     int32_t v = -7;
