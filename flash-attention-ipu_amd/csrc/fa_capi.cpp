@@ -465,8 +465,6 @@ extern "C" {
 
 int fa_abi_version(void) { return FA_ABI_VERSION; }
 
-int fa_experimental_kernels(void) { return 0; }
-
 const char* fa_last_error(void) { return g_err; }
 
 const char* fa_error_string(int code) {
@@ -484,7 +482,6 @@ const char* fa_error_string(int code) {
         case FA_ERR_TOO_LARGE: return "problem too large";
         case FA_ERR_BAD_SCALE: return "softmax_scale must be finite and > 0";
         case FA_ERR_BAD_OPTION: return "unknown debug option or value out of range";
-        case FA_ERR_UNSUPPORTED: return "unsupported combination (reserved: every combination fa_fwd serves is served with a mask / dropout too)";
         case FA_ERR_BAD_MASK: return "bad mask kind or mask pointer";
         case FA_ERR_BAD_DROPOUT: return "dropout_p must be in [0, 1)";
         default: return "unknown error";

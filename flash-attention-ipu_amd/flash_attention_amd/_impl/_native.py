@@ -17,7 +17,7 @@ _LIB = None
 _LIB_PATH = None
 
 FA_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class FaPlan(ctypes.Structure):
@@ -77,8 +77,6 @@ def _declare(lib):
     p64 = ctypes.POINTER(ctypes.c_int64)
     lib.fa_abi_version.restype = ctypes.c_int
     lib.fa_abi_version.argtypes = []
-    lib.fa_experimental_kernels.restype = ctypes.c_int
-    lib.fa_experimental_kernels.argtypes = []
     lib.fa_last_error.restype = ctypes.c_char_p
     lib.fa_last_error.argtypes = []
     lib.fa_error_string.restype = ctypes.c_char_p
@@ -114,8 +112,6 @@ def _declare(lib):
 def _raise(rc):
     lib = load_native_library()
     msg = lib.fa_last_error().decode() or lib.fa_error_string(rc).decode()
-    if rc == -13:
-        raise NotImplementedError(f"flash_attention_amd: {msg}")
     if rc in (-2, -3, -4, -5, -7, -9, -11, -12, -14, -15):
         raise ValueError(f"flash_attention_amd: {msg}")
     raise RuntimeError(f"flash_attention_amd: {msg} (code {rc})")
@@ -134,7 +130,7 @@ def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale: float = 1.0
 
 _KERNEL_CODE = {"auto": 0, "": 0, None: 0, "dma": ord("d"), "pipe": ord("p"), "pipe16": ord("x"), "kh": ord("h")}
 _OPTION_AUTO = {"kernel": 0, "qb": 0, "waves": 0, "sched": 0, "skipmax": -1, "f32_generic": 0, "table": 1, "split": 0, "pair": -1,
-                "balance": -1, "subsets": -1}
+                "balance": -1, "subsets": -1, "bsplit": -1}
 
 
 def set_debug_option(name: str, value) -> None:

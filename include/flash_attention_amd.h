@@ -47,10 +47,12 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 6   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
+#define FA_ABI_VERSION 7   /* 3: fa_bwd takes heads_kv (grouped-query backward without expanded K/V); 4: fa_plan_t gains pair / balanced,
                               fa_fwd_ex / fa_bwd_ex (attention mask or bias, dropout); 5: fa_fwd_ex / fa_bwd_ex take `dropout_state`
-                              (seed and offset in DEVICE memory: graph-safe dropout), fa_experimental_kernels(); 6: fa_plan_t gains xs, the A/B kernels
-                              (plan kernel 5, debug kernels 't' / 'P', options "fold" / "mirror") are gone */
+                              (seed and offset in DEVICE memory: graph-safe dropout); 6: fa_plan_t gains xs, the A/B kernels (plan kernel 5,
+                              debug kernels 't' / 'P', options "fold" / "mirror") are gone; 7: what only existed so that older callers link is
+                              gone too - fa_experimental_kernels() (always 0 since ABI 6) and the never-returned FA_ERR_UNSUPPORTED (-13 stays
+                              unassigned) - and the debug option "bsplit" names the backward's split groups */
 
 /* element types (reference allows FLOAT16 and FLOAT, FA.cpp:609; bf16 is new here) */
 enum { FA_DTYPE_F16 = 0, FA_DTYPE_BF16 = 1, FA_DTYPE_F32 = 2 };
@@ -71,8 +73,8 @@ enum {
     FA_ERR_TOO_LARGE = -10,         /* grid or offsets exceed what the kernel indexes */
     FA_ERR_BAD_SCALE = -11,         /* softmax_scale must be finite and > 0 */
     FA_ERR_BAD_OPTION = -12,        /* fa_debug_set_option: unknown name or value out of range */
-    FA_ERR_UNSUPPORTED = -13,       /* reserved (ABI 4 drafts returned it for a mask / dropout on operands the MFMA kernels do not take;
-                                       the generic kernels serve those now) */
+    /* (-13 is unassigned: ABI 4 drafts returned FA_ERR_UNSUPPORTED for a mask / dropout on operands the MFMA kernels do not take; the generic
+        kernels have served those since, and the name left the header with ABI 7) */
     FA_ERR_BAD_MASK = -14,          /* mask_kind out of range, or mask pointer and mask_kind disagree */
     FA_ERR_BAD_DROPOUT = -15        /* dropout_p outside [0, 1) */
 };
@@ -84,7 +86,7 @@ typedef struct fa_plan_t {
                             2 = MFMA kernel, software-pipelined 32-key steps,
                             3 = fp32 MFMA kernel (fp32 inputs, D in {64,128}, 16-byte rows),
                             4 = software-pipelined kernel on v_mfma_f32_16x16x32 (bf16/f16, D in {64,128}),
-                            (5: retired - the complementary-phase kernel left the library in ABI 6),
+                            (5 is unassigned: the complementary-phase kernel of rounds 3-4 left the library in ABI 6),
                             6 = 64-key tiles, 64-row workgroups whose 4 waves are (row block, key half) pairs (bf16/f16, D in {64,128}) */
     int32_t block_q;     /* q rows per workgroup */
     int32_t block_kv;    /* keys per LDS tile / step */
@@ -112,9 +114,6 @@ typedef struct fa_plan_t {
 } fa_plan_t;
 
 int fa_abi_version(void);
-
-/* Always 0 since ABI 6 (kept so that ABI 5 callers link): the A/B kernels of earlier rounds left the library, docs/HISTORY.md. */
-int fa_experimental_kernels(void);
 
 /* thread-local text of the last failure on this thread ("" if none) */
 const char* fa_last_error(void);
@@ -159,6 +158,9 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  *   "pair"    -1 auto | 0 | 1       q-tile pairs (n - 1 - i, i) per workgroup ('d' kernel, causal, 4 waves)
  *   "balance" -1 auto | 0 | 1       placement-balanced block order of a causal grid below one round of workgroup slots
  *   "subsets" -1 auto | 0 off       q-tile subsets for group counts that leave XCDs idle (fa_plan_t.xs)
+ *   "bsplit"  -1 auto | 0 | 1 off | 2 | 3   split groups inside the backward's workgroups (fa_bwd: kv split groups of a dQ workgroup, query-sweep
+ *                                   split groups of a dK/dV workgroup; their partial sums meet in LDS in group order).  Auto: for grids of at most
+ *                                   one workgroup per CU at L >= 1024 - 3 groups at head_dim 64 (both kernels), 2 at head_dim 128 (dQ only)
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
 int fa_debug_set_option(const char* name, int32_t value);
 int fa_debug_get_option(const char* name, int32_t* value);

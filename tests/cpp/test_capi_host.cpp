@@ -122,7 +122,6 @@ int main() {
         }
         for (int i = 0; i < 11; ++i) EXPECT(fa_debug_set_option(names[i], autos[i]) == FA_OK);
         EXPECT(checked > 100000);
-        EXPECT(fa_experimental_kernels() == 0);
         EXPECT(fa_debug_set_option("kernel", 't') == FA_ERR_BAD_OPTION && fa_debug_set_option("kernel", 'P') == FA_ERR_BAD_OPTION);   // (retired with ABI 6; round 6's team-list kernel borrowed 't' for one commit: profiles/r06_tl)
     }
     // ---- debug options

@@ -45,13 +45,13 @@ def test_library_exports_every_declared_symbol(native):
     lib = native.load_native_library()
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/flash_attention_amd.h but not exported"
-    assert lib.fa_abi_version() == 6
+    assert lib.fa_abi_version() == 7
     assert native.library_path().name == "libflash_attention.so"
 
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 6;}\n')
+    src.write_text('#include "flash_attention_amd.h"\nint main(void){fa_plan_t p; (void)p; return FA_ABI_VERSION - 7;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
 
 
@@ -208,7 +208,7 @@ def _check_builtin_rules(native):
     for gone in ("pp", "tile"):
         with pytest.raises(KeyError):
             native.set_debug_option("kernel", gone)
-    assert native.load_native_library().fa_experimental_kernels() == 0
+    assert not hasattr(native.load_native_library(), "fa_experimental_kernels")      # (ABI 7: the link-compatibility stub is gone)
     assert native.plan(4, 6, 2, torch.float32, 3, 3).kernel == 1             # generic kernel
     assert native.plan(4, 256, 64, torch.float32, 1, 1).kernel == 3             # fp32 MFMA kernel (D 64 / 128)
     assert native.plan(4, 256, 80, torch.float32, 1, 1).kernel == 1
