@@ -398,6 +398,20 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
     // KN_ / VP_ / KI_ / VI_: ring slots of K(I_+1), V(I_-1) and of the DMA targets K(I_+3), V(I_+2) - compile-time
     // constants in the 4-step groups, i-dependent values in the ragged steps; MASK_: mask mode (above);
     // QK_: a next step exists
+// MEASUREMENT BUILD ONLY (-DFA_PIPE_MAXPROBE=1; round 6, verdict item 8): what the per-step row max and rescale DECISION of an exact-max
+// arithmetic (unscaled f16) would cost the hand-ordered step - the 15-deep v_max3 chain per block, the half-wave swap, the ballot - with a
+// threshold no score reaches, so that results do not change.  The shipped library compiles it to nothing.
+#if defined(FA_PIPE_MAXPROBE) && FA_PIPE_MAXPROBE
+#define FA_MAXPROBE(S_)                                                                            \
+        _Pragma("unroll") for (int b = 0; b < QB; ++b) {                                           \
+            float mx_ = max2(S_[b][0], S_[b][1]);                                                  \
+            _Pragma("unroll") for (int e = 2; e < 16; e += 2) mx_ = max3(mx_, S_[b][e], S_[b][e + 1]); \
+            mx_ = half_swap_max(mx_);                                                              \
+            if (__builtin_amdgcn_ballot_w64((mx_ - m[b]) * c > p.scale * 3.0e38f) != 0) bad = true; \
+        }
+#else
+#define FA_MAXPROBE(S_)
+#endif
 #define FA_ISSUE_FAST(I_, KSLOT_, VSLOT_) FA_ISSUE(I_, KSLOT_, VSLOT_)
 #define FA_PUBLISH_FAST() FA_PUBLISH()
 #define FA_FAST(I_, KN_, VP_, KI_, VI_, SC_, SN_, PP_, PC_, MASK_, QK_)                             \
@@ -417,6 +431,7 @@ __device__ __forceinline__ void fa_fwd_pipe_body(const FwdParams& p) {
         fa_static_for<NPRE, (NPRE > PF_ ? NPRE : PF_)>([&](auto xi_) { constexpr int x_ = decltype(xi_)::value; FA_OPND_LOAD(x_, NK) }); \
         float mc[QB], ls[QB];                                                                      \
         _Pragma("unroll") for (int b = 0; b < QB; ++b) { mc[b] = m[b] * c; ls[b] = 0.f; }          \
+        FA_MAXPROBE(SC_)                                                                           \
         if constexpr (VB != 0 && (MASK_) == 3) {   /* the wave's last step: the dead block's P must read as 0 in the drain step's PV */ \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) { PC_[0][0][j] = (T)0.f; PC_[0][1][j] = (T)0.f; } \
         }                                                                                          \

@@ -334,6 +334,26 @@ def bwd_bhld(q, k, v, out, dout, lse_ptr, dq, dk, dv, dsum_ptr, scale, causal):
         _raise(rc)
 
 
+def bwd_packed(qkv, out, dout, lse_ptr, dqkv, dsum_ptr):
+    """fa_bwd of the packed op: qkv / dqkv contiguous [3, G, L, D], out / dout contiguous [G, L, D]; q, k, v and their gradients are
+    addressed inside the packed tensors by pointer arithmetic (no index views), the stride block is one cached entry per (L, D)."""
+    lib = _LIB or load_native_library()
+    _, G, L, D = qkv.shape
+    st = (L * D, 0, D, 0)
+    _, strides = _stride_block((st,) * 8, 8)
+    step = G * L * D * qkv.element_size()
+    p, dp = qkv.data_ptr(), dqkv.data_ptr()
+    stream, prev = _stream_for(qkv)
+    try:
+        rc = lib.fa_bwd(p, p + step, p + 2 * step, out.data_ptr(), dout.data_ptr(), lse_ptr, dp, dp + step, dp + 2 * step, dsum_ptr,
+                        G, L, D, 1, 1, strides, FA_DTYPE[qkv.dtype], 1.0, 1, stream)
+    finally:
+        if prev >= 0:
+            torch.cuda.set_device(prev)
+    if rc != 0:
+        _raise(rc)
+
+
 MASK_NONE, MASK_BOOL, MASK_BIAS = 0, 1, 2
 
 

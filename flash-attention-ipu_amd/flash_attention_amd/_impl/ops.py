@@ -289,17 +289,29 @@ class _GqaAttentionFn(torch.autograd.Function):
 
 
 class _PackedAttentionFn(torch.autograd.Function):
+    """eager path of the packed op (fa.py:38-46 is ONE custom-op call in the reference): the forward's one fp32 allocation carries LSE and the
+    backward's Dsum workspace, q / k / v and their gradients are addressed inside the packed tensors by pointer arithmetic (no index views)"""
+
     @staticmethod
     def forward(ctx, qkv, num_chunks_q, num_chunks_kv):
-        out, lse = _fwd_qkv_packed_impl(qkv, num_chunks_q, num_chunks_kv)
-        ctx.save_for_backward(qkv, out, lse)
+        qkv = qkv.contiguous()
+        _, G, L, D = qkv.shape
+        out = torch.empty((G, L, D), dtype=qkv.dtype, device=qkv.device)
+        stash = torch.empty((2, G, L), dtype=torch.float32, device=qkv.device)       # [0] LSE, [1] the backward's Dsum workspace
+        if out.numel() > 0:
+            _native.fwd_packed(qkv, out, stash, num_chunks_q, num_chunks_kv)          # (lse = the first [G, L] block of the stash)
+        ctx.save_for_backward(qkv, out, stash)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        qkv, out, lse = ctx.saved_tensors
-        return _bwd_qkv_packed_impl(qkv, out, dout, lse), None, None
+        qkv, out, stash = ctx.saved_tensors
+        dqkv = torch.empty_like(qkv)
+        if dqkv.numel() > 0:
+            p0 = stash.data_ptr()
+            _native.bwd_packed(qkv, out, dout.contiguous(), p0, dqkv, p0 + stash.stride(0) * 4)
+        return dqkv, None, None
 
 
 # ---- eager training on [B, H, L, D] views: no reshape, no copies, the caller's layout kept ---------------------------------------------
@@ -389,7 +401,8 @@ def attention_gqa(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal=Tr
         return out.view(B, H, L, D)
     if torch.compiler.is_compiling():
         return fwd_gqa(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)[0]
-    return _GqaAttentionFn.apply(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)
+    # eager: the same kernels through the lean [B, H, L, D] path (operand layout kept, cached stride blocks, one fp32 allocation for LSE + Dsum)
+    return _BhldAttentionFn.apply(q, k, v, softmax_scale, num_chunks_q, num_chunks_kv, causal)
 
 
 def attention_qkv_packed(qkv, num_chunks_q, num_chunks_kv):

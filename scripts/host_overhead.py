@@ -27,3 +27,12 @@ def fb(fn):
     o = fn(qg, qg, qg, is_causal=True); o.sum().backward(); qg.grad = None
 print(f"stock sdpa fwd+bwd              {bench(lambda: fb(stock), 500):7.1f} us/call")
 print(f"override  fwd+bwd               {bench(lambda: fb(patched), 500):7.1f} us/call")
+# the packed op (the reference's own entry point), tiny problem
+import flash_attention_amd as fa
+qkv = torch.randn(3, 8, 64, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+gp = torch.randn(8, 64, 64, device="cuda", dtype=torch.bfloat16)
+def fbp():
+    o = fa.flash_attention_qkv_packed(qkv, 1, 1); o.backward(gp); qkv.grad = None
+with torch.no_grad():
+    print(f"packed op (no grad)             {bench(lambda: fa.flash_attention_qkv_packed(qkv, 1, 1)):7.1f} us/call")
+print(f"packed op fwd+bwd               {bench(fbp, 500):7.1f} us/call")

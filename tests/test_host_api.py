@@ -484,3 +484,31 @@ def test_bench_engine_clock_from_sysfs_needs_no_child_process(monkeypatch, tmp_p
     monkeypatch.setattr(bench, "sysfs_max_sclk_mhz", lambda index: 2400)
     monkeypatch.setattr(subprocess, "run", lambda *a, **kw: (_ for _ in ()).throw(AssertionError("no child process when sysfs answers")))
     assert bench.smi_clock_mhz(0) == 2400
+
+
+def test_design_md_quotes_the_tree(native):
+    """Round-5 verdict, item 7: DESIGN.md drifted from the tree (a pass count two rounds old, rocprofv3's register field quoted as the kernel's
+    register count).  Every `GPUTEST_rNN.json`: **N passed** it quotes must be that driver record's count, the count it gives for the final
+    sources must not be below the newest driver record (tests are only added), and the headline kernel's VGPR figure must be the build's."""
+    design = (ROOT / "DESIGN.md").read_text()
+    quoted = re.findall(r"`GPUTEST_r(\d+)\.json`: \*\*([\d ]+) passed", design)
+    assert quoted, "DESIGN.md section 6 names the driver's GPU test record it quotes"
+    newest = 0
+    for rnd, count in quoted:
+        rec = ROOT / f"GPUTEST_r{rnd}.json"
+        if rec.exists():
+            passed = json.loads(rec.read_text())["gpu_tests_passed"]
+            assert int(count.replace(" ", "")) == passed, f"DESIGN.md quotes {count} for GPUTEST_r{rnd}.json, the record says {passed}"
+            newest = max(newest, passed)
+    for rec in ROOT.glob("GPUTEST_r*.json"):
+        newest = max(newest, json.loads(rec.read_text()).get("gpu_tests_passed") or 0)
+    final = re.search(r"final sources:\s+\*\*([\d ]+) passed", design)
+    assert final and int(final.group(1).replace(" ", "")) >= newest
+    m = re.search(r"(\d+) VGPRs \(the build's resource remark", design)
+    assert m, "DESIGN.md section 3.1 quotes the headline kernel's register count from the build"
+    remarks = ROOT / "flash-attention-ipu_amd" / "build" / "obj" / "fa_fwd_pipe.remarks"
+    if remarks.exists():
+        text = remarks.read_text()
+        at = text.index("fa_fwd_pipe_kernelIDF16bLi64ELi4ELi2ELb1EE")
+        vgprs = int(re.search(r"VGPRs: (\d+)", text[at:]).group(1))
+        assert int(m.group(1)) == vgprs, f"DESIGN.md says {m.group(1)} VGPRs for the headline kernel, the build says {vgprs}"
