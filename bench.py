@@ -13,14 +13,18 @@ starts N fresh rank processes itself (torch.distributed.run as a child; never an
 line and the exit code.
   * default (cfg2, "scaling": "weak"): every rank owns its own 128 groups (groups are independent, FA.cpp:186); the
     only exchange is the gather of O, double-buffered so the gather of step s overlaps the kernel of step s+1.
-  * --config cfg5 ("scaling": "strong") = BASELINE configs[4] as written: G = 64*32 = 2048 groups in total, L = 8192,
-    D = 64, G/N groups per rank, cut into slabs so the gather of slab s overlaps the kernel of slab s+1.
+  * right after that headline, in the same launch and process group, BASELINE configs[4] ("scaling": "strong": G = 64*32 = 2048 groups
+    in total, L = 8192, D = 64, G/N groups per rank, cut into slabs so the gather of slab s overlaps the kernel of slab s+1) runs as
+    `secondary.cfg5_strong` {value, kernel_only_value, ms_per_step, exchange_only_ms, achieved_GBps_per_link, expected_link_bound_ms,
+    n1_anchor_kernel_tflops, scaling_efficiency, kernel_scaling_efficiency} with its own exchange selection (strong_record);
+  * --config cfg5 runs configs[4] as the headline instead.
 `value` is end-to-end (gather included); `roofline.achieved` is kernel-only (HIP events around the launches) and
-`kernel_only_value` repeats it as a whole-job figure.
+`kernel_only_value` repeats it as a whole-job figure; `scaling_efficiency` = value / (N x the one-GPU kernel-only rate of the launch shape,
+measured in the same run on every rank): 1.0 = the exchange is free.
 
 N = 1 also reports, in `secondary`, a small-grid shape (split-KV plan), the backward at cfg2, and the other single-GPU configs of BASELINE.json (cfg3 long context, the cfg5
-per-GPU shard shape, and cfg4: a GPT-2-small forward step through the automatic SDPA override with the attention
-share) - the headline stays cfg2.
+per-GPU shard shape, `cfg5_full` = ALL 2048 groups of configs[4] on this one GPU - the anchor of its 1/2/4/8 strong-scaling curve - and cfg4: a
+GPT-2-small forward step through the automatic SDPA override with the attention share) - the headline stays cfg2.
 
 FLOPs = 2*G*L^2*D (causal convention); roofline = MFMA, dense bf16 peak 2.5 PFLOP/s.
 The cpu_baseline leg times the oracle's dense restatement of the reference CPU path

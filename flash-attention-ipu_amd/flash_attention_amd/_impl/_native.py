@@ -368,6 +368,55 @@ def _mask_args(mask, q):
     return mask.data_ptr(), kind, _strides3((mask.stride(0), mask.stride(1), mask.stride(2)))
 
 
+_U64 = 2 ** 64 - 1
+
+
+def _mask_args_cached(mask, q):
+    """(pointer, kind, cached stride block) of a mask already expanded to [B, H, L, L] - _mask_args without the per-call ctypes array"""
+    if mask is None:
+        return None, MASK_NONE, None
+    kind = MASK_BOOL if mask.dtype in (torch.bool, torch.uint8) else MASK_BIAS
+    if kind == MASK_BIAS and mask.dtype != q.dtype:
+        raise ValueError("a float attn_mask must have the dtype of the query")
+    return mask.data_ptr(), kind, _stride_block(mask.stride(), 1)
+
+
+def fwd_ex_bhld(q, k, v, out, lse_ptr, scale, causal, mask, dropout_p, seed, offset, state):
+    """fa_fwd_ex on [B, H, L, D] views, the eager training path's lean form (cached stride blocks; lse_ptr: a device address or None)"""
+    lib = _LIB or load_native_library()
+    B, H, L, D = q.shape
+    mptr, kind, mst = _mask_args_cached(mask, q)
+    stream, prev = _stream_for(q)
+    try:
+        rc = lib.fa_fwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse_ptr, B * H, L, D, H, k.shape[1],
+                           _stride_block(q.stride(), 1), _stride_block(k.stride(), 1), _stride_block(v.stride(), 1), _stride_block(out.stride(), 1),
+                           1, 1, FA_DTYPE[q.dtype], scale, 1 if causal else 0, mptr, kind, mst, dropout_p, seed & _U64, offset & _U64,
+                           state.data_ptr() if state is not None else None, stream)
+    finally:
+        if prev >= 0:
+            torch.cuda.set_device(prev)
+    if rc != 0:
+        _raise(rc)
+
+
+def bwd_ex_bhld(q, k, v, out, dout, lse_ptr, dq, dk, dv, dsum_ptr, scale, causal, mask, dropout_p, seed, offset, state):
+    """fa_bwd_ex on [B, H, L, D] views (k, v, dk, dv [B, H_kv, L, D]), the eager training path's lean form"""
+    lib = _LIB or load_native_library()
+    B, H, L, D = q.shape
+    _, strides = _stride_block((q.stride(), k.stride(), v.stride(), out.stride(), dout.stride(), dq.stride(), dk.stride(), dv.stride()), 8)
+    mptr, kind, mst = _mask_args_cached(mask, q)
+    stream, prev = _stream_for(q)
+    try:
+        rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse_ptr, dq.data_ptr(), dk.data_ptr(),
+                           dv.data_ptr(), dsum_ptr, B * H, L, D, H, k.shape[1], strides, FA_DTYPE[q.dtype], scale, 1 if causal else 0,
+                           mptr, kind, mst, dropout_p, seed & _U64, offset & _U64, state.data_ptr() if state is not None else None, stream)
+    finally:
+        if prev >= 0:
+            torch.cuda.set_device(prev)
+    if rc != 0:
+        _raise(rc)
+
+
 def fwd_ex(q, k, v, out, lse, L, D, scale, causal, mask, dropout_p, seed, offset, state=None):
     """fa_fwd_ex on [B, H, L, D] views (k, v may carry fewer heads); mask: None or a [B, H, L, L] view (see _mask_args);
     state: None or an int64 [2] DEVICE tensor {seed, offset} read by the kernels instead of the two integers (graph-safe dropout)."""

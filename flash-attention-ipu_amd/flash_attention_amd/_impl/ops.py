@@ -455,23 +455,39 @@ def _bwd_ex_impl(q, k, v, out, dout, lse, mask, softmax_scale, causal, dropout_p
 
 
 class _ExtraAttentionFn(torch.autograd.Function):
+    """eager path of the mask / dropout kernels, as lean as _BhldAttentionFn: result and gradients in the operands' layout, LSE + Dsum in one
+    allocation, cached stride blocks (nanoGPT's own `shakespeare_char` config trains with attention dropout: this is its per-layer call)"""
+
     @staticmethod
     def forward(ctx, q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state):
-        out, lse = _fwd_ex_impl(q, k, v, mask, softmax_scale, causal, dropout_p, seed, offset, state)
+        out = _dense_like(q)
+        q, k, v = _rows(q), _rows(k), _rows(v)
+        B, H, L, _ = q.shape
+        stash = torch.empty((2, B * H, L), dtype=torch.float32, device=q.device)      # [0] LSE, [1] the backward's Dsum workspace
+        if out.numel() > 0:
+            _native.fwd_ex_bhld(q, k, v, out, stash.data_ptr(), softmax_scale, causal, mask, dropout_p, seed, offset, state)
         extra = tuple(t for t in (mask, state) if t is not None)
-        ctx.save_for_backward(q, k, v, out, lse, *extra)
+        ctx.save_for_backward(q, k, v, out, stash, *extra)
         ctx.args = (softmax_scale, causal, dropout_p, seed, offset, mask is not None, state is not None)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        q, k, v, out, lse = ctx.saved_tensors[:5]
+        saved = ctx.saved_tensors
+        q, k, v, out, stash = saved[:5]
         softmax_scale, causal, dropout_p, seed, offset, has_mask, has_state = ctx.args
-        rest = list(ctx.saved_tensors[5:])
-        mask = rest.pop(0) if has_mask else None
-        state = rest.pop(0) if has_state else None
-        dq, dk, dv = _bwd_ex_impl(q, k, v, out, dout, lse, mask, softmax_scale, causal, dropout_p, seed, offset, state)
+        mask = saved[5] if has_mask else None
+        state = saved[5 + (1 if has_mask else 0)] if has_state else None
+        dout = _rows(dout)
+        if k.shape[1] == q.shape[1]:
+            dq, dk, dv = _dense_like(q, 3).unbind(0)
+        else:
+            dq, dk, dv = _dense_like(q), _dense_like(k), _dense_like(v)
+        if dq.numel() > 0:
+            p0 = stash.data_ptr()
+            _native.bwd_ex_bhld(q, k, v, out, dout, p0, dq, dk, dv, p0 + stash.stride(0) * 4, softmax_scale, causal, mask, dropout_p, seed,
+                                offset, state)
         return dq, dk, dv, None, None, None, None, None, None, None
 
 

@@ -107,3 +107,29 @@ def test_bench_multi_gpu_control_flow_on_rccl_at_world_size_1(extra):
         assert s5["value"] > 500 and s5["kernel_only_value"] >= s5["value"] * 0.9 and s5["exchange_only_ms"] > 0
         assert s5["exchange_selected"] == ("direct" if "--gather" in extra else s5["exchange_selected"]) and s5["exchange_selected"] in ("allgather", "direct")
         assert 0.5 < s5["scaling_efficiency"] <= 1.05 and s5["kernel"] in ("fwd_pipe", "fwd_pipe16", "fwd_dma")
+
+
+def test_bench_two_rank_processes_on_the_one_gpu_with_the_real_configs():
+    """`FA_BENCH_REHEARSE=1 python bench.py --gpus 2`: two rank PROCESSES started by bench.py itself (one torch.distributed.run child), both on
+    cuda:0, gloo for the barriers and reductions, no exchange - the multi-process control flow of the driver's N > 1 command on the REAL configs:
+    the cfg2 weak headline (128 groups per rank), then BASELINE config 5 split over two ranks (1 024 groups each, 8 slabs of 128), the
+    max-over-ranks reductions, rank 0's one JSON line.  (RCCL itself needs one GPU per rank: its call path runs at world size 1 above.)"""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(FA_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--ramp-ms", "30", "--no-probes"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 200 and rec["config"]["groups_per_gpu"] == 128
+    s5 = rec["secondary"]["cfg5_strong"]
+    assert "error" not in s5, s5
+    assert s5["n_gpus"] == 2 and s5["groups_total"] == 2048 and s5["groups_per_gpu"] == 1024 and s5["groups_per_launch"] == 128
+    assert s5["value"] > 200 and s5["kernel_only_value"] > 0 and s5["scaling_efficiency"] > 0 and s5["n1_anchor_kernel_tflops"] > 200

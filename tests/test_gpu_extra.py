@@ -536,8 +536,9 @@ def test_attn_mask_stays_on_the_hip_path_under_torch_compile():
     lens = torch.tensor([200, 256], device="cuda")
     mask = (torch.arange(L, device="cuda")[None, :] < lens[:, None]).view(B, 1, 1, L)
     calls = []
-    real = _native.fwd_ex
+    real, real_eager = _native.fwd_ex, _native.fwd_ex_bhld          # (the custom op's entry point, and the eager path's lean form of it)
     _native.fwd_ex = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    _native.fwd_ex_bhld = lambda *a, **kw: (calls.append(1), real_eager(*a, **kw))[1]
     try:
         def block(q, k, v, mask):
             return F.scaled_dot_product_attention(q * 1.0, k, v, attn_mask=mask) + 1.0
@@ -549,7 +550,7 @@ def test_attn_mask_stays_on_the_hip_path_under_torch_compile():
         out = compiled(q, k, v, mask)
         gc = torch.autograd.grad(out, (q, k, v), torch.ones_like(out))
     finally:
-        _native.fwd_ex = real
+        _native.fwd_ex, _native.fwd_ex_bhld = real, real_eager
     assert n_eager == 1 and len(calls) == 2, "the compiled block must call fa_fwd_ex (not stock SDPA)"
     assert torch.equal(out, eager)
     for a, b in zip(gc, ge):
