@@ -512,3 +512,29 @@ def test_design_md_quotes_the_tree(native):
         at = text.index("fa_fwd_pipe_kernelIDF16bLi64ELi4ELi2ELb1EE")
         vgprs = int(re.search(r"VGPRs: (\d+)", text[at:]).group(1))
         assert int(m.group(1)) == vgprs, f"DESIGN.md says {m.group(1)} VGPRs for the headline kernel, the build says {vgprs}"
+
+
+def test_eager_training_path_helpers_keep_the_operand_layout_and_cache_stride_blocks(native):
+    """Round 6 (host cost of an eager forward + backward): `ops._dense_like` allocates results and gradients in the LAYOUT of the operand
+    (a head-inner [B, L, H, D] view stays head-inner, three gradients come as one allocation), and `_native._stride_block` builds the ctypes
+    stride block of a layout once."""
+    from flash_attention_amd._impl import ops
+
+    B, H, L, D = 2, 3, 5, 8
+    contiguous = torch.empty(B, H, L, D)
+    head_inner = torch.empty(B, L, 3 * H * D).split(H * D, dim=2)[1].view(B, L, H, D).transpose(1, 2)      # nanoGPT's k
+    assert head_inner.stride() == (L * 3 * H * D, D, 3 * H * D, 1)
+    a, b = ops._dense_like(contiguous), ops._dense_like(head_inner)
+    assert a.shape == b.shape == (B, H, L, D) and a.is_contiguous()
+    assert b.stride() == (L * H * D, D, H * D, 1) and b.transpose(1, 2).is_contiguous()      # head-inner in, head-inner out (dense)
+    g3 = ops._dense_like(head_inner, 3)
+    assert g3.shape == (3, B, H, L, D) and g3.stride() == (B * H * L * D, L * H * D, D, H * D, 1)
+    dq, dk, dv = g3.unbind(0)
+    assert dq.stride() == b.stride() and dk.data_ptr() - dq.data_ptr() == B * H * L * D * 4
+    # one ctypes block per distinct layout, the same object on the next call; forward blocks (3 strides) and backward blocks (8 x 3) do not collide
+    blk = native._stride_block(head_inner.stride(), 1)
+    assert blk is native._stride_block(head_inner.stride(), 1) and list(blk) == [L * 3 * H * D, D, 3 * H * D]
+    key = (contiguous.stride(),) * 8
+    arr, ptr = native._stride_block(key, 8)
+    assert native._stride_block(key, 8)[0] is arr and list(arr) == [H * L * D, L * D, D] * 8
+    assert native._stride_block(contiguous.stride(), 1) is not arr
