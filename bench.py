@@ -69,6 +69,17 @@ PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MIC
 
 _emit_lock = threading.Lock()
 _emitted = [False]
+_json_fd = [None]       # the process's ORIGINAL stdout, once keep_stdout_for_the_json_line() has pointed fd 1 at stderr
+
+
+def keep_stdout_for_the_json_line() -> None:
+    """stdout carries rank 0's ONE JSON line and nothing else: RCCL prints a five-line banner (version, host, library path) on fd 1 when its
+    first communicator comes up, and any library may chat there.  Everything that writes to fd 1 from here on - C libraries included - lands on
+    stderr; the JSON line goes to a private duplicate of the original stdout."""
+    if _json_fd[0] is None:
+        sys.stdout.flush()
+        _json_fd[0] = os.dup(1)
+        os.dup2(2, 1)
 
 
 def emit_once(line) -> None:
@@ -76,7 +87,12 @@ def emit_once(line) -> None:
     with _emit_lock:
         if not _emitted[0]:
             _emitted[0] = True
-            print(json.dumps(line), flush=True)
+            text = (json.dumps(line) + "\n").encode()
+            if _json_fd[0] is None:
+                sys.stdout.flush()
+                os.write(1, text)
+            else:
+                os.write(_json_fd[0], text)
 
 
 def csrc_fingerprint(kernels=None) -> str:
@@ -597,6 +613,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)          # (nothing above has imported torch.cuda or made a HIP call)
 
+    keep_stdout_for_the_json_line()
     smi_mhz = smi_clock_mhz(int(os.environ.get("LOCAL_RANK", "0"))) if int(os.environ.get("RANK", "0")) == 0 else None   # (before the first HIP call)
     import torch
     import torch.distributed as dist

@@ -181,7 +181,8 @@ def test_bench_n2_control_flow_and_json_schema_on_cpu(config, extra):
                          capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]           # rank 0 alone prints
+    assert len(lines) == 1, res.stdout[-2000:]
+    assert res.stdout.strip().splitlines() == lines, "stdout carries the JSON line and nothing else (RCCL's banner, library chatter: stderr)"           # rank 0 alone prints
     line = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "kernel_only_value", "exchange_bytes_per_rank"):
@@ -240,6 +241,7 @@ def test_bench_rehearsal_at_8_ranks_on_cpu(config):
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) < 8000, res.stdout[-2000:]
+    assert res.stdout.strip().splitlines() == lines, "stdout carries the JSON line and nothing else"
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["scaling"] == ("strong" if config == "cfg5" else "weak")
     assert line["config"]["exchange_selected"] in ("allgather", "direct")

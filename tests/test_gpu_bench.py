@@ -20,6 +20,7 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_every_baseline_con
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
+    assert res.stdout.strip().splitlines() == lines, "stdout carries the JSON line and nothing else (RCCL's banner, library chatter: stderr)"
     # (the cpu_baseline object this run skips adds ~650 bytes)
     assert len(lines[0]) + 700 < 8000, f"{len(lines[0])} bytes: the driver keeps an 8 KB tail of stdout"
     rec = json.loads(lines[0])

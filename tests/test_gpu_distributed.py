@@ -80,6 +80,7 @@ def test_bench_multi_gpu_control_flow_on_rccl_at_world_size_1(extra):
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
+    assert res.stdout.strip().splitlines() == lines, "stdout carries the JSON line and nothing else (RCCL's banner, library chatter: stderr)"
     assert len(lines[0]) < 8000, "the driver keeps an 8 KB tail: the line must fit"
     rec = json.loads(lines[0])
     strong = "cfg5" in extra
@@ -127,6 +128,7 @@ def test_bench_two_rank_processes_on_the_one_gpu_with_the_real_configs():
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
+    assert res.stdout.strip().splitlines() == lines, "stdout carries the JSON line and nothing else (RCCL's banner, library chatter: stderr)"
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 200 and rec["config"]["groups_per_gpu"] == 128
     s5 = rec["secondary"]["cfg5_strong"]
