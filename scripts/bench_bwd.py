@@ -7,7 +7,8 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "flash-attention-ipu_amd")]
 import torch
 from flash_attention_amd._impl import _native
-CFG = {"cfg2": (128, 4096, 64), "d128": (64, 4096, 128), "short": (512, 1024, 64), "cfg5": (256, 8192, 64), "gpt": (96, 1024, 64)}
+CFG = {"cfg2": (128, 4096, 64), "d128": (64, 4096, 128), "short": (512, 1024, 64), "cfg5": (256, 8192, 64), "gpt": (96, 1024, 64),
+       "b1l8k": (1, 8192, 64), "g2l16k": (2, 16384, 64), "b1l32k": (1, 32768, 64), "g4l4k": (4, 4096, 64), "g8l2k": (8, 2048, 64), "g4l8kd128": (4, 8192, 128)}
 DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 args = sys.argv[1:]
 ab = []
