@@ -309,3 +309,39 @@ def test_backward_fp16_at_the_reference_cpp_test_size():
     out.backward(dout.cuda())
     _blocked_check(x, dout, range(G), 1.0, "t_cpp fp16 8x2048x128")
     assert (x.grad.float() - 0).abs().max().item() < 1e4
+
+
+def test_override_training_at_the_headline_shape_on_head_inner_operands():
+    """Round 6: the eager training path of the override (`ops._BhldAttentionFn`) at the headline shape `[8,16,4096,64]` on nanoGPT's operand layout -
+    q, k, v are head-inner slices of ONE fused [B, T, 3C] projection, read through their strides (no reshape, no copy).  Result and gradients come
+    back head-inner; three sampled groups against the blocked fp64 oracle; bit-identical to the same call on contiguous copies of the operands
+    (the layout is an addressing matter, not an arithmetic one) and from call to call."""
+    import torch.nn.functional as F
+
+    import flash_attention_amd.auto  # noqa: F401
+
+    B, H, L, D = 8, 16, 4096, 64
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    proj = (torch.randn(B, L, 3 * H * D, device="cuda", generator=gen) * 0.8).to(torch.bfloat16).requires_grad_(True)
+    dout = torch.randn(B, H, L, D, device="cuda", generator=gen).to(torch.bfloat16)
+
+    def run(p, contiguous):
+        q, k, v = (t.view(B, L, H, D).transpose(1, 2) for t in p.split(H * D, dim=2))
+        if contiguous:
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+        (g,) = torch.autograd.grad(out, p, dout)
+        return out, g
+
+    out, g = run(proj, False)
+    assert out.stride() == (L * H * D, D, H * D, 1), "head-inner operands: head-inner result"
+    assert torch.isfinite(g).all()
+    out2, g2 = run(proj, False)
+    assert torch.equal(out, out2) and torch.equal(g, g2)
+    outc, gc = run(proj, True)
+    assert torch.equal(out, outc) and torch.equal(g, gc), "strided and contiguous operands: the same arithmetic"
+    # as a packed launch for the oracle: groups (batch 0 head 0), (batch 3 head 9), (batch 7 head 15)
+    qkv = proj.detach().view(B, L, 3, H, D).permute(2, 0, 3, 1, 4).reshape(3, B * H, L, D)
+    x = qkv.clone().requires_grad_(True)
+    x.grad = g.view(B, L, 3, H, D).permute(2, 0, 3, 1, 4).reshape(3, B * H, L, D).contiguous()
+    _blocked_check(x, dout.reshape(B * H, L, D), (0, 3 * H + 9, B * H - 1), D ** -0.5, "override training, head-inner, cfg2 shape")
