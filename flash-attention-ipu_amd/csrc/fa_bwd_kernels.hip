@@ -526,9 +526,15 @@ __global__ __launch_bounds__(NWAVES * QS * 64) void fa_bwd_dq_kernel(const BwdPa
 // QS > 1 (query-sweep split groups, for grids that cannot fill the chip): QS groups of NWAVES waves own the SAME 128 keys; group s streams the
 // items s, s + QS, ... of the (head, query tile) stream through buffers of its own, in lock step with the others, and the groups' dK^T / dV^T
 // partial sums meet in LDS after the loop, added in group order (deterministic: no atomics, as everywhere in this backward).
-template <typename T, int D, int NWAVES, int EXTRA = 0, int PASS = 0, int QS = 1>
+// QH = 2 (row halves, head_dim 128's form of the same idea - its single sweep fills 256 registers, so a second group cannot run a sweep of its own): the
+// workgroup has TWO groups of NWAVES waves on the same 128 keys AND the same streamed tiles (one set of LDS buffers: no extra LDS); group h computes
+// the 32-row half h of every 64-row query tile, i.e. half of each item's products - twice the waves per SIMD on half the chain per item - and
+// the two groups' dK^T / dV^T partial sums meet in LDS after the loop (group 1's added to group 0's: deterministic).  Group 0 issues the Q tile
+// DMA, group 1 the dO tile's.
+template <typename T, int D, int NWAVES, int EXTRA = 0, int PASS = 0, int QS = 1, int QH = 1>
 __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     static_assert(QS == 1 || (EXTRA == 0 && PASS == 0), "query-sweep split groups: the plain kernels only");
+    static_assert(QH == 1 || (QH == 2 && QS == 1 && EXTRA == 0 && PASS == 0), "row halves: the plain unsplit sweep only");
     using E = Elt<T>;
     using vec8 = typename E::vec8;
     using GM = BwdGeom<T, D, NWAVES>;
@@ -552,7 +558,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     const int L = p.L;
     const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int ws = QS == 1 ? 0 : wave_all / NWAVES;                    // query-sweep split group of this wave
-    const int wave = QS == 1 ? wave_all : wave_all - ws * NWAVES;      // its 32 keys inside the group
+    const int wh = QH == 1 ? 0 : wave_all / NWAVES;                    // row-half group of this wave (QH = 2)
+    const int wave = (QS == 1 && QH == 1) ? wave_all : wave_all - (ws + wh) * NWAVES;      // its 32 keys inside the group
     const int tid = (int)threadIdx.x, lane = tid & 63;                 // (tid: the unsplit kernel's thread index; split groups use wave / lane)
     // (per group: Q / dO images, then rowc = [buf][ lse2 0..63 | dsum 0..63 ] - the pointers are formed inside the group's copy of the loop)
     const int r = lane & 31, h = lane >> 5;
@@ -629,16 +636,16 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         if (d_full) {                                                                              \
             fa_static_for<0, PPW>([&](auto ji_) {                                                  \
                 constexpr int j = decltype(ji_)::value;                                            \
-                lds_dma_b128_imm<64 * j>(qr_, smem_lds + (BUF_) * IMG_B + j * 4096 + wave * 1024, q_vb); \
-                lds_dma_b128_imm<64 * j>(gr_, smem_lds + (NB + (BUF_)) * IMG_B + j * 4096 + wave * 1024, g_vb); \
+                if (QH == 1 || wh == 0) lds_dma_b128_imm<64 * j>(qr_, smem_lds + (BUF_) * IMG_B + j * 4096 + wave * 1024, q_vb); \
+                if (QH == 1 || wh == 1) lds_dma_b128_imm<64 * j>(gr_, smem_lds + (NB + (BUF_)) * IMG_B + j * 4096 + wave * 1024, g_vb); \
             });                                                                                    \
         } else {   /* (the lane's chunk through an opaque copy: the per-piece offsets are formed here, not kept in 2 PPW registers across the loop) */ \
             int c0_ = d_c0;                                                                        \
             asm volatile("" : "+v"(c0_));                                                          \
             _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                      \
                 const bool in_ = 4 * j + c0_ < dchunks;                                            \
-                lds_dma_b128(qr_, smem_lds + (BUF_) * IMG_B + j * 4096 + wave * 1024, in_ ? q_vb + 64 * j : 0x80000000u); \
-                lds_dma_b128(gr_, smem_lds + (NB + (BUF_)) * IMG_B + j * 4096 + wave * 1024, in_ ? g_vb + 64 * j : 0x80000000u); \
+                if (QH == 1 || wh == 0) lds_dma_b128(qr_, smem_lds + (BUF_) * IMG_B + j * 4096 + wave * 1024, in_ ? q_vb + 64 * j : 0x80000000u); \
+                if (QH == 1 || wh == 1) lds_dma_b128(gr_, smem_lds + (NB + (BUF_)) * IMG_B + j * 4096 + wave * 1024, in_ ? g_vb + 64 * j : 0x80000000u); \
             }                                                                                      \
         }                                                                                          \
         }                                                                                          \
@@ -760,6 +767,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
             const float* rc_ = rowc + (BUF_) * 128;                                                \
             _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {       /* query rows q0 + 32 hb .. +31 */ \
+                if (QH == 2 && hb != wh) continue;                  /* row halves: the other group's half */ \
                 if (causal && q0 + 32 * hb + 31 < key0) continue;   /* every query of this half lies before the wave's keys */ \
                 f32x16 s0, t0;                                                                     \
                 /* dP accumulators start at -Dsum[q] (rowc holds the negated sums) */              \
@@ -1022,6 +1030,31 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         }
         if (ws != 0) return;
     }
+    if constexpr (QH == 2) {      // row halves: group 1's dK^T, then its dV^T, into group 0's through LDS (every buffer is free after the loop's last barrier)
+        float* xb = (float*)smem_all + wave * (DT * 16 * 64) + lane;
+        static_assert(QH == 1 || NWAVES * DT * 16 * 64 * 4 <= GROUP_B, "exchange area must fit the Q / dO buffers");
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            if (which > 0) __syncthreads();           // (group 0 has read dK's values)
+            if (wh == 1) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) xb[(dt * 16 + e) * 64] = which == 0 ? dk[dt][e] : dv[dt][e];
+            }
+            __syncthreads();
+            if (wh == 0) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if (which == 0) dk[dt][e] += xb[(dt * 16 + e) * 64];
+                        else dv[dt][e] += xb[(dt * 16 + e) * 64];
+                    }
+            }
+        }
+        if (wh != 0) return;
+    }
     if (!wave_active || key >= L) return;
     int key_e = key;                                // (the output rows' addresses are formed here, not carried through the loop)
     asm volatile("" : "+v"(key_e));
@@ -1047,9 +1080,9 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 
 #ifndef FA_BWD_BODY_ONLY
 // (head_dim 128: 254 + 4 registers as allocated freely - held to 256 = two waves per SIMD)
-template <typename T, int D, int NWAVES, int QS = 1>
-__global__ __launch_bounds__(NWAVES * QS * 64, D == 128 ? 2 : QS == 3 ? 3 : 1) void fa_bwd_dkdv_kernel(const BwdParams p) {
-    fa_bwd_dkdv_body<T, D, NWAVES, 0, 0, QS>(p);
+template <typename T, int D, int NWAVES, int QS = 1, int QH = 1>
+__global__ __launch_bounds__(NWAVES * QS * QH * 64, D == 128 ? 2 : QS == 3 ? 3 : 1) void fa_bwd_dkdv_kernel(const BwdParams p) {
+    fa_bwd_dkdv_body<T, D, NWAVES, 0, 0, QS, QH>(p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1073,8 +1106,10 @@ static hipError_t launch_bwd_t(const BwdParams& p, hipStream_t stream) {
         e = p.qs_q == 2 ? launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 2>), qgrid, dim3(512), 0, stream, p)
                         : launch1((const void*)(fa_bwd_dq_kernel<T, D, 4>), qgrid, dim3(256), 0, stream, p);
         if (e != hipSuccess) return e;
-        // (no split dK/dV at head_dim 128: the unsplit kernel fills its 256 registers; the split form spilled eight - not built)
-        return launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), kgrid, dim3(256), 0, stream, p);
+        // (head_dim 128: the single sweep fills its 256 registers, so a second group cannot run a sweep of its own - it takes the other ROW HALF of
+        //  every item instead: QH = 2, the same LDS buffers, two waves per SIMD)
+        return p.qs_kv == 2 ? launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4, 1, 2>), kgrid, dim3(512), 0, stream, p)
+                            : launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), kgrid, dim3(256), 0, stream, p);
     } else {
         e = launch1((const void*)(fa_bwd_dq_kernel<T, D, 4>), qgrid, dim3(256), 0, stream, p);
         if (e == hipSuccess) e = launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), kgrid, dim3(256), 0, stream, p);

@@ -851,7 +851,8 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
             if ((int64_t)p.G * p.nq_tiles <= 256) p.qs_q = qs_max;
             if ((int64_t)p.Gkv * p.nk_tiles <= 256) p.qs_kv = qs_max;
         }
-        if (p.D == 128) p.qs_kv = 1;       // (the head_dim 128 dK/dV kernel has no split form: it fills its 256 registers unsplit)
+        // (head_dim 128: qs_kv = 2 selects the dK/dV kernel's ROW-HALVES form - two groups on the same streamed tiles, fa_bwd_kernels.hip QH - since its
+        //  single sweep fills the register file and a second group cannot run a sweep of its own)
     }
     if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     p.scale = softmax_scale;

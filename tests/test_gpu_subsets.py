@@ -165,7 +165,8 @@ def test_backward_block_subsets_vs_autograd_fp64_and_whole_group_map(B, H, Hkv, 
     (1, 1, 1, 2048, 64, torch.bfloat16, 3, True),       # the rule's own case: one group, 16 blocks per grid
     (1, 2, 2, 1500, 64, torch.float16, 3, True),        # ragged L: the groups' item counts differ by one
     (1, 4, 2, 1024, 64, torch.bfloat16, 2, True),       # grouped-query heads: the dK/dV stream is (head, query tile) items
-    (1, 2, 2, 2048, 128, torch.bfloat16, 2, True),      # head_dim 128: dQ split, dK/dV unsplit
+    (1, 2, 2, 2048, 128, torch.bfloat16, 2, True),      # head_dim 128: dQ with two kv split groups, dK/dV with two row-half groups on shared tiles
+    (1, 6, 2, 1100, 128, torch.float16, 2, True),       # the same with grouped-query heads and a ragged length
     (2, 1, 1, 4096, 64, torch.bfloat16, -1, True),      # whatever the library picks by itself
     (1, 2, 2, 1024, 64, torch.bfloat16, 3, False),      # no causal mask: every block sweeps everything
 ])
