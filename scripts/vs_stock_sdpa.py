@@ -2,7 +2,7 @@
 
 usage: python scripts/vs_stock_sdpa.py [out.md]
 `import flash_attention_amd.auto` patches F.scaled_dot_product_attention; `.__wrapped__` is stock SDPA.  Each timing = the best of 3 rounds of
-N back-to-back calls between two events.  FLOPs: 4 B H L^2 D (halved for causal), x 3.5 for forward + backward (the usual 2 + 5 GEMM convention / 2).
+N back-to-back calls between two events (N sized for >= 20 ms per round, at most 400).  FLOPs: 4 B H L^2 D (halved for causal), x 3.5 for forward + backward (the usual 2 + 5 GEMM convention / 2).
 """
 import sys, pathlib
 ROOT = pathlib.Path(__file__).resolve().parent.parent
@@ -56,7 +56,7 @@ for name, B, H, Hkv, L, D, dt, causal in CASES:
     if Hkv != H:
         kw["enable_gqa"] = True
     fl = 4.0 * B * H * L * L * D * (0.5 if causal else 1.0)
-    n = max(3, min(50, int(2e-2 / (fl / 6e14))))
+    n = max(3, min(400, int(2e-2 / (fl / 6e14))))      # (>= 20 ms per round where the call allows: a 16-call round of a 0.1 ms call reads its own ramp)
 
     def fwd_bwd(f):
         o = f(q, k, v, **kw)
@@ -65,7 +65,7 @@ for name, B, H, Hkv, L, D, dt, causal in CASES:
 
     with torch.no_grad():
         tf_o, tf_s = best(lambda: ours(q, k, v, **kw), n), best(lambda: stock(q, k, v, **kw), n)
-    tb_o, tb_s = best(lambda: fwd_bwd(ours), max(3, n // 3)), best(lambda: fwd_bwd(stock), max(3, n // 3))
+    tb_o, tb_s = best(lambda: fwd_bwd(ours), max(3, n // 2)), best(lambda: fwd_bwd(stock), max(3, n // 2))
     rows.append(f"| {name}: [{B}, {H}{'/' + str(Hkv) if Hkv != H else ''}, {L}, {D}] {str(dt).split('.')[-1]} | **{tf_o * 1e3:.0f} us** / {tf_s * 1e3:.0f} us ({tf_s / tf_o:.2f}x) | "
                 f"{fl / tf_o / 1e9:.0f} / {fl / tf_s / 1e9:.0f} | **{tb_o * 1e3:.0f} us** / {tb_s * 1e3:.0f} us ({tb_s / tb_o:.2f}x) | {3.5 * fl / tb_o / 1e9:.0f} / {3.5 * fl / tb_s / 1e9:.0f} |")
     print(rows[-1], flush=True)
