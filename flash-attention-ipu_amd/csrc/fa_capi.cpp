@@ -838,21 +838,26 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
             p.sched_kv = cap_sched(p.sched_kv, p.G8kv);
         }
     }
-    // Split groups inside the workgroups (fa_bwd_kernels.hip QS) for grids of at most one workgroup per CU: such a launch lasts as long as its
-    // heaviest block's chain - [1,8192,64]: 64 workgroups, the longest sweeping 128 tiles with one wave per SIMD, 0.07 of peak -
-    // and the chain shrinks with the groups: 3 at head_dim 64 (144 / 164 registers: three waves per SIMD), 2 at head_dim 128 (two).
+    // Split groups inside the workgroups (fa_bwd_kernels.hip QS / QH) for grids that leave the chip short of waves: such a launch lasts as long as
+    // its heaviest block's chain - [1,8192,64]: 64 workgroups, the longest sweeping 128 tiles with one wave per SIMD, 0.03 of peak - and the chain
+    // shrinks with the groups.  Measured map (profiles/r06_bwd_split/threshold_map_*.txt, in-process A/B over 28 shapes): the split forms win up to
+    // 512 workgroups in the grid in question at L >= 2048 (x1.06 .. 1.58) and up to 384 at L = 1024 (x1.05 .. 1.19), and lose from 640 on (x0.82 ..
+    // 0.93); three groups (head_dim 64 only: 144 / 168 registers = three waves per SIMD) beat two up to 256 workgroups at L >= 2048, two win elsewhere.
+    // At head_dim 128 "two groups" is two kv split groups in dQ and two row-half groups on shared tiles in dK/dV (its sweep fills the register file).
     p.qs_q = p.qs_kv = 1;
     if (mfma && !extra && dtype != FA_DTYPE_F32 && (p.D == 64 || p.D == 128) && options().bsplit != 0) {
         const int qs_max = p.D == 64 ? 3 : 2;
         const int forced = options().bsplit > 0 ? (options().bsplit > qs_max ? qs_max : (int)options().bsplit) : 0;
+        const auto groups_for = [&](int64_t wgs) {
+            if (L < 1024 || wgs > (L >= 2048 ? 512 : 384)) return 1;
+            return (qs_max == 3 && wgs <= 256 && L >= 2048) ? 3 : 2;
+        };
         if (forced == 1) { /* (1 = unsplit) */ }
         else if (forced > 1) p.qs_q = p.qs_kv = forced;
-        else if (L >= 1024) {
-            if ((int64_t)p.G * p.nq_tiles <= 256) p.qs_q = qs_max;
-            if ((int64_t)p.Gkv * p.nk_tiles <= 256) p.qs_kv = qs_max;
+        else {
+            p.qs_q = groups_for((int64_t)p.G * p.nq_tiles);
+            p.qs_kv = groups_for((int64_t)p.Gkv * p.nk_tiles);
         }
-        // (head_dim 128: qs_kv = 2 selects the dK/dV kernel's ROW-HALVES form - two groups on the same streamed tiles, fa_bwd_kernels.hip QH - since its
-        //  single sweep fills the register file and a second group cannot run a sweep of its own)
     }
     if ((int64_t)p.G8 * p.nq_tiles > 0x7fffffffll) return fail(FA_ERR_TOO_LARGE, "grid exceeds 2^31-1 workgroups");
     p.scale = softmax_scale;

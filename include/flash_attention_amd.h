@@ -159,9 +159,10 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  *   "balance" -1 auto | 0 | 1       placement-balanced block order of a causal grid below one round of workgroup slots
  *   "subsets" -1 auto | 0 off       q-tile subsets for group counts that leave XCDs idle (fa_plan_t.xs)
  *   "bsplit"  -1 auto | 0 | 1 off | 2 | 3   split groups inside the backward's workgroups (fa_bwd: kv split groups of a dQ workgroup, query-sweep
- *                                   split groups of a dK/dV workgroup; their partial sums meet in LDS in group order).  Auto: for grids of at most
- *                                   one workgroup per CU at L >= 1024 - 3 groups at head_dim 64 (both kernels), 2 at head_dim 128 (dQ: kv split
- *                                   groups; dK/dV: two groups that take the two 32-row halves of every streamed query tile)
+ *                                   split groups of a dK/dV workgroup; their partial sums meet in LDS in group order).  Auto, per grid: at most 512
+ *                                   workgroups at L >= 2048 or 384 at L >= 1024 - 3 groups at head_dim 64 up to 256 workgroups (L >= 2048), else 2;
+ *                                   at head_dim 128 "2" = two kv split groups in dQ, two groups that take the two 32-row halves of every streamed
+ *                                   query tile in dK/dV
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
 int fa_debug_set_option(const char* name, int32_t value);
 int fa_debug_get_option(const char* name, int32_t* value);
