@@ -169,6 +169,9 @@ def test_backward_block_subsets_vs_autograd_fp64_and_whole_group_map(B, H, Hkv, 
     (1, 6, 2, 1100, 128, torch.float16, 2, True),       # the same with grouped-query heads and a ragged length
     (2, 1, 1, 4096, 64, torch.bfloat16, -1, True),      # whatever the library picks by itself
     (1, 2, 2, 1024, 64, torch.bfloat16, 3, False),      # no causal mask: every block sweeps everything
+    (1, 12, 12, 4096, 64, torch.bfloat16, -1, True),    # the rule's upper range: 384 workgroups per grid at L >= 2048 -> two groups
+    (1, 40, 40, 1024, 64, torch.float16, -1, True),     # 320 workgroups at L = 1024 -> two groups
+    (1, 12, 4, 4096, 128, torch.bfloat16, -1, True),    # head_dim 128, grouped-query: dQ grid 384 (two kv split groups), dK/dV grid 128 (row-half groups)
 ])
 def test_backward_split_groups_vs_autograd_fp64_and_bit_reproducible(B, H, Hkv, L, D, dtype, bsplit, causal):
     """Round-5 verdict, item 4: grids of at most one workgroup per CU run the dQ and dK/dV workgroups as 2 | 3 split groups whose partial sums meet
