@@ -95,7 +95,7 @@ __device__ __forceinline__ bool bwd_block_map(int G8, int G, int sched, int nblk
 // the SAME query rows; group s streams the kv tiles s, s + QS, ... through buffers of its own, in lock step with the others (one workgroup
 // barrier per round), and the groups' dQ partial sums meet in LDS after the loop, added in group order (deterministic).  A launch of at most
 // one workgroup per CU lasts as long as its heaviest row block's kv chain; the chain shrinks QS-fold.
-template <typename T, int D, int NWAVES, int EXTRA = 0, int QS = 1>
+template <typename T, int D, int NWAVES, int EXTRA = 0, int QS = 1, int BAL = 0>
 __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     using E = Elt<T>;
     using vec8 = typename E::vec8;
@@ -112,7 +112,27 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[QS * GROUP_B];
 
     int g, qi;
-    if (!bwd_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, p.xs_q, p.nq_real, g, qi)) return;
+    // BAL (balanced units, for causal grids of at most one workgroup per CU - where the launch lasts as long as its heaviest row block, twice the
+    // mean): the grid runs over UNITS instead of row blocks.  The heavy half of a group's row blocks (the upper half: their kv sweeps are the long
+    // ones) are two units each - the first and the second half of the sweep, `half` = 1 | 2 - whose fp32 partial sums meet in a reduce pass
+    // (fa_bwd_dq_reduce_kernel); a light row block stays one unit (`half` = 0) and stores dQ itself.  1.5x the workgroups, the longest half as long.
+    // The partial sums of the heavy rows need 2 x (L/2 rows x D floats) per group = exactly the bytes of the group's dK and dV, which nobody reads or
+    // writes before the dK/dV kernel (next on the stream) fills them: half 1 parks its sums in dK, half 2 in dV (partial row i = rows 2i, 2i + 1 there).
+    int half = 0;
+    if constexpr (BAL) {
+        int qd;
+        if (!bwd_block_map(p.G8, p.G, p.sched, p.nq_tiles, false, p.xs_q, p.nq_real, g, qd)) return;
+        // units in descending length for the dispatcher (the row-block count is a multiple of 4): level l = nh .. nh/2 + 1 holds the four halves of
+        // row blocks 2l - 1 and 2l - 2 (l and l - 1/2 rounds) and the whole light block l - 1 (l rounds); below that the remaining light blocks
+        const int nq_true = (p.L + BQ - 1) / BQ, nh = nq_true >> 1, nlev = nh >> 1;
+        if (qd < 5 * nlev) {
+            const int lv = nh - qd / 5, sl = qd % 5;
+            if (sl == 4) qi = lv - 1;
+            else { qi = 2 * lv - 1 - (sl >> 1); half = 1 + (sl & 1); }
+        } else qi = nlev - 1 - (qd - 5 * nlev);
+    } else {
+        if (!bwd_block_map(p.G8, p.G, p.sched, p.nq_tiles, true, p.xs_q, p.nq_real, g, qi)) return;
+    }
 
     const int L = p.L;
     const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -172,7 +192,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             for (int j = 0; j < 8; ++j) acc += (float)of[j] * (float)dof[ks][j];
         }
         dsum = half_swap_sum(acc);
-        if (h == 0 && qrow < L && ws == 0) p.dsum[(int64_t)g * L + qrow] = dsum;
+        if (h == 0 && qrow < L && ws == 0 && half != 2) p.dsum[(int64_t)g * L + qrow] = dsum;
     }
     const float ndsum = -dsum;
     const float c = p.scale_log2;
@@ -218,7 +238,9 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 
     const bool causal = p.causal != 0;             // 0: no mask, every key (keys past L are masked)
     const int kv_end = (causal && (qi + 1) * BQ < L) ? (qi + 1) * BQ : L;
-    const int n_tiles = (kv_end + BK - 1) / BK;
+    const int n_tiles_all = (kv_end + BK - 1) / BK;
+    const int t_lo = half == 2 ? n_tiles_all >> 1 : 0;
+    const int n_tiles = half == 0 ? n_tiles_all : half == 1 ? n_tiles_all >> 1 : n_tiles_all - (n_tiles_all >> 1);
     const int wave_last = causal ? q_row0 : L - 1, wave_kv_last = causal ? q_row0 + 31 : L - 1, klim = causal ? qrow : L - 1;
 
     f32x16 dq[DT];
@@ -446,7 +468,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     // (kv split groups: the group's j-th tile is tile ws + QS j; n_local of them; every group keeps the workgroup's n_rounds barriers)
     const int n_rounds = QS == 1 ? n_tiles : (n_tiles + QS - 1) / QS;
     const int n_local = QS == 1 ? n_tiles : (n_tiles - ws + QS - 1) / QS;
-    fa_static_for<0, NB - 1>([&](auto bi_) { constexpr int b_ = decltype(bi_)::value; if (b_ < n_local) { FA_MTERM_LOAD(b_) FA_DMA_KV(ws + QS * b_, b_) FA_DMA_MASK(b_, b_) FA_MTERM_STORE(b_) } });
+    fa_static_for<0, NB - 1>([&](auto bi_) { constexpr int b_ = decltype(bi_)::value; if (b_ < n_local) { FA_MTERM_LOAD(b_) FA_DMA_KV(t_lo + ws + QS * b_, b_) FA_DMA_MASK(b_, b_) FA_MTERM_STORE(b_) } });
     FA_TILE_BARRIER()
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));   // row operands landed
@@ -457,8 +479,8 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
             const int t = t0 + k_;
             if (t < n_rounds) {                                  // (workgroup-uniform)
                 const bool more = t + NB - 1 < n_local;
-                if (more) { FA_MTERM_LOAD(t + NB - 1) FA_DMA_KV(ws + QS * (t + NB - 1), (k_ + NB - 1) % NB) FA_DMA_MASK(t + NB - 1, (k_ + NB - 1) % NB) }
-                if (QS == 1 || t < n_local) FA_DQ_TILE(ws + QS * t, k_)
+                if (more) { FA_MTERM_LOAD(t + NB - 1) FA_DMA_KV(t_lo + ws + QS * (t + NB - 1), (k_ + NB - 1) % NB) FA_DMA_MASK(t + NB - 1, (k_ + NB - 1) % NB) }
+                if (QS == 1 || t < n_local) FA_DQ_TILE(t_lo + ws + QS * t, k_)
                 if (more) FA_MTERM_STORE((k_ + NB - 1) % NB)
                 if (more && NB > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NB - 2)) : "memory");
                 else lds_dma_wait_all();
@@ -497,6 +519,26 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
         if (ws != 0) return;
     }
     if (!wave_active || qrow >= L) return;
+    if constexpr (BAL) {
+        if (half != 0) {      // fp32 partial sums for the reduce pass, parked in the group's dK (half 1) / dV (half 2): see above
+            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+            const int hr = qrow - (((L + BQ - 1) / BQ) >> 1) * BQ;        // row among the heavy rows
+            T* const base = half == 1 ? (T*)p.dk + (int64_t)bb * p.dk_sb + (int64_t)hh * p.dk_sh : (T*)p.dv + (int64_t)bb * p.dv_sb + (int64_t)hh * p.dv_sh;
+            const int64_t sl = half == 1 ? p.dk_sl : p.dv_sl;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                float* const wp = (float*)(base + (int64_t)(2 * hr + (dt >= DT / 2 ? 1 : 0)) * sl) + 32 * (dt % (DT / 2));
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4_ w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = dq[dt][4 * rg + j] * p.scale;
+                    *(f32x4_*)(wp + 8 * rg + 4 * h) = w;
+                }
+            }
+            return;
+        }
+    }
     T* __restrict__ og = (T*)p.dq + (int64_t)bb * p.dq_sb + (int64_t)hh * p.dq_sh + (int64_t)qrow * p.dq_sl;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -511,9 +553,29 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
 }
 
 #ifndef FA_BWD_BODY_ONLY
-template <typename T, int D, int NWAVES, int QS = 1>
+template <typename T, int D, int NWAVES, int QS = 1, int BAL = 0>
 __global__ __launch_bounds__(NWAVES * QS * 64) void fa_bwd_dq_kernel(const BwdParams p) {
-    fa_bwd_dq_body<T, D, NWAVES, 0, QS>(p);
+    fa_bwd_dq_body<T, D, NWAVES, 0, QS, BAL>(p);
+}
+// BAL: dQ rows of the heavy row blocks = the sum of the two fp32 partial sums parked in dK and dV (fa_bwd_dq_body), one thread per 4 columns
+template <typename T, int D>
+__global__ __launch_bounds__(256) void fa_bwd_dq_reduce_kernel(const BwdParams p, int row0, int Gt) {
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = (int)(i % (D / 4));
+    const int64_t rr = i / (D / 4);
+    const int rows = p.L - row0;
+    const int g = (int)(rr / rows), hr = (int)(rr % rows);
+    if (g >= Gt) return;
+    const int bb = g / p.H, hh = g - bb * p.H;
+    const int up = c4 >= D / 8 ? 1 : 0, cc = 4 * (c4 - up * (D / 8));      // which of the two parked rows, float column in it
+    const f32x4_ a = *(const f32x4_*)((const float*)((const T*)p.dk + (int64_t)bb * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)(2 * hr + up) * p.dk_sl) + cc);
+    const f32x4_ b = *(const f32x4_*)((const float*)((const T*)p.dv + (int64_t)bb * p.dv_sb + (int64_t)hh * p.dv_sh + (int64_t)(2 * hr + up) * p.dv_sl) + cc);
+    vec4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (T)(a[j] + b[j]);
+    *(vec4*)((T*)p.dq + (int64_t)bb * p.dq_sb + (int64_t)hh * p.dq_sh + (int64_t)(row0 + hr) * p.dq_sl + 4 * c4) = w;
 }
 #endif
 
@@ -1093,7 +1155,33 @@ __global__ __launch_bounds__(NWAVES * QS * QH * 64, D == 128 ? 2 : QS == 3 ? 3 :
 template <typename T, int D>
 static hipError_t launch_bwd_t(const BwdParams& p, hipStream_t stream) {
     const dim3 qgrid((unsigned)((int64_t)p.G8 * p.nq_tiles)), kgrid((unsigned)((int64_t)p.G8kv * p.nk_tiles));
-    hipError_t e;
+ hipError_t e;
+    if constexpr (D == 64 || D == 128) {
+        if (p.bal) {   // balanced dQ units (fa_bwd_dq_body BAL), the reduce pass, then dK/dV as always
+            if constexpr (D == 64)
+                e = p.qs_q == 3   ? launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 3, 1>), qgrid, dim3(768), 0, stream, p)
+                    : p.qs_q == 2 ? launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 2, 1>), qgrid, dim3(512), 0, stream, p)
+                                  : launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 1, 1>), qgrid, dim3(256), 0, stream, p);
+            else
+                e = p.qs_q == 2 ? launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 2, 1>), qgrid, dim3(512), 0, stream, p)
+                                : launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 1, 1>), qgrid, dim3(256), 0, stream, p);
+            if (e != hipSuccess) return e;
+            const int nq_true = (p.L + 127) / 128, row0 = (nq_true / 2) * 128, Gt = p.G / p.xs_q;
+            const int64_t n = (int64_t)Gt * (p.L - row0) * (D / 4);
+            if (n > 0) {
+                void* args[] = {(void*)&p, (void*)&row0, (void*)&Gt};
+                e = hipLaunchKernel((const void*)(fa_bwd_dq_reduce_kernel<T, D>), dim3((unsigned)((n + 255) / 256)), dim3(256), args, 0, stream);
+                if (e != hipSuccess) return e;
+            }
+            if constexpr (D == 64)
+                return p.qs_kv == 3   ? launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4, 3>), kgrid, dim3(768), 0, stream, p)
+                       : p.qs_kv == 2 ? launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4, 2>), kgrid, dim3(512), 0, stream, p)
+                                      : launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), kgrid, dim3(256), 0, stream, p);
+            else
+                return p.qs_kv == 2 ? launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4, 1, 2>), kgrid, dim3(512), 0, stream, p)
+                                    : launch1((const void*)(fa_bwd_dkdv_kernel<T, D, 4>), kgrid, dim3(256), 0, stream, p);
+        }
+    }
     if constexpr (D == 64) {
         e = p.qs_q == 3   ? launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 3>), qgrid, dim3(768), 0, stream, p)
             : p.qs_q == 2 ? launch1((const void*)(fa_bwd_dq_kernel<T, D, 4, 2>), qgrid, dim3(512), 0, stream, p)

@@ -48,6 +48,7 @@ struct Options {
     std::atomic<int> pair{-1};      // -1 auto, 0 | 1 q-tile pairs per workgroup (fa_fwd_dma.hip, causal)
     std::atomic<int> balance{-1};   // -1 auto, 0 | 1 placement-balanced block order for grids below one round of slots
     std::atomic<int> subsets{-1};   // -1 auto, 0 off: q-tile subsets for group counts that leave XCDs idle (FwdParams::xs)
+    std::atomic<int> bbal{-1};      // -1 auto, 0 off, 1 forced where the form exists: balanced dQ units (BwdParams::bal)
     std::atomic<int> bsplit{-1};    // -1 auto, 0 off, 2 | 3: split groups inside the backward's workgroups (BwdParams::qs_q / qs_kv), forced where a kernel has that form
 };
 Options g_opt;
@@ -77,6 +78,7 @@ const Options& options() {
         if (const char* e = getenv("FA_AMD_BALANCE")) { if (*e) g_opt.balance = atoi(e); }
         if (const char* e = getenv("FA_AMD_SUBSETS")) { if (*e) g_opt.subsets = atoi(e); }
         if (const char* e = getenv("FA_AMD_BSPLIT")) { if (*e) g_opt.bsplit = atoi(e); }
+        if (const char* e = getenv("FA_AMD_BBAL")) { if (*e) g_opt.bbal = atoi(e); }
     });
     return g_opt;
 }
@@ -457,6 +459,7 @@ const OptionName kOptionNames[] = {
     {"f32_generic", &Options::f32_generic, 0, 1}, {"table", &Options::table, 0, 1}, {"split", &Options::split, 0, 4},
     {"pair", &Options::pair, -1, 1}, {"balance", &Options::balance, -1, 1}, {"subsets", &Options::subsets, -1, 0},
     {"bsplit", &Options::bsplit, -1, 3},
+    {"bbal", &Options::bbal, -1, 1},
 };
 
 }  // namespace
@@ -811,6 +814,18 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
         const int64_t ng = p.G8 / 8, ngkv = p.G8kv / 8;
         p.sched = (int32_t)(bunch > ng ? ng : bunch);
         p.sched_kv = (int32_t)(bunch > ngkv ? ngkv : bunch);
+    }
+    // Balanced dQ units (fa_bwd_kernels.hip BAL): a causal dQ grid of at most one workgroup per CU lasts as long as its heaviest row block - twice the
+    // mean.  The heavy half of the row blocks become two units each (halves of the kv sweep; fp32 partial sums parked in the group's dK / dV until the
+    // reduce pass, so: query and K/V heads agree, the operands' own head dim), the units go out in descending length.  Measured
+    // (profiles/r06_bwd_split/balanced_dq_units_rule.txt, whole backward): up to 128 row blocks in the grid x1.06 (16 blocks a group) .. 1.20 (64 and more),
+    // level at 8 a group; at 129 - 256 row blocks x1.07 - 1.08 from 64 blocks a group on and a loss below (32: x0.99, 16: x0.93, 8: x0.82); a loss beyond.
+    p.bal = 0;
+    if (mfma && !extra && dtype != FA_DTYPE_F32 && causal && (p.D == 64 || p.D == 128) && p.Dr == p.D && p.kv_div == 1 && options().bbal != 0 &&
+        p.nq_tiles >= 8 && p.nq_tiles % 4 == 0 &&
+        (options().bbal > 0 || (p.nq_tiles >= 16 && (G * p.nq_tiles <= 128 || (G * p.nq_tiles <= 256 && p.nq_tiles >= 64))))) {
+        p.bal = 1;
+        p.nq_tiles = p.nq_tiles + p.nq_tiles / 2;      // units per group
     }
     // block subsets for group counts that leave XCDs idle (as the forward, subsets_for): MFMA kernels only
     p.xs_q = p.xs_kv = 1;

@@ -83,6 +83,9 @@ struct BwdParams {
     // of a dK/dV workgroup - for grids of at most one workgroup per CU, where the launch lasts as long as its heaviest block's chain.  (Read by
     // the host-side launcher only; last, so that no field the kernels read moved.)
     int32_t qs_q, qs_kv;
+    // balanced dQ units (fa_bwd_kernels.hip BAL): with bal = 1 the dQ grid runs over units - nq_real / nq_tiles count UNITS (1.5 per row block);
+    // the heavy row blocks' fp32 partial sums are parked in dk / dv until fa_bwd_dq_reduce_kernel has added them.  (Host-side launcher only.)
+    int32_t bal;
 };
 // One launch, reporting ITS OWN status: hipLaunchKernel returns this launch's result, whereas hipGetLastError()
 // after a <<<>>> launch also returns (and clears) a stale error left on the thread by an unrelated earlier HIP

@@ -130,7 +130,7 @@ def plan(G, L, D, dtype, num_chunks_q, num_chunks_kv, softmax_scale: float = 1.0
 
 _KERNEL_CODE = {"auto": 0, "": 0, None: 0, "dma": ord("d"), "pipe": ord("p"), "pipe16": ord("x"), "kh": ord("h")}
 _OPTION_AUTO = {"kernel": 0, "qb": 0, "waves": 0, "sched": 0, "skipmax": -1, "f32_generic": 0, "table": 1, "split": 0, "pair": -1,
-                "balance": -1, "subsets": -1, "bsplit": -1}
+                "balance": -1, "subsets": -1, "bsplit": -1, "bbal": -1}
 
 
 def set_debug_option(name: str, value) -> None:

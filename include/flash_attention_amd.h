@@ -163,6 +163,10 @@ int fa_plan(int64_t G, int64_t L, int64_t D, int32_t dtype, int32_t num_chunks_q
  *                                   workgroups at L >= 2048 or 384 at L >= 1024 - 3 groups at head_dim 64 up to 256 workgroups (L >= 2048), else 2;
  *                                   at head_dim 128 "2" = two kv split groups in dQ, two groups that take the two 32-row halves of every streamed
  *                                   query tile in dK/dV
+ *   "bbal"    -1 auto | 0 off | 1   balanced dQ units (fa_bwd, causal, heads == heads_kv, D 64 | 128, row-block count a multiple of 4): the heavy
+ *                                   half of a group's 128-row blocks run as two workgroups each (halves of the kv sweep) whose fp32 partial sums
+ *                                   are parked in dk / dv until a reduce pass adds them.  Auto: at most 128 row blocks in the grid with >= 16 per
+ *                                   group, or at most 256 with >= 64 per group
  * Returns FA_OK or FA_ERR_BAD_OPTION.  (No reference counterpart.) */
 int fa_debug_set_option(const char* name, int32_t value);
 int fa_debug_get_option(const char* name, int32_t* value);
@@ -210,7 +214,9 @@ int fa_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
  * f16/bf16/fp32 with D in {64, 128}, f16/bf16 with D any other multiple of 8 up to 256 (zero-extended at 64 / 128 / 192 / 256 inside
  * the kernels) and 16-byte aligned rows run the MFMA kernels; every other case (other D <= 1024, unaligned rows) runs generic
  * fp32-arithmetic kernels.
- * Deterministic: no gradient is accumulated across workgroups.
+ * Deterministic: no gradient is accumulated across workgroups with atomics; results are bit-reproducible from call to call.
+ * dq, dk and dv are pure outputs that the call may ALSO use as scratch before it writes their final values (an under-filled causal dQ grid
+ * parks fp32 partial sums of dQ in dk / dv until a reduce pass has added them - "bbal" below): they must not overlap each other or any input.
  */
 int fa_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
            void* dq, void* dk, void* dv, float* dsum_workspace,

@@ -209,3 +209,49 @@ def test_backward_split_groups_vs_autograd_fp64_and_bit_reproducible(B, H, Hkv, 
         lim = 6e-2 * max(1.0, want.abs().max().item())
         assert (got.double() - want).abs().max().item() <= lim, name
         assert (got.float() - unsplit.float()).abs().max().item() <= 0.5 * lim, f"{name}: split and unsplit kernels disagree beyond rounding"
+
+
+@pytest.mark.parametrize("B,H,L,D,dtype,bsplit,head_inner", [
+    (1, 2, 2048, 64, torch.bfloat16, -1, False),     # 32 row blocks -> 48 units; the library's own split groups on top
+    (1, 1, 4096, 64, torch.float16, 3, False),       # one group: subsets spread its units over the XCDs
+    (2, 2, 1024, 64, torch.bfloat16, 1, True),       # the smallest count the form takes (8 row blocks), unsplit workgroups, head-inner operands
+    (1, 2, 1900, 64, torch.bfloat16, 2, False),      # ragged L (15 row blocks: not a multiple of 4 -> the form is refused, the plain grid runs)
+    (1, 2, 1980, 64, torch.float16, 2, False),       # ragged L inside the last of 16 row blocks
+    (1, 4, 2048, 128, torch.bfloat16, -1, True),     # head_dim 128
+    (1, 2, 4096, 128, torch.float16, 2, False),
+])
+def test_backward_balanced_dq_units_vs_autograd_fp64_and_bit_reproducible(B, H, L, D, dtype, bsplit, head_inner):
+    """Balanced dQ units (fa_bwd_kernels.hip BAL; debug option bbal): the heavy half of a causal grid's row blocks run as two units whose fp32 partial
+    sums are parked in the dK / dV buffers until a reduce pass adds them - so: dQ against autograd through the dense fp64 expression and bit-reproducible,
+    and dK / dV (written AFTER their buffers served as scratch) bit-equal to the run without the form."""
+    native = _mods()
+    torch.manual_seed(B * 131 + H * 17 + L + D)
+    def mk():
+        if head_inner:
+            return (torch.randn(B, L, H, D, device="cuda") * 0.7).to(dtype).transpose(1, 2)
+        return (torch.randn(B, H, L, D, device="cuda") * 0.7).to(dtype)
+    q, k, v, g = mk(), mk(), mk(), mk()
+    scale = D ** -0.5
+    out = torch.empty_like(q)
+    lse = torch.empty(B * H, L, device="cuda", dtype=torch.float32)
+    st = lambda t: (t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
+    native.fwd_strided(q, k, v, out, lse, B * H, L, D, H, st(q), st(k), st(v), st(out), 1, 1, scale, True)
+
+    def grads(bbal):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        with native.debug_options(bbal=bbal, bsplit=bsplit):
+            native.bwd(q, k, v, out, g, lse, dq, dk, dv, B * H, L, D, H, scale, True)
+        torch.cuda.synchronize()
+        return dq, dk, dv
+
+    a, b, plain = grads(1), grads(1), grads(0)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), "two partial sums per element, added in one order: the same bits on every call"
+    assert torch.equal(a[1], plain[1]) and torch.equal(a[2], plain[2]), "dK / dV must not notice that their buffers were scratch"
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = (qd @ kd.transpose(-1, -2)) * scale
+    s = s.masked_fill(torch.triu(torch.ones(L, L, device="cuda", dtype=torch.bool), 1), float("-inf"))
+    (torch.softmax(s, -1) @ vd).backward(g.double())
+    lim = 6e-2 * max(1.0, qd.grad.abs().max().item())
+    assert (a[0].double() - qd.grad).abs().max().item() <= lim
+    assert (a[0].float() - plain[0].float()).abs().max().item() <= 0.5 * lim

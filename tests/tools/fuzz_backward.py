@@ -17,14 +17,14 @@ from flash_attention_amd._impl.scaled_dot_product_attention import chunk_heurist
 dev = torch.device("cuda")
 
 
-def native_grads(q, k, v, g, scale, causal, bsplit):
+def native_grads(q, k, v, g, scale, causal, bsplit, bbal=0):
     B, H, L, D = q.shape
     out = torch.empty(B, H, L, D, device=dev, dtype=q.dtype)
     lse = torch.empty(B * H, L, device=dev, dtype=torch.float32)
     st = lambda t: (t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
     _native.fwd_strided(q, k, v, out, lse, B * H, L, D, H, st(q), st(k), st(v), st(out), 1, 1, scale, causal, heads_kv=k.shape[1])
     dq, dk, dv = torch.empty_like(out), torch.empty(k.shape, device=dev, dtype=k.dtype), torch.empty(v.shape, device=dev, dtype=v.dtype)
-    with _native.debug_options(bsplit=bsplit):
+    with _native.debug_options(bsplit=bsplit, bbal=bbal):
         _native.bwd(q, k, v, out, g, lse, dq, dk, dv, B * H, L, D, H, scale, causal, heads_kv=k.shape[1])
     torch.cuda.synchronize()
     return out, dq, dk, dv
@@ -35,7 +35,7 @@ def fuzz(cases, seed, log=print):
     bad = n_override = 0
     for case in range(cases):
         D = rng.choice([64, 64, 128])
-        L = rng.choice([rng.randint(1, 300), rng.randint(300, 1500), rng.randint(1024, 4200)])
+        L = rng.choice([rng.randint(1, 300), rng.randint(300, 1500), rng.randint(1024, 4200), 512 * rng.randint(2, 8) - rng.choice([0, 0, 1, 77])])
         B = rng.randint(1, 2)
         Hkv = rng.randint(1, 3)
         H = Hkv * rng.choice([1, 1, 2, 4])
@@ -43,16 +43,17 @@ def fuzz(cases, seed, log=print):
         causal = rng.random() < 0.8
         head_inner = rng.random() < 0.4
         bsplit = rng.choice([2, 3, -1])
+        bbal = rng.choice([1, -1])        # balanced dQ units: forced where the form exists / the library's rule
         gen = torch.Generator(device=dev).manual_seed(seed * 100003 + case)
         mk = lambda h: (torch.randn(B, L, h, D, device=dev, generator=gen).transpose(1, 2) if head_inner else torch.randn(B, h, L, D, device=dev, generator=gen))  # noqa: E731
         q, k, v = (mk(H) * 0.7).to(dtype), (mk(Hkv) * 0.7).to(dtype), (mk(Hkv) * 0.7).to(dtype)
         g = torch.randn(B, H, L, D, device=dev, generator=gen).to(dtype)
         scale = D ** -0.5
-        what = f"case {case}: [{B},{H}/{Hkv},{L},{D}] {str(dtype).split('.')[-1]} causal={causal} head_inner={head_inner} bsplit={bsplit}"
+        what = f"case {case}: [{B},{H}/{Hkv},{L},{D}] {str(dtype).split('.')[-1]} causal={causal} head_inner={head_inner} bsplit={bsplit} bbal={bbal}"
         try:
             o1, *plain = native_grads(q, k, v, g, scale, causal, 1)
-            _, *a = native_grads(q, k, v, g, scale, causal, bsplit)
-            _, *b = native_grads(q, k, v, g, scale, causal, bsplit)
+            _, *a = native_grads(q, k, v, g, scale, causal, bsplit, bbal)
+            _, *b = native_grads(q, k, v, g, scale, causal, bsplit, bbal)
             ok = all(torch.equal(x, y) for x, y in zip(a, b))
             lims = [6e-2 * max(1.0, x.float().abs().max().item()) for x in plain]
             ok &= all((x.float() - y.float()).abs().max().item() <= 0.5 * lim for x, y, lim in zip(a, plain, lims))
