@@ -822,7 +822,7 @@ int bwd_impl(const void* q, const void* k, const void* v, const void* out, const
     // level at 8 a group; at 129 - 256 row blocks x1.07 - 1.08 from 64 blocks a group on and a loss below (32: x0.99, 16: x0.93, 8: x0.82); a loss beyond.
     p.bal = 0;
     if (mfma && !extra && dtype != FA_DTYPE_F32 && causal && (p.D == 64 || p.D == 128) && p.Dr == p.D && p.kv_div == 1 && options().bbal != 0 &&
-        p.nq_tiles >= 8 && p.nq_tiles % 4 == 0 &&
+        p.nq_tiles >= 8 && p.nq_tiles % 4 == 0 && p.dk_sl >= p.D && p.dv_sl >= p.D && dk != dv &&   // (rows of dk / dv that can hold the parked sums)
         (options().bbal > 0 || (p.nq_tiles >= 16 && (G * p.nq_tiles <= 128 || (G * p.nq_tiles <= 256 && p.nq_tiles >= 64))))) {
         p.bal = 1;
         p.nq_tiles = p.nq_tiles + p.nq_tiles / 2;      // units per group
