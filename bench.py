@@ -22,7 +22,8 @@ line and the exit code.
 `kernel_only_value` repeats it as a whole-job figure; `scaling_efficiency` = value / (N x the one-GPU kernel-only rate of the launch shape,
 measured in the same run on every rank): 1.0 = the exchange is free.
 
-N = 1 also reports, in `secondary`, a small-grid shape (split-KV plan), the backward at cfg2, and the other single-GPU configs of BASELINE.json (cfg3 long context, the cfg5
+N = 1 also reports, in `secondary`, a small-grid shape (split-KV plan), the backward at cfg2 and on two grids that cannot fill the chip
+(`bwd_small_grids`: the library's split groups + balanced dQ units against the plain grid), and the other single-GPU configs of BASELINE.json (cfg3 long context, the cfg5
 per-GPU shard shape, `cfg5_full` = ALL 2048 groups of configs[4] on this one GPU - the anchor of its 1/2/4/8 strong-scaling curve - and cfg4: a
 GPT-2-small forward step through the automatic SDPA override with the attention share) - the headline stays cfg2.
 
@@ -350,6 +351,31 @@ def secondary_attention(name, dev, steps=20, warmup=5, backward=False):
         rec["flops"] = "5GL^2D"
     elif plan is not None:
         rec["tile"] = f"{plan.block_q}x{plan.block_kv}/{plan.waves}w" + (f"/split{32 * plan.waves * plan.qb // plan.block_q}" if 32 * plan.waves * plan.qb > plan.block_q else "") + (f"/xs{plan.xs}" if plan.xs > 1 else "")
+    return rec
+
+
+def secondary_backward_small_grids(dev, steps=10, warmup=3):
+    """fa_bwd on two causal grids that cannot fill the chip (batch-1 long-context shapes: the round-5 verdict's item 4): the library's own choice -
+    split groups inside the workgroups, balanced dQ units - against the plain grid of unsplit kernels in the same process.
+    value = TFLOP/s on 5 G L^2 D."""
+    import torch
+    from flash_attention_amd._impl import _native
+    from flash_attention_amd._impl.flash_attention_qkv_packed import flash_attention_qkv_packed_with_lse
+
+    rec = {}
+    for G, L, D in ((1, 8192, 64), (4, 8192, 128)):
+        gen = torch.Generator(device=dev).manual_seed(7)
+        qkv = (torch.randn(3, G, L, D, device=dev, generator=gen) * 0.5).to(torch.bfloat16)
+        dout = torch.randn(G, L, D, device=dev, generator=gen).to(torch.bfloat16)
+        out, lse = flash_attention_qkv_packed_with_lse(qkv, 1, 1)
+        dqkv = torch.empty_like(qkv)
+        fn = lambda: _native.bwd(qkv[0], qkv[1], qkv[2], out, dout, lse, dqkv[0], dqkv[1], dqkv[2], G, L, D, 1, 1.0, True)  # noqa: E731
+        ms = sorted([time_kernel(fn, steps, warmup, ramp_ms=60.0)] + [time_kernel(fn, steps, 0) for _ in range(2)])[1]
+        with _native.debug_options(bsplit=1, bbal=0):
+            plain = sorted(time_kernel(fn, steps, warmup if i == 0 else 0) for i in range(3))[1]
+        tf = 5.0 * G * L * L * D / (ms * 1e-3) / 1e12
+        rec[f"[{G},{L},{D}]"] = {"value": round(tf, 1), "frac": round(tf / PEAK_TFLOPS, 4), "ms": round(ms, 4), "plain_grid_ms": round(plain, 4),
+                                 "speedup": round(plain / ms, 3)}
     return rec
 
 
@@ -1031,12 +1057,17 @@ def main():
             except Exception as e:  # noqa: BLE001
                 sec["cfg2_bwd"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             try:
+                sec["bwd_small_grids"] = secondary_backward_small_grids(dev)
+            except Exception as e:  # noqa: BLE001
+                sec["bwd_small_grids"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            try:
                 sec["cfg4_gpt2_fwd"] = secondary_gpt2_forward(dev)
             except Exception as e:  # noqa: BLE001
                 sec["cfg4_gpt2_fwd"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             line["secondary"] = sec
             line["roofline"]["other_configs"] = {
                 k: ({"tflops": v["value"], "frac": v["frac"], "kernel": v["kernel"], "ms": v["ms"]} if "frac" in v else
+                    {s_: [r_["ms"], r_["plain_grid_ms"]] for s_, r_ in v.items()} if k == "bwd_small_grids" and "error" not in v else
                     {"step_ms": v.get("value"), "stock_ms": v.get("stock_sdpa_ms"), "graph_ms": v.get("hip_graph_ms"), "attn_frac": v.get("attn_frac")} if "error" not in v else v)
                 for k, v in sec.items()}
         if not args.no_cpu_baseline and not dist_on:

@@ -35,7 +35,12 @@ def test_default_bench_line_fits_the_drivers_tail_and_carries_every_baseline_con
     for name in ("cfg3", "cfg5_shard", "cfg2_f16", "cfg4_attn", "cfg2_sdpa", "cfg2_bwd", "cfg4_gpt2_fwd", "small_grid", "l1024", "nb_65536", "few_groups"):
         assert name in others and "error" not in others[name], (name, others.get(name))
         assert name in rec["secondary"]
-    assert list(rec["secondary"])[-5:-2] == ["cfg5_shard", "cfg5_full", "cfg3"], "the BASELINE configs come last among the forward records"
+    assert list(rec["secondary"])[-6:-3] == ["cfg5_shard", "cfg5_full", "cfg3"], "the BASELINE configs come last among the forward records"
+    # round 6: the backward on grids that cannot fill the chip - split groups + balanced dQ units against the plain grid, in one process
+    small = rec["secondary"]["bwd_small_grids"]
+    assert "error" not in small, small
+    for shape in ("[1,8192,64]", "[4,8192,128]"):
+        assert small[shape]["speedup"] > 1.15 and small[shape]["value"] > 0 and others["bwd_small_grids"][shape] == [small[shape]["ms"], small[shape]["plain_grid_ms"]]
     # round-5 verdict, item 1: the one-GPU anchor of BASELINE configs[4]'s strong-scaling curve - all 2 048 groups on this GPU, the slab launches of the N > 1 flow
     full = rec["secondary"]["cfg5_full"]
     assert "error" not in full, full
