@@ -607,8 +607,14 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     // Q0 .. Q(NB-1), dO0 .. dO(NB-1) images, then per-buffer row constants: lse2[64], dsum[64]
     // (EXTRA == 2 | 3: plus per buffer the item's mask tile, 64 rows x the workgroup's 128 keys: 8 KB of boolean bytes or 16 KB of bias)
     constexpr int MIMG_B = EXTRA == 3 ? 16384 : 8192, MOFF = 2 * NB * IMG_B + NB * 512;
-    constexpr bool MDMA = !(D == 256 && EXTRA == 3);   // (head_dim 256: the Q / dO images fill 128 KB - two 16 KB bias images do not fit beside them: that bias is loaded in place)
-    constexpr int GROUP_B = MOFF + ((EXTRA >= 2 && MDMA) ? NB * MIMG_B : 0);
+    // (head_dim 256 with a bias: the Q / dO images fill 128 KB - two 16 KB bias images do not fit beside them.  There every wave keeps the bias of ITS 32
+    //  keys only, in half-item pieces - 32 rows x 32 keys x 2 B = 2 KB - that travel through a wave-private ring of three: half k of the (item, row half)
+    //  sequence lives in slot k % 3, the first half of item j + 1 is requested at the top of round j (the slot the second half of item j - 1 has left), its
+    //  second half as soon as the wave has read the first half of item j (whose slot it takes): 24 KB in all, no barrier of its own - a wave is the only
+    //  writer and the only reader of its ring - and every piece has 85 % of an item's time or more to land before the round's closing wait.)
+    constexpr bool MPRIV = D == 256 && EXTRA == 3;
+    constexpr int MHALF_B = 2048, MRING_B = 3 * MHALF_B;
+    constexpr int GROUP_B = MOFF + (EXTRA >= 2 ? (MPRIV ? NWAVES * MRING_B : NB * MIMG_B) : 0);
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[QS * GROUP_B];
 
     // Grouped-query attention: the workgroup owns 128 keys of ONE K/V head and sweeps the query tiles of all kv_div query
@@ -764,13 +770,23 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
     // read hold rows i and i + 4, which a plain row-major image would put on the same banks.  Needs mask_vec (pointer and strides multiples
     // of four elements); any other mask is loaded in place, element by element.
     constexpr bool mbias = EXTRA == 3;
-    const bool mdma = EXTRA >= 2 && MDMA && p.ex.mask != nullptr && (p.ex.mask_vec & 2) != 0;
+    const bool mdma = EXTRA >= 2 && p.ex.mask != nullptr && (p.ex.mask_vec & 2) != 0;
     const unsigned m_slb = (unsigned)p.ex.m_sl * (unsigned)mask_esz;
     int m_row[EXTRA >= 2 ? 4 : 1];
     unsigned m_col[EXTRA >= 2 ? 4 : 1];
     int m_rd = 0;
     (void)mbias; (void)mdma; (void)m_slb; (void)m_row; (void)m_col; (void)m_rd;
-    if constexpr (EXTRA >= 2) {
+    if constexpr (MPRIV) {
+        // a piece = 16 rows x the wave's 32 keys (64 B a row), lane-linear in LDS: 64-byte slot lane >> 2 holds row b0 + 2 b1 + 4 b2 + 8 b3 of the
+        // piece at slot b2 + 2 b0 + 4 b1 + 8 b3 - the two half-waves of one read hold rows i and i + 4 (b2), which land on neighbouring slots, i.e. on
+        // different banks, and every register's row is the lane's own address plus a constant
+        const int sl_ = lane >> 2;
+        m_row[0] = ((sl_ >> 1) & 1) + 2 * ((sl_ >> 2) & 1) + 4 * (sl_ & 1) + 8 * (sl_ >> 3);
+        m_col[0] = (unsigned)(lane & 3) << 4;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) { m_row[j] = 0; m_col[j] = 0; }
+        m_rd = wave * MRING_B + h * 64 + r * 2;
+    } else if constexpr (EXTRA >= 2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pc = wave + 4 * j;
@@ -782,8 +798,30 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
         m_rd = mbias ? 4 * h * 256 + (((4 * wave + (r >> 3)) ^ (8 * h)) << 4) + (r & 7) * 2
                      : 4 * h * 128 + (((2 * wave + (r >> 4)) ^ (4 * h)) << 4) + (r & 15);
     }
+    // MPRIV: half K_ = 2 item + row half of the wave's bias sequence -> ring slot K_ % 3 (two 1 KiB pieces; the wave's own reads of the slot's
+    // previous tenant are drained first)
+#define FA_DMA_MHALF(K_)                                                                           \
+    if constexpr (MPRIV) {                                                                         \
+        if (mdma && wave_active) {                                                                 \
+            const int km_ = (K_), jm_ = km_ >> 1;                                                  \
+            FA_ITEM(jm_, hqm_, itm_)                                                               \
+            const int q0m_ = itm_ * BQ, rl_ = L - 1 - q0m_;                                        \
+            const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqm_) * p.ex.m_sh + (int64_t)q0m_ * p.ex.m_sl + kb * BKW + wave * 32) * mask_esz; \
+            const int64_t left_ = ((int64_t)rl_ * p.ex.m_sl + (L - kb * BKW - wave * 32)) * mask_esz;   /* to the end of the slice's last row (> 0: the wave is active) */ \
+            i32x4 mr_ = make_raw_rsrc(mb_, left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu);   \
+            _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   \
+            const unsigned dst_ = smem_lds + MOFF + wave * MRING_B + (km_ % 3) * MHALF_B;          \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {   /* (rows past L: the last row again - their P is 0) */ \
+                const int row_ = 32 * (km_ & 1) + 16 * i_ + m_row[0];                              \
+                lds_dma_b128(mr_, dst_ + i_ * 1024, (unsigned)(row_ < rl_ ? row_ : rl_) * m_slb + m_col[0]); \
+            }                                                                                      \
+        }                                                                                          \
+    }
 #define FA_DMA_MASK(J_, BUF_)                                                                      \
-    if constexpr (EXTRA >= 2) {                                                                    \
+    if constexpr (MPRIV) {   /* the first half of the item; its second half follows the wave's reads of the slot's tenant (FA_DKDV_TILE) */ \
+        FA_DMA_MHALF(2 * (J_))                                                                     \
+    } else if constexpr (EXTRA >= 2) {                                                             \
         if (mdma) {                                                                                \
             FA_ITEM(J_, hqm_, itm_)                                                                \
             const int q0m_ = itm_ * BQ, rl_ = L - 1 - q0m_;                                        \
@@ -824,6 +862,8 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 kskip = __builtin_amdgcn_ballot_w64(kterm != -INFINITY) == 0;                      \
             }                                                                                      \
         }                                                                                          \
+        bool mh_sent_ = false;   /* (MPRIV) the next item's second bias half is on its way */       \
+        (void)mh_sent_;                                                                            \
         if (wave_active && !(EXTRA == 1 && kskip) && (!causal || q0 + BQ - 1 >= key0)) {           \
             const unsigned char* qb_ = smem + (BUF_) * IMG_B;                                      \
             const unsigned char* gb_ = smem_g + (BUF_) * IMG_B;                                    \
@@ -844,7 +884,15 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                 if constexpr (EXTRA) {                                                             \
                     if (p.ex.mask != nullptr) {   /* mask[row][this lane's key], one row per register */ \
                         if constexpr (EXTRA >= 2) {                                                \
-                            if (mdma) {   /* this lane's column of the tile image */               \
+                            if (MPRIV && mdma) {   /* this lane's column of the wave's half (ring slot (2 item + hb) % 3) */ \
+                                const unsigned char* mi_ = smem + MOFF + m_rd + ((2 * (J_) + hb) % 3) * MHALF_B; \
+                                _Pragma("unroll") for (int e = 0; e < 16; ++e)                     \
+                                    s0[e] += bias_term((float)*(const T*)(mi_ + (e >> 3) * 1024 + ((e >> 2) & 1) * 512 + (e & 3) * 128), p.ex.inv_scale); \
+                                if (hb == 0 && more) {   /* the slot is read: the next item's second half takes it */ \
+                                    FA_DMA_MHALF(2 * (J_) + 3)                                     \
+                                    mh_sent_ = true;                                               \
+                                }                                                                  \
+                            } else if (mdma) {   /* this lane's column of the tile image */        \
                                 const unsigned char* mi_ = smem + MOFF + (BUF_) * MIMG_B + m_rd;   \
                                 if (mbias) {                                                       \
                                     _Pragma("unroll") for (int e = 0; e < 16; ++e)                 \
@@ -921,6 +969,9 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
                     }                                                                              \
                 }                                                                                  \
             }                                                                                      \
+        }                                                                                          \
+        if constexpr (MPRIV) {   /* (a wave that skipped the first half of this item - or all of it - sends the next item's second half here) */ \
+            if (more && !mh_sent_) { FA_DMA_MHALF(2 * (J_) + 3) }                                  \
         }                                                                                          \
     }
 #else
@@ -1021,6 +1072,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             FA_ROWC_LOAD(ws + QS * b_)
             FA_DMA_QG(ws + QS * b_, b_)
             FA_DMA_MASK(ws + QS * b_, b_)
+            FA_DMA_MHALF(2 * (ws + QS * b_) + 1)
             FA_ROWC_STORE(b_)
         }
     });
@@ -1062,6 +1114,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
 #undef RC_IDX
 #undef FA_DKDV_TILE
 #undef FA_DMA_MASK
+#undef FA_DMA_MHALF
 
     // query-sweep split groups: fold the other groups' dK^T and dV^T partial sums into group 0 through LDS - one group and one of the two
     // gradients at a time, in that order (every buffer is free after the loop's last barrier; a lane's values at [value][lane])

@@ -117,9 +117,6 @@ def _masked_or_dropped(query, key, value, attn_mask, dropout_p, is_causal, scale
             return None
         if m.stride(-1) != 1:      # (a mask broadcast along the keys: materialise that row once)
             m = m.contiguous()
-        if needs_grad and D > 192 and m.dtype != torch.bool and m.stride(-2) != 0:
-            return None            # (a bias that differs from row to row at head_dim 256: its tile images do not fit beside the backward's 128 KB of
-            #                          Q / dO images, the in-place loads make fa_bwd_ex slower than stock SDPA there - measured 11.6 vs 8.7 ms at [8,16,2048,256])
         mask = m      # (boolean masks go down as they are: one byte per element; no dtype view - inductor cannot lower bool.view(uint8))
     softmax_scale = D ** -0.5 if scale is None else scale
     seed, offset, state = 0, 0, None
@@ -212,7 +209,7 @@ def _scaled_dot_product_attention_amd(
         if out is not None:
             return _unpad(out, D_true)
         on_device = False       # (a combination the mask / dropout kernels do not take: stock SDPA serves it)
-        _handoff("attn_mask / dropout_p in a combination the mask kernels do not take (head dim above 256, a per-row bias at head dim 256 with a gradient wanted, fp32, attn_mask with is_causal, a mask "
+        _handoff("attn_mask / dropout_p in a combination the mask kernels do not take (head dim above 256, fp32, attn_mask with is_causal, a mask "
                  "that wants a gradient or does not broadcast to [B, H, L, L], dropout traced before init_graph_dropout_state())")
         if query.shape[-1] != D_true:
             query, key, value = (t[..., :D_true] for t in (query, key, value))

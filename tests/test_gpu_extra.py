@@ -104,6 +104,44 @@ def test_masked_forward_and_backward_vs_oracle(kind, dtype, D, B, H, Hkv, L):
             _grad_close(got, want, f"{name} {kind} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
 
 
+@pytest.mark.parametrize("kind", ["bias_BHLL", "bias_1HLL", "bool_LL"])
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 256), (torch.float16, 232), (torch.bfloat16, 128)])
+@pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 1, 1284), (2, 2, 2, 448), (1, 4, 2, 64), (1, 1, 1, 129)])
+def test_masked_backward_under_the_causal_mask_vs_oracle(kind, dtype, D, B, H, Hkv, L):
+    """fa_bwd_ex with a mask AND the causal mask (the C ABI takes both; the override hands that pair to stock SDPA, as torch rejects it): at
+    head_dim 256 a wave of dK/dV keeps the bias of its own 32 keys in a private ring of half-item pieces, and a wave whose keys lie past a query
+    tile's rows - or past its first row half - skips those reads but must still request the pieces that follow; one-item and two-item
+    sweeps, a ragged last key block, grouped K/V heads."""
+    from flash_attention_amd._impl import ops
+    from oracle import dense_attention_extra, frozen_randn
+
+    gen = torch.Generator().manual_seed(SEED + 3 * L + H)
+    q = (frozen_randn(SEED + L, (B, H, L, D)) * 0.6).to(dtype)
+    k = (frozen_randn(SEED + L + 1, (B, Hkv, L, D)) * 0.6).to(dtype)
+    v = (frozen_randn(SEED + L + 2, (B, Hkv, L, D)) * 0.6).to(dtype)
+    g = frozen_randn(SEED + L + 3, (B, H, L, D)).to(dtype)
+    mask = _masks(kind, B, H, L, dtype, gen)
+    if mask.dtype == torch.bool:
+        mask[..., :1] = True            # (every row admits key 0: under the causal mask a row must keep a key of its past)
+    else:
+        mask = mask.clone()
+        mask[..., 0] = 0.0
+    scale = D ** -0.5
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, _ = dense_attention_extra(qr, kr, vr, scale, True, mask)
+    ref.backward(g.double())
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    mc = mask.cuda().expand(B, H, L, L)
+    mc = mc.view(torch.uint8) if mc.dtype == torch.bool else mc
+    if mc.stride(-1) != 1:
+        mc = mc.contiguous()
+    out = ops.attention_extra(qc, kc, vc, mc, scale, True)
+    _fwd_close(out, ref.detach(), f"masked causal forward {kind} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
+    out.backward(g.cuda())
+    for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
+        _grad_close(got, want, f"{name} causal {kind} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
+
+
 @pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 64), (torch.float16, 128), (torch.bfloat16, 192)])
 def test_key_padding_with_a_batch_entry_that_keeps_no_key_and_tiles_that_keep_none(dtype, D):
     """A key-padding mask whose first batch entry keeps NO key (every tile of it is skipped by the staged-terms path: its rows are NaN with
@@ -224,14 +262,20 @@ def test_override_serves_wide_head_masks_with_and_without_a_gradient(monkeypatch
     assert len(calls) == 2                          # ... and again for the call that wants a gradient
     for a, b in zip(*grads):
         assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item())
-    # one combination stays stock SDPA's: a bias that differs from row to row, head_dim 256, gradient wanted (its tile images do not fit
-    # beside the backward's operand images; with in-place loads fa_bwd_ex is slower than stock there) - served here under no_grad only
+    # a bias that differs from row to row, head_dim 256, gradient wanted - stock SDPA's until round 6 (two 16 KB tile images do not fit beside the
+    # backward's 128 KB of operand images): each wave of dK/dV now keeps the bias of its own 32 keys in a private ring of half-item pieces
     bias = torch.randn(1, H, L, L, device="cuda", dtype=torch.bfloat16)
-    qg = q.clone().requires_grad_(True)
-    assert torch.equal(F.scaled_dot_product_attention(qg, k, v, attn_mask=bias), stock(qg, k, v, attn_mask=bias)) and len(calls) == 2
+    grads = []
+    for fn, cast in ((F.scaled_dot_product_attention, lambda t: t), (stock, lambda t: t.float())):
+        qg, kg, vg = (cast(t).clone().requires_grad_(True) for t in (q, k, v))
+        fn(qg, kg, vg, attn_mask=cast(bias)).backward(cast(g))
+        grads.append((qg.grad.float(), kg.grad.float(), vg.grad.float()))
+    assert len(calls) == 3
+    for a, b in zip(*grads):
+        assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item())
     with torch.no_grad():
         F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
-    assert len(calls) == 3
+    assert len(calls) == 4
 
 
 @pytest.mark.parametrize("causal", [True, False])
