@@ -148,11 +148,16 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     // padded tail) is skipped by the whole workgroup.
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     constexpr int MIMG_B = MM == 3 ? 16384 : 8192, MT_F = 80;
-    constexpr bool MDMA = !(D == 256 && MM == 3);    // (head_dim 256: K / V fill 132 KB - two 16 KB bias images do not fit beside them: that bias is loaded in place)
-    __shared__ __attribute__((aligned(16))) unsigned char smem_mk[EXTRA ? (MM >= 2 ? (MDMA ? 2 * MIMG_B : 16) : 2 * MT_F * 4) : 16];
+    // (head_dim 256: K / V fill 132 KB - two 16 KB bias images do not fit beside them.  There every wave keeps the bias of ITS 32 rows only, in half-tile
+    //  pieces - 32 rows x 32 keys x 2 B = 2 KB - that travel through a wave-private ring of three: half k of the (tile, key half) sequence lives in slot
+    //  k % 3; the first half of tile t + 1 is requested with that tile's K / V, its second half as soon as the wave has read tile t's bias (it takes the
+    //  slot of tile t's first half): 24 KB in all, and no barrier of its own - a wave is the only writer and the only reader of its ring.)
+    constexpr bool MPRIV = EXTRA && D == 256 && MM == 3;
+    constexpr int MHALF_B = 2048, MRING_B = 3 * MHALF_B;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_mk[EXTRA ? (MM >= 2 ? (MPRIV ? NWAVES * MRING_B : 2 * MIMG_B) : 2 * MT_F * 4) : 16];
     float* const mterm = (float*)smem_mk;
     constexpr bool mbias = MM == 3;
-    const bool mdma = EXTRA && MM >= 2 && MDMA && mask_g != nullptr && (p.ex.mask_vec & 2) != 0;
+    const bool mdma = EXTRA && MM >= 2 && mask_g != nullptr && (p.ex.mask_vec & 2) != 0;
     const bool mbc = EXTRA && MM == 0 && mask_g != nullptr;
     static_assert(!EXTRA || (QB == 1 && SPLIT == 1 && NWAVES == 4), "mask staging: one 32-row block per wave, unsplit 4-wave workgroups");
     unsigned m_vo[(EXTRA && MM >= 2) ? 4 : 1];
@@ -160,7 +165,17 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     float mt_stage = 0.f;
     (void)mterm; (void)mdma; (void)mbc; (void)m_vo; (void)m_rd; (void)mt_stage;
 #define FA_MASK_GEOM(QI_)                                                                          \
-    if constexpr (EXTRA && MM >= 2) {                                                              \
+    if constexpr (MPRIV) {   /* piece i of a half = rows 16 i .. + 15 of the wave (64 B a row, lane-linear in LDS): 16-byte chunk c of row-slot s sits at \
+                                chunk position c ^ (s >> 2) - the 16 rows one read instruction covers per half-wave then spread over all banks */ \
+        const unsigned m_slb_ = (unsigned)p.ex.m_sl * (unsigned)mask_esz;                          \
+        const int rl_ = L - 1 - (QI_) * BQ;          /* (rows past L: the last row again - they are never stored) */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                         \
+            const int row = wave * 32 + 16 * i_ + (lane >> 2);                                     \
+            m_vo[i_] = (unsigned)(row < rl_ ? row : rl_) * m_slb_ + ((unsigned)((lane & 3) ^ (lane >> 4)) << 4); \
+        }                                                                                          \
+        m_vo[2] = m_vo[3] = 0u;                                                                    \
+        m_rd = wave * MRING_B + r * 64 + (((r >> 2) & 3) << 4) + 8 * h;                            \
+    } else if constexpr (EXTRA && MM >= 2) {                                                       \
         const unsigned m_slb_ = (unsigned)p.ex.m_sl * (unsigned)mask_esz;                          \
         const int rl_ = L - 1 - (QI_) * BQ;          /* (rows past L: the last row again - they are never stored) */ \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
@@ -172,8 +187,25 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         const int il = wave * 32 + r;                                                              \
         m_rd = mbias ? il * 128 + (((il >> 1) & 7) << 4) + 8 * h : il * 64 + (((il >> 2) & 3) << 4) + 4 * h; \
     }
+    /* MPRIV: half HALF_ (keys 32 HALF_ .. + 31) of tile T_ -> ring slot (2 T_ + HALF_) % 3; the wave's own reads of the slot's tenant are drained first */ \
+#define FA_DMA_MHALF(QI_, T_, HALF_)                                                               \
+    if constexpr (MPRIV) {                                                                         \
+        if (mdma && wave_active) {                                                                 \
+            const int c0_ = (T_) * BK + 32 * (HALF_);                                              \
+            const char* mb_ = mask_g + ((int64_t)((QI_) * BQ) * p.ex.m_sl + c0_) * mask_esz;       \
+            const int64_t left_ = ((int64_t)(L - 1 - (QI_) * BQ) * p.ex.m_sl + (L - c0_)) * mask_esz;   /* to the end of the slice's last row (<= 0: a half past L - zeros) */ \
+            i32x4 mr_ = make_raw_rsrc(mb_, left_ <= 0 ? 0u : left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu); \
+            _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   \
+            const unsigned dst_ = lds_offset(smem_mk) + wave * MRING_B + ((2 * (T_) + (HALF_)) % 3) * MHALF_B; \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+            lds_dma_b128(mr_, dst_, m_vo[0]);                                                      \
+            lds_dma_b128(mr_, dst_ + 1024, m_vo[1]);                                               \
+        }                                                                                          \
+    }
 #define FA_DMA_MASKTILE(QI_, T_, BUF_)                                                             \
-    if constexpr (EXTRA && MM >= 2) {                                                              \
+    if constexpr (MPRIV) {   /* the tile's first half; its second half follows the wave's reads of tile T_ - 1 (FA_COMPUTE) */ \
+        FA_DMA_MHALF(QI_, T_, 0)                                                                   \
+    } else if constexpr (EXTRA && MM >= 2) {                                                       \
         if (mdma) {                                                                                \
             const char* mb_ = mask_g + ((int64_t)((QI_) * BQ) * p.ex.m_sl + (T_) * BK) * mask_esz; \
             const int64_t left_ = ((int64_t)(L - 1 - (QI_) * BQ) * p.ex.m_sl + (L - (T_) * BK)) * mask_esz;   /* to the end of the slice's last row */ \
@@ -324,6 +356,21 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                     const f32x4_ a0_ = *(const f32x4_*)(mt_ + 8 * j), a1_ = *(const f32x4_*)(mt_ + 32 + 8 * j); \
                     _Pragma("unroll") for (int i = 0; i < 4; ++i) { s0[0][4 * j + i] += a0_[i]; s1[0][4 * j + i] += a1_[i]; } \
                 }                                                                                  \
+            } else if (MPRIV && mdma) {   /* this lane's row of the wave's two halves (ring slots (2 tile), (2 tile + 1) % 3) */ \
+                const unsigned char* mi0_ = smem_mk + ((2 * (kv0 / BK)) % 3) * MHALF_B;            \
+                const unsigned char* mi1_ = smem_mk + ((2 * (kv0 / BK) + 1) % 3) * MHALF_B;        \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
+                    const vec4 b0_ = __builtin_bit_cast(vec4, *(const u32x2*)(mi0_ + (m_rd ^ (j << 4)))); \
+                    const vec4 b1_ = __builtin_bit_cast(vec4, *(const u32x2*)(mi1_ + (m_rd ^ (j << 4)))); \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
+                        s0[0][4 * j + i] += bias_term((float)b0_[i], p.ex.inv_scale);              \
+                        s1[0][4 * j + i] += bias_term((float)b1_[i], p.ex.inv_scale);              \
+                    }                                                                              \
+                }                                                                                  \
+                if ((kv0 / BK) + tstride < n_tiles) {   /* the first half's slot is read: the next tile's second half takes it */ \
+                    FA_DMA_MHALF(qi, kv0 / BK + tstride, 1)                                        \
+                    mh_sent_ = true;                                                               \
+                }                                                                                  \
             } else if (MM >= 2 && mdma) {   /* this lane's row of the tile image */                \
                 const unsigned char* mi_ = smem_mk + (BUF_) * MIMG_B;                              \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                    \
@@ -445,6 +492,8 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #define FA_COMPUTE(T_, BUF_, MODE_)                                                                \
     {                                                                                              \
         const int kv0 = (T_) * BK;                                                                 \
+        bool mh_sent_ = false;   /* (MPRIV) the next tile's second bias half is on its way */       \
+        (void)mh_sent_;                                                                            \
         if (wave_active && (SPLIT == 1 || (T_) < n_tiles) && kv0 <= wave_kv_last && !FA_TILE_DEAD(BUF_)) { \
             f32x16 s0[QB], s1[QB];                                                                 \
             if (FA_DMA_ABL != 5) { FA_QK(BUF_) } else {                                            \
@@ -462,11 +511,14 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
                     _Pragma("unroll") for (int e = 0; e < 16; ++e) { o[b][0][e] += s0[b][e]; o[b][1][e] += s1[b][e]; } \
             }                                                                                      \
         }                                                                                          \
+        if constexpr (MPRIV) {   /* (a wave that skipped this tile sends the next tile's second half here) */ \
+            if (!mh_sent_ && (T_) + tstride < n_tiles) { FA_DMA_MHALF(qi, (T_) + tstride, 1) }     \
+        }                                                                                          \
     }
     // one pass over the workgroup's kv tiles (the kv loop is unrolled by two: LDS addresses are base + immediate)
 #define FA_PASS(MODE_)                                                                             \
     {                                                                                              \
-        if (!tile0_requested && (SPLIT == 1 || tfirst < n_tiles)) { FA_MTERM_LOAD(tfirst) FA_DMA_TILE(tfirst, 0) FA_DMA_MASKTILE(qi, tfirst, 0) FA_MTERM_STORE(0) } \
+        if (!tile0_requested && (SPLIT == 1 || tfirst < n_tiles)) { FA_MTERM_LOAD(tfirst) FA_DMA_TILE(tfirst, 0) FA_DMA_MASKTILE(qi, tfirst, 0) FA_DMA_MHALF(qi, tfirst, 1) FA_MTERM_STORE(0) } \
         tile0_requested = false;                                                                   \
         FA_TILE_BARRIER()                                                                          \
         if (pass == 0) FA_STAMP(st1_)                                                              \
@@ -635,6 +687,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
 #undef FA_MASK_GEOM
 #undef FA_TILE_DEAD
 #undef FA_DMA_MASKTILE
+#undef FA_DMA_MHALF
 #undef FA_MTERM_LOAD
 #undef FA_MTERM_STORE
 #undef FA_TILE_BARRIER

@@ -207,7 +207,7 @@ def test_mask_that_is_a_strided_view_equals_its_contiguous_copy(kind, causal):
 def test_masked_forward_at_head_dims_up_to_256_vs_oracle(kind, dtype, D, B, H, Hkv, L, causal):
     """fa_fwd_ex at head_dim 192 / 256 and at dims that run zero-extended at them (160, 232): the forward's mask kernels take every head dim
     the plain forward takes.  Boolean
-    masks and biases through the LDS-DMA tile images (at 256 a bias is loaded in place: the images do not fit beside 132 KB of K / V
+    masks and biases through the LDS-DMA tile images (at 256 a bias through wave-private rings of half-tile pieces: two images do not fit beside 132 KB of K / V
     tiles), row-broadcast masks through the staged key terms, with and without the causal mask underneath, grouped K/V heads."""
     from flash_attention_amd._impl import ops
     from oracle import dense_attention_extra, frozen_randn
