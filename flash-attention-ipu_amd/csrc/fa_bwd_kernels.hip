@@ -302,7 +302,7 @@ __device__ __forceinline__ void fa_bwd_dq_body(const BwdParams& p) {
     unsigned long long m_at = 0, m_left = 0;
     if constexpr (EXTRA >= 2) {
         m_at = (unsigned long long)((const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)hh * p.ex.m_sh + (int64_t)(qi * BQ) * p.ex.m_sl) * mask_esz);
-        m_left = (unsigned long long)(((int64_t)(L - 1 - qi * BQ) * p.ex.m_sl + L) * mask_esz);
+        m_left = (unsigned long long)((((int64_t)(L - 1 - qi * BQ) * p.ex.m_sl + L) * mask_esz + 3) & ~3ll);   // (whole dwords: fa_fwd_dma.hip FA_MASK_EXTENT)
         m_at = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m_at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m_at);
         m_left = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m_left >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m_left);
     }
@@ -807,7 +807,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             FA_ITEM(jm_, hqm_, itm_)                                                               \
             const int q0m_ = itm_ * BQ, rl_ = L - 1 - q0m_;                                        \
             const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqm_) * p.ex.m_sh + (int64_t)q0m_ * p.ex.m_sl + kb * BKW + wave * 32) * mask_esz; \
-            const int64_t left_ = ((int64_t)rl_ * p.ex.m_sl + (L - kb * BKW - wave * 32)) * mask_esz;   /* to the end of the slice's last row (> 0: the wave is active) */ \
+            const int64_t left_ = (((int64_t)rl_ * p.ex.m_sl + (L - kb * BKW - wave * 32)) * mask_esz + 3) & ~3ll;   /* to the end of the slice's last row, whole dwords (> 0: the wave is active) */ \
             i32x4 mr_ = make_raw_rsrc(mb_, left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu);   \
             _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   \
             const unsigned dst_ = smem_lds + MOFF + wave * MRING_B + (km_ % 3) * MHALF_B;          \
@@ -826,7 +826,7 @@ __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdParams& p) {
             FA_ITEM(J_, hqm_, itm_)                                                                \
             const int q0m_ = itm_ * BQ, rl_ = L - 1 - q0m_;                                        \
             const char* mb_ = (const char*)p.ex.mask + ((int64_t)bb * p.ex.m_sb + (int64_t)(hq0 + hqm_) * p.ex.m_sh + (int64_t)q0m_ * p.ex.m_sl + kb * BKW) * mask_esz; \
-            const int64_t left_ = ((int64_t)rl_ * p.ex.m_sl + (L - kb * BKW)) * mask_esz;   /* to the end of the slice's last row */ \
+            const int64_t left_ = (((int64_t)rl_ * p.ex.m_sl + (L - kb * BKW)) * mask_esz + 3) & ~3ll;   /* to the end of the slice's last row, whole dwords (fa_fwd_dma.hip FA_MASK_EXTENT) */ \
             i32x4 mr_ = make_raw_rsrc(mb_, left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu);   \
             _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   /* (64-bit products leave the scalar unit) */ \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \

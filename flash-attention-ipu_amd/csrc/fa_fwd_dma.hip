@@ -187,13 +187,18 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
         const int il = wave * 32 + r;                                                              \
         m_rd = mbias ? il * 128 + (((il >> 1) & 7) << 4) + 8 * h : il * 64 + (((il >> 2) & 3) << 4) + 4 * h; \
     }
-    /* MPRIV: half HALF_ (keys 32 HALF_ .. + 31) of tile T_ -> ring slot (2 T_ + HALF_) % 3; the wave's own reads of the slot's tenant are drained first */ \
+    // FA_MASK_EXTENT: a mask tile's descriptor ends with the slice's last row - rounded UP to whole dwords: the range check of a buffer load is per
+    // dword, and with L odd (a bias; L % 4 != 0 for a boolean mask) the last key of the last row shares its dword with the element after it - cut
+    // exactly at L that dword read as zero (bias[L-1][L-1] lost, the last row's last keys masked out: found by tests/tools/fuzz_extra.py on a strided
+    // view).  Pointer and strides are multiples of four elements here (mask_vec), so the dword is aligned and belongs to the allocation; keys >= L are
+    // masked by the ragged-tile path.
+    // MPRIV: half HALF_ (keys 32 HALF_ .. + 31) of tile T_ -> ring slot (2 T_ + HALF_) % 3; the wave's own reads of the slot's tenant are drained first
 #define FA_DMA_MHALF(QI_, T_, HALF_)                                                               \
     if constexpr (MPRIV) {                                                                         \
         if (mdma && wave_active) {                                                                 \
             const int c0_ = (T_) * BK + 32 * (HALF_);                                              \
             const char* mb_ = mask_g + ((int64_t)((QI_) * BQ) * p.ex.m_sl + c0_) * mask_esz;       \
-            const int64_t left_ = ((int64_t)(L - 1 - (QI_) * BQ) * p.ex.m_sl + (L - c0_)) * mask_esz;   /* to the end of the slice's last row (<= 0: a half past L - zeros) */ \
+            const int64_t left_ = (((int64_t)(L - 1 - (QI_) * BQ) * p.ex.m_sl + (L - c0_)) * mask_esz + 3) & ~3ll;   /* to the end of the slice's last row in whole dwords, FA_MASK_EXTENT (<= 0: a half past L - zeros) */ \
             i32x4 mr_ = make_raw_rsrc(mb_, left_ <= 0 ? 0u : left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu); \
             _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   \
             const unsigned dst_ = lds_offset(smem_mk) + wave * MRING_B + ((2 * (T_) + (HALF_)) % 3) * MHALF_B; \
@@ -208,7 +213,7 @@ __device__ __forceinline__ void fa_fwd_dma_body(const FwdParams& p) {
     } else if constexpr (EXTRA && MM >= 2) {                                                       \
         if (mdma) {                                                                                \
             const char* mb_ = mask_g + ((int64_t)((QI_) * BQ) * p.ex.m_sl + (T_) * BK) * mask_esz; \
-            const int64_t left_ = ((int64_t)(L - 1 - (QI_) * BQ) * p.ex.m_sl + (L - (T_) * BK)) * mask_esz;   /* to the end of the slice's last row */ \
+            const int64_t left_ = (((int64_t)(L - 1 - (QI_) * BQ) * p.ex.m_sl + (L - (T_) * BK)) * mask_esz + 3) & ~3ll;   /* to the end of the slice's last row (whole dwords) */ \
             i32x4 mr_ = make_raw_rsrc(mb_, left_ < 0xffffffffll ? (unsigned)left_ : 0xffffffffu);   \
             _Pragma("unroll") for (int w_ = 0; w_ < 3; ++w_) mr_[w_] = __builtin_amdgcn_readfirstlane(mr_[w_]);   /* (64-bit products leave the scalar unit) */ \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                          \

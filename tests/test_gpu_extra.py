@@ -104,6 +104,48 @@ def test_masked_forward_and_backward_vs_oracle(kind, dtype, D, B, H, Hkv, L):
             _grad_close(got, want, f"{name} {kind} {dtype} {B}x{H}/{Hkv}x{L}x{D}")
 
 
+@pytest.mark.parametrize("kind", ["bool", "bias"])
+@pytest.mark.parametrize("dtype,D", [(torch.float16, 64), (torch.bfloat16, 128), (torch.bfloat16, 256), (torch.float16, 192)])
+@pytest.mark.parametrize("L,pad,off", [(115, 5, 4), (115, 5, 0), (201, 7, 8), (126, 2, 4), (333, 3, 12)])
+def test_mask_view_with_padded_rows_and_a_length_that_ends_inside_a_dword_vs_oracle(kind, dtype, D, L, pad, off):
+    """A mask that is a view of a buffer with padded rows: row stride and pointer multiples of four elements (the LDS-DMA tile images), L not - the
+    last key of the last row then shares its dword with the element after it.  Found by tests/tools/fuzz_extra.py in round 6: the tile's
+    buffer descriptor ended exactly at key L - 1 of the slice's last row, the per-dword range check zeroed that dword, and bias[L-1][L-1] (a
+    boolean mask: up to three keys of the last row) was lost in the forward and in all three gradients.  The extent now covers whole dwords."""
+    from flash_attention_amd._impl import ops
+    from oracle import dense_attention_extra, frozen_randn
+
+    B, H, Hkv = 2, 2, 1
+    assert (L + pad) % 4 == 0 and off % 4 == 0 and L % 4 != 0
+    gen = torch.Generator().manual_seed(SEED + L + D)
+    q = (frozen_randn(SEED + L, (B, H, L, D)) * 0.6).to(dtype)
+    k = (frozen_randn(SEED + L + 1, (B, Hkv, L, D)) * 0.6).to(dtype)
+    v = (frozen_randn(SEED + L + 2, (B, Hkv, L, D)) * 0.6).to(dtype)
+    g = frozen_randn(SEED + L + 3, (B, H, L, D)).to(dtype)
+    if kind == "bool":
+        big = torch.rand(1, H, L + 1, L + pad + off, generator=gen) < 0.6
+        big[..., off] = True                     # (every row keeps its first key)
+        big[..., -1, off + L - 3:off + L] = True   # the keys in question are admitted, and carry weight: their scores are the row's largest
+    else:
+        big = (0.8 * torch.randn(1, H, L + 1, L + pad + off, generator=gen)).to(dtype)
+        big[..., -1, off + L - 1] = 3.0          # the element in question matters: the last row's largest term
+    view = big[:, :, 1:1 + L, off:off + L]
+    scale = D ** -0.5
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, _ = dense_attention_extra(qr, kr, vr, scale, False, view)
+    ref.backward(g.double())
+    bc = big.cuda()
+    mc = bc[:, :, 1:1 + L, off:off + L].expand(B, H, L, L)
+    mc = mc.view(torch.uint8) if mc.dtype == torch.bool else mc
+    assert mc.stride(-2) % 4 == 0 and mc.stride(-1) == 1
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = ops.attention_extra(qc, kc, vc, mc, scale, False)
+    _fwd_close(out, ref.detach(), f"mask view {kind} {dtype} L={L} D={D} pad={pad} off={off}")
+    out.backward(g.cuda())
+    for name, got, want in (("dq", qc.grad, qr.grad), ("dk", kc.grad, kr.grad), ("dv", vc.grad, vr.grad)):
+        _grad_close(got, want, f"{name} mask view {kind} {dtype} L={L} D={D}")
+
+
 @pytest.mark.parametrize("kind", ["bias_BHLL", "bias_1HLL", "bool_LL"])
 @pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 256), (torch.float16, 232), (torch.bfloat16, 128)])
 @pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 1, 1284), (2, 2, 2, 448), (1, 4, 2, 64), (1, 1, 1, 129)])
