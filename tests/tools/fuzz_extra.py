@@ -1,6 +1,6 @@
 """Developer aid (test infrastructure): differential fuzz of the mask / bias kernels (fa_fwd_ex / fa_bwd_ex through ops.attention_extra).
 Random shapes, head dims 64 .. 256 (native and zero-extended), dtypes, grouped-query head counts, with and without the causal mask underneath,
-every mask kind a caller may pass - boolean / additive, [L, L], [B, H, L, L], [1, H, L, L], key padding, a per-key bias, strided views with
+every mask kind a caller may pass, with and without dropout (the keep decisions are oracle/dropout.py's) - boolean / additive, [L, L], [B, H, L, L], [1, H, L, L], key padding, a per-key bias, strided views with
 strides that are and are not multiples of four elements (LDS-DMA tile images / wave-private rings at head_dim 256 / element loads) - against
 autograd through the dense fp64 expression of oracle/dropout.py (dense_attention_extra) on the same 16-bit-rounded inputs; out, and all three
 gradients; every call twice (bit-reproducible).
@@ -65,25 +65,31 @@ def fuzz(cases, seed, log=print):
         H = Hkv * rng.choice([1, 1, 2])
         dtype = rng.choice([torch.bfloat16, torch.float16])
         causal = rng.random() < 0.3
-        kind = rng.choice(["bool_LL", "bool_BHLL", "bool_padding", "bias_BHLL", "bias_1HLL", "bias_1HLL", "bias_key", "bias_view", "bias_view"])
+        kind = rng.choice(["bool_LL", "bool_BHLL", "bool_padding", "bias_BHLL", "bias_1HLL", "bias_1HLL", "bias_key", "bias_view", "bias_view", "none"])
+        drop = rng.choice([0.0, 0.0, 0.0, 0.1, 0.3, 0.5]) if kind != "none" else rng.choice([0.1, 0.25, 0.5])
+        if drop > 0.0:               # (the oracle takes its keep decisions element by element in numpy: short sequences)
+            L = min(L, rng.randint(1, 450))
+        dseed, doff = rng.getrandbits(62), 4 * rng.randint(0, 1 << 20)
         gen = torch.Generator(device=dev).manual_seed(seed * 100003 + case)
         q, k, v = ((torch.randn(B, h, L, D, device=dev, generator=gen) * 0.6).to(dtype) for h in (H, Hkv, Hkv))
         g = torch.randn(B, H, L, D, device=dev, generator=gen).to(dtype)
-        mask = make_mask(rng, gen, kind, B, H, L, dtype)
+        mask = make_mask(rng, gen, kind, B, H, L, dtype) if kind != "none" else None
         scale = D ** -0.5
-        what = f"case {case}: [{B},{H}/{Hkv},{L},{D}] {str(dtype).split('.')[-1]} causal={causal} {kind} strides={tuple(mask.stride())}"
+        what = f"case {case}: [{B},{H}/{Hkv},{L},{D}] {str(dtype).split('.')[-1]} causal={causal} {kind} p={drop} strides={tuple(mask.stride()) if mask is not None else None}"
         try:
             qr, kr, vr = (t.cpu().double().requires_grad_(True) for t in (q, k, v))      # (the oracle runs on the host)
-            ref, _ = dense_attention_extra(qr, kr, vr, scale, causal, mask.cpu())
+            ref, _ = dense_attention_extra(qr, kr, vr, scale, causal, mask.cpu() if mask is not None else None, drop, dseed, doff)
             ref.backward(g.cpu().double())
-            mc = mask.expand(B, H, L, L)
-            mc = mc.view(torch.uint8) if mc.dtype == torch.bool else mc
-            if mc.stride(-1) != 1:
-                mc = mc.contiguous()
+            mc = None
+            if mask is not None:
+                mc = mask.expand(B, H, L, L)
+                mc = mc.view(torch.uint8) if mc.dtype == torch.bool else mc
+                if mc.stride(-1) != 1:
+                    mc = mc.contiguous()
             runs = []
             for _ in range(2):
                 qc, kc, vc = (t.clone().requires_grad_(True) for t in (q, k, v))
-                out = ops.attention_extra(qc, kc, vc, mc, scale, causal)
+                out = ops.attention_extra(qc, kc, vc, mc, scale, causal, drop, dseed, doff)
                 out.backward(g)
                 runs.append((out.detach(), qc.grad, kc.grad, vc.grad))
             ok = all(torch.equal(a, b) for a, b in zip(*runs))
