@@ -59,7 +59,17 @@ def fuzz(cases, seed, log=print):
         scale = rng.choice([D ** -0.5, D ** -0.5, 1.0 if D <= 64 else D ** -0.5])
         mag = 0.6 if scale < 1.0 else 0.25
         gen = torch.Generator(device=dev).manual_seed(seed * 100003 + case)
-        what = f"case {case}: [{B},{H}/{Hkv},{L},{D}] {str(dtype).split('.')[-1]} causal={causal} head_inner={head_inner} aligned={aligned} scale={scale:.4f}"
+        # every third case forces a kernel family / workgroup form (the library's constraint pass turns what a shape cannot launch into what it
+        # can) and the backward's split forms: the same checks must hold on every path, not only on the rules' choice
+        knobs = {}
+        if case % 3 == 2 and dtype != torch.float32:
+            knobs = dict(rng.choice([dict(kernel="dma", waves=4), dict(kernel="dma", waves=8), dict(kernel="dma", waves=2), dict(kernel="dma", waves=4, qb=2),
+                                     dict(kernel="dma", waves=4, split=2), dict(kernel="dma", waves=4, split=4), dict(kernel="dma", waves=4, pair=1),
+                                     dict(kernel="pipe", waves=4, qb=2), dict(kernel="pipe", waves=2), dict(kernel="pipe", waves=1), dict(kernel="pipe16", waves=4),
+                                     dict(kernel="pipe16", waves=8), dict(kernel="kh"), dict(kernel="kh", split=2), dict(subsets=0), dict(balance=1)]))
+            knobs.update(bsplit=rng.choice([-1, 2, 3]), bbal=rng.choice([-1, 1]))
+        what = (f"case {case}: [{B},{H}/{Hkv},{L},{D}] {str(dtype).split('.')[-1]} causal={causal} head_inner={head_inner} aligned={aligned} scale={scale:.4f}"
+                + (f" knobs={knobs}" if knobs else ""))
         try:
             ops_ = {}
             for name, h in (("q", H), ("k", Hkv), ("v", Hkv), ("g", H)):
@@ -78,8 +88,9 @@ def fuzz(cases, seed, log=print):
                 out, dq, dk, dv = (res[n][0] for n in ("out", "dq", "dk", "dv"))
                 lse = torch.full((B * H, L), SENT, device=dev, dtype=torch.float32)
                 st = lambda t: (t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
-                _native.fwd_strided(q, k, v, out, lse, B * H, L, D, H, st(q), st(k), st(v), st(out), 1, 1, scale, causal, heads_kv=Hkv)
-                _native.bwd(q, k, v, out, g, lse, dq, dk, dv, B * H, L, D, H, scale, causal, heads_kv=Hkv)
+                with _native.debug_options(**knobs):
+                    _native.fwd_strided(q, k, v, out, lse, B * H, L, D, H, st(q), st(k), st(v), st(out), 1, 1, scale, causal, heads_kv=Hkv)
+                    _native.bwd(q, k, v, out, g, lse, dq, dk, dv, B * H, L, D, H, scale, causal, heads_kv=Hkv)
                 torch.cuda.synchronize()
                 runs.append((res, lse))
             ok, why = True, ""
