@@ -239,6 +239,9 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* out, const v
  *                   FA_MASK_BOOL: bytes, non-zero = the key takes part;  FA_MASK_BIAS: values of the operand dtype, added to
  *                   softmax_scale * (q . k) - use -inf to exclude a key.  A row that excludes every key returns NaN (as torch
  *                   does) and lse = -inf.  May be combined with causal = 1.  No gradient is computed for a bias.
+ *                   A mask whose pointer and non-zero strides are multiples of four ELEMENTS travels to LDS in 16-byte pieces; its
+ *                   loads stay inside the aligned 4-byte word that holds the last element of the last row (up to 3 bytes past
+ *                   mask[..][L-1][L-1], never another word); any other mask is read element by element.
  *   dropout_p     : probability in [0, 1) of dropping an attention weight (0 = off); kept weights are scaled by 1 / (1 - p).
  *                   The decision for (g, row, key) is a pure function of (dropout_seed, dropout_offset, g, row, key)
  *                   (csrc/fa_extras.h), so fa_bwd_ex given the same three values regenerates the forward's mask.
