@@ -32,3 +32,14 @@ def test_fuzz_of_the_plain_kernels_on_padded_views():
     msgs = []
     bad = fuzz(60, 6002, log=msgs.append)
     assert bad == 0, "\n".join(m for m in msgs if m.startswith("BAD"))
+
+
+def test_fuzz_of_the_sdpa_override_against_stock_sdpa():
+    """tests/tools/fuzz_override.py: every routing decision of the `F.scaled_dot_product_attention` override (HIP kernels, zero-extended and padded
+    head dims, mask kernels, generic kernel, hand-off to stock) gives stock SDPA's fp64 result and gradients; where it raises, it is the
+    reference's chunk guard (fa.py:28-35 via sdpa.py:52-53) and nothing else."""
+    from fuzz_override import fuzz
+
+    msgs = []
+    bad = fuzz(60, 6003, log=msgs.append)
+    assert bad == 0, "\n".join(m for m in msgs if m.startswith("BAD"))
